@@ -1,0 +1,79 @@
+"""Build recipes for the native parts (run here without a GPU: hipcc cross-compiles).
+
+    python -m flake_amd.build            # everything
+    python -m flake_amd.build hip host   # selected targets
+
+Targets
+  hip   flake_amd/lib/libflakehip.so   gfx950 kernels + C ABI (include/flakehip.h)
+  host  flake_amd/lib/libflake_amd.so  host C layer (include/flake_amd.h) on top of it
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "flake_amd")
+LIB = os.path.join(PKG, "lib")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+HIP_SRCS = ["csrc/kernels.hip", "csrc/api.hip"]
+HIP_DEPS = HIP_SRCS + ["csrc/kernels.h", "../include/flakehip.h"]
+HOST_SRCS = ["host/flake_host.c", "host/synth.c", "host/md5.c"]
+HOST_DEPS = HOST_SRCS + ["../include/flakehip.h", "../include/flake_amd.h"]
+
+# -ffp-contract=off is load-bearing: the fp64 LPC stages must round after every
+# multiply and add to reproduce the reference bit for bit.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
+             "-std=c++17", "-fvisibility=hidden", "-fgpu-rdc" if False else ""]
+HIP_FLAGS = [f for f in HIP_FLAGS if f]
+
+
+def _stale(out: str, deps: list[str]) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.exists(os.path.join(PKG, d)) and os.path.getmtime(os.path.join(PKG, d)) > t
+               for d in deps)
+
+
+def _run(cmd: list[str]) -> None:
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def build_hip(force: bool = False, extra: list[str] | None = None) -> str:
+    out = os.path.join(LIB, "libflakehip.so")
+    if force or _stale(out, HIP_DEPS):
+        os.makedirs(LIB, exist_ok=True)
+        _run([HIPCC, *HIP_FLAGS, *(extra or []), "-I", os.path.join(ROOT, "include"),
+              "-I", os.path.join(PKG, "csrc"),
+              *[os.path.join(PKG, s) for s in HIP_SRCS], "-o", out])
+    return out
+
+
+def build_host(force: bool = False) -> str:
+    out = os.path.join(LIB, "libflake_amd.so")
+    srcs = [os.path.join(PKG, s) for s in HOST_SRCS if os.path.exists(os.path.join(PKG, s))]
+    if not srcs:
+        return ""
+    if force or _stale(out, HOST_DEPS):
+        os.makedirs(LIB, exist_ok=True)
+        _run(["gcc", "-std=gnu99", "-O2", "-Wall", "-fPIC", "-shared", "-fvisibility=hidden",
+              "-I", os.path.join(ROOT, "include"), *srcs, "-o", out,
+              "-L", LIB, "-lflakehip", "-Wl,-rpath,$ORIGIN", "-lm"])
+    return out
+
+
+def build_all(force: bool = False) -> None:
+    build_hip(force)
+    build_host(force)
+
+
+if __name__ == "__main__":
+    targets = sys.argv[1:] or ["hip", "host"]
+    if "hip" in targets:
+        build_hip(force=True, extra=["-Rpass-analysis=kernel-resource-usage"] if os.environ.get("FHIP_REMARKS") else None)
+    if "host" in targets:
+        build_host(force=True)

@@ -1,0 +1,463 @@
+// api.hip -- the C ABI of libflakehip.so (include/flakehip.h) on top of the
+// gfx950 kernels.  No allocation happens after fhip_create(); every entry
+// point maps HIP failures to FHIP_E_HIP and never throws.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "flakehip.h"
+#include "kernels.h"
+
+struct fhip_ctx {
+    int device = 0;
+    fhip_params p{};
+    int max_frames = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    // device workspaces, sized for max_frames * channels subframes of p.block_size
+    int32_t *d_smp = nullptr;         // [nsub][n]
+    double  *d_autoc = nullptr;       // [nsub][33]
+    int32_t *d_coefs = nullptr;       // [nsub][32][32]
+    int32_t *d_shift = nullptr;       // [nsub][32]
+    int32_t *d_opt = nullptr;         // [nsub]
+    // staging for the host-pointer entry points
+    int32_t *d_pcm = nullptr;
+    fhip_subframe_info *d_info = nullptr;
+    int32_t *d_res = nullptr;
+    uint8_t *d_bits = nullptr;
+    size_t d_bits_bytes = 0;
+
+    bool profiling = false;
+    struct KTime { const char *name; double ms = 0; int launches = 0; };
+    std::vector<KTime> ktimes;
+    struct Pending { int idx; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+
+    std::string err;
+};
+
+namespace {
+
+const char *const kKernelNames[4] = {"k_prepare", "k_autocorr", "k_lpc", "k_encode"};
+
+int fail_hip(fhip_ctx *c, hipError_t e, const char *what)
+{
+    if (c) {
+        c->err = std::string(what) + ": " + hipGetErrorString(e);
+    }
+    (void)hipGetLastError();
+    return FHIP_E_HIP;
+}
+
+int fail(fhip_ctx *c, int code, const char *what)
+{
+    if (c) c->err = what;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                   \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return fail_hip(ctx, e_, #call); \
+    } while (0)
+
+// flake_validate_params(), encode.c:268-373, on the fields we mirror.
+int validate(const fhip_params *p)
+{
+    if (!p) return -1;
+    if (p->channels < 1 || p->channels > FHIP_MAX_CH) return -1;
+    if (p->sample_rate < 1 || p->sample_rate > 655350) return -1;
+    if (p->bits_per_sample < 4 || p->bits_per_sample > 32) return -1;
+    if (p->order_method < 0 || p->order_method > 6) return -1;
+    if (p->stereo_method < 0 || p->stereo_method > 1) return -1;
+    if (p->block_size < 16 || p->block_size > 65535) return -1;
+    if (p->prediction_type < 0 || p->prediction_type > 2) return -1;
+    if (p->min_prediction_order > p->max_prediction_order) return -1;
+    if (p->prediction_type == 1) {
+        if (p->min_prediction_order < 0 || p->min_prediction_order > 4) return -1;
+        if (p->max_prediction_order < 0 || p->max_prediction_order > 4) return -1;
+    } else {
+        if (p->min_prediction_order < 1 || p->min_prediction_order > 32) return -1;
+        if (p->max_prediction_order < 1 || p->max_prediction_order > 32) return -1;
+    }
+    if (p->min_partition_order > p->max_partition_order) return -1;
+    if (p->min_partition_order < 0 || p->min_partition_order > 8) return -1;
+    if (p->max_partition_order < 0 || p->max_partition_order > 8) return -1;
+    if (p->variable_block_size < 0 || p->variable_block_size > 1) return -1;
+    if (p->variable_block_size > 0 && !p->allow_vbs) return -1;
+    if (p->block_size < 128 && p->allow_vbs) return -1;
+    if (p->lpc_precision < 2 || p->lpc_precision > 15) return -1;
+    return 0;
+}
+
+struct Prof {
+    fhip_ctx *c;
+    int idx;
+    hipEvent_t a = nullptr, b = nullptr;
+    Prof(fhip_ctx *ctx, int i) : c(ctx), idx(i)
+    {
+        if (!c->profiling) return;
+        a = take();
+        b = take();
+        if (a && b) (void)hipEventRecord(a, c->stream);
+    }
+    hipEvent_t take()
+    {
+        if (!c->event_pool.empty()) {
+            hipEvent_t e = c->event_pool.back();
+            c->event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    ~Prof()
+    {
+        if (!c->profiling || !a || !b) return;
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back({idx, a, b});
+    }
+};
+
+void drain_profile(fhip_ctx *c)
+{
+    for (auto &pd : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pd.a, pd.b) == hipSuccess) {
+            c->ktimes[pd.idx].ms += ms;
+            c->ktimes[pd.idx].launches += 1;
+        }
+        c->event_pool.push_back(pd.a);
+        c->event_pool.push_back(pd.b);
+    }
+    c->pending.clear();
+}
+
+// The four launches of one batch.  All pointers are device pointers.
+int run_pipeline(fhip_ctx *c, const int32_t *pcm, int nframes, int n,
+                 fhip_subframe_info *info, int32_t *residual, uint8_t *bits,
+                 int64_t slot_bytes, int32_t *samples_out, double *autoc_out)
+{
+    const fhip_params &p = c->p;
+    const int nsub = nframes * p.channels;
+    int32_t *smp = samples_out ? samples_out : c->d_smp;
+    double *autoc = autoc_out ? autoc_out : c->d_autoc;
+    const bool lpc_path = (p.prediction_type == 2) && (n > p.max_prediction_order) && n >= 5;
+
+    {
+        Prof pr(c, 0);
+        HIP_TRY(c, fhip::launch_prepare(c->stream, p, pcm, nframes, n, smp, info));
+    }
+    if (lpc_path) {
+        {
+            Prof pr(c, 1);
+            HIP_TRY(c, fhip::launch_autocorr(c->stream, smp, nsub, n, p.max_prediction_order, autoc));
+        }
+        {
+            Prof pr(c, 2);
+            HIP_TRY(c, fhip::launch_lpc(c->stream, autoc, nsub, p.max_prediction_order,
+                                        p.lpc_precision, p.order_method, c->d_coefs,
+                                        c->d_shift, c->d_opt));
+        }
+    }
+    {
+        Prof pr(c, 3);
+        HIP_TRY(c, fhip::launch_encode(c->stream, p, smp, nsub, n, c->d_coefs, c->d_shift,
+                                       c->d_opt, info, residual, bits, slot_bytes));
+    }
+    return FHIP_OK;
+}
+
+int check_batch(fhip_ctx *c, const fhip_batch *b)
+{
+    if (!c || !b || !b->pcm || !b->info) return fail(c, FHIP_E_INVALID, "null batch argument");
+    if (b->nframes < 0 || b->nframes > c->max_frames)
+        return fail(c, FHIP_E_INVALID, "nframes exceeds the handle's max_frames");
+    if (b->block_size < 1 || b->block_size > c->p.block_size)
+        return fail(c, FHIP_E_INVALID, "block_size out of range (encode.c:987)");
+    if (b->block_size > FHIP_MAX_BLOCK)
+        return fail(c, FHIP_E_UNSUPPORTED, "block_size above FHIP_MAX_BLOCK");
+    if (b->rice_bits && (b->rice_slot_bytes < 4 || (b->rice_slot_bytes & 3)))
+        return fail(c, FHIP_E_INVALID, "rice_slot_bytes must be a positive multiple of 4");
+    return FHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return FHIP_E_HIP;
+    }
+    return n;
+}
+
+const char *fhip_version(void) { return "flake-amd 0.1 (gfx950)"; }
+
+const char *fhip_strerror(int code)
+{
+    switch (code) {
+    case FHIP_OK: return "ok";
+    case FHIP_E_GENERIC: return "generic failure";
+    case FHIP_E_HIP: return "HIP runtime error";
+    case FHIP_E_UNSUPPORTED: return "parameters not supported by the HIP layer";
+    case FHIP_E_INVALID: return "invalid parameters";
+    case FHIP_E_NOMEM: return "out of memory";
+    default: return code > 0 ? "ok" : "unknown error";
+    }
+}
+
+const char *fhip_last_error(const fhip_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int fhip_create(fhip_ctx **out, int device, const fhip_params *p, int max_frames)
+{
+    if (!out) return FHIP_E_INVALID;
+    *out = nullptr;
+    if (validate(p) < 0 || max_frames < 1) return FHIP_E_INVALID;
+    if (p->block_size > FHIP_MAX_BLOCK) return FHIP_E_UNSUPPORTED;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        (void)hipGetLastError();
+        return FHIP_E_HIP;
+    }
+    fhip_ctx *c = new (std::nothrow) fhip_ctx();
+    if (!c) return FHIP_E_NOMEM;
+    c->device = device;
+    c->p = *p;
+    c->max_frames = max_frames;
+    for (int i = 0; i < 4; i++) c->ktimes.push_back({kKernelNames[i], 0.0, 0});
+
+    const size_t nsub = (size_t)max_frames * p->channels;
+    const size_t n = (size_t)p->block_size;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_smp, nsub * n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_autoc, nsub * FHIP_MAX_LAGS * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_coefs, nsub * FHIP_MAX_ORDER * FHIP_MAX_ORDER * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_shift, nsub * FHIP_MAX_ORDER * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_opt, nsub * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_coefs, 0, nsub * FHIP_MAX_ORDER * FHIP_MAX_ORDER * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_shift, 0, nsub * FHIP_MAX_ORDER * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_opt, 0, nsub * sizeof(int32_t));
+    if (e != hipSuccess) {
+        int rc = (e == hipErrorOutOfMemory) ? FHIP_E_NOMEM : FHIP_E_HIP;
+        fhip_destroy(c);
+        (void)hipGetLastError();
+        return rc;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return FHIP_OK;
+}
+
+void fhip_destroy(fhip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    drain_profile(c);
+    for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
+    void *bufs[] = {c->d_smp, c->d_autoc, c->d_coefs, c->d_shift, c->d_opt,
+                    c->d_pcm, c->d_info, c->d_res, c->d_bits};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int fhip_set_stream(fhip_ctx *c, void *hip_stream)
+{
+    if (!c) return FHIP_E_INVALID;
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return FHIP_OK;
+}
+
+int fhip_sync(fhip_ctx *c)
+{
+    if (!c) return FHIP_E_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drain_profile(c);
+    return FHIP_OK;
+}
+
+int fhip_set_profiling(fhip_ctx *c, int on)
+{
+    if (!c) return FHIP_E_INVALID;
+    c->profiling = on != 0;
+    return FHIP_OK;
+}
+
+int fhip_get_kernel_times(fhip_ctx *c, const char **names, double *ms, int *launches,
+                          int cap, int reset)
+{
+    if (!c) return FHIP_E_INVALID;
+    int k = 0;
+    for (auto &t : c->ktimes) {
+        if (k < cap) {
+            if (names) names[k] = t.name;
+            if (ms) ms[k] = t.ms;
+            if (launches) launches[k] = t.launches;
+        }
+        k++;
+        if (reset) { t.ms = 0; t.launches = 0; }
+    }
+    return k;
+}
+
+int fhip_encode_subframes_dev(fhip_ctx *c, const fhip_batch *b)
+{
+    int rc = check_batch(c, b);
+    if (rc != FHIP_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return run_pipeline(c, b->pcm, b->nframes, b->block_size, b->info, b->residual,
+                        b->rice_bits, b->rice_slot_bytes, b->samples, b->autoc);
+}
+
+// Lazily sized staging buffers for the host-pointer entry points.
+static int ensure_staging(fhip_ctx *c, size_t bits_bytes)
+{
+    const size_t nsub = (size_t)c->max_frames * c->p.channels;
+    const size_t n = (size_t)c->p.block_size;
+    if (!c->d_pcm) HIP_TRY(c, hipMalloc((void **)&c->d_pcm, nsub * n * sizeof(int32_t)));
+    if (!c->d_info) HIP_TRY(c, hipMalloc((void **)&c->d_info, nsub * sizeof(fhip_subframe_info)));
+    if (!c->d_res) HIP_TRY(c, hipMalloc((void **)&c->d_res, nsub * n * sizeof(int32_t)));
+    if (bits_bytes > c->d_bits_bytes) {
+        if (c->d_bits) (void)hipFree(c->d_bits);
+        c->d_bits = nullptr;
+        c->d_bits_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_bits, bits_bytes));
+        c->d_bits_bytes = bits_bytes;
+    }
+    return FHIP_OK;
+}
+
+int fhip_encode_subframes(fhip_ctx *c, const fhip_batch *b)
+{
+    int rc = check_batch(c, b);
+    if (rc != FHIP_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nch = (size_t)c->p.channels, n = (size_t)b->block_size;
+    const size_t nsub = (size_t)b->nframes * nch;
+    const size_t bits_bytes = b->rice_bits ? nsub * (size_t)b->rice_slot_bytes : 0;
+    rc = ensure_staging(c, bits_bytes);
+    if (rc != FHIP_OK) return rc;
+    if (nsub == 0) return FHIP_OK;
+
+    double *d_autoc_out = b->autoc ? c->d_autoc : nullptr;
+    HIP_TRY(c, hipMemcpyAsync(c->d_pcm, b->pcm, nsub * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_info, 0, nsub * sizeof(fhip_subframe_info), c->stream));
+    if (bits_bytes) HIP_TRY(c, hipMemsetAsync(c->d_bits, 0, bits_bytes, c->stream));
+    rc = run_pipeline(c, c->d_pcm, b->nframes, b->block_size, c->d_info,
+                      b->residual ? c->d_res : nullptr, b->rice_bits ? c->d_bits : nullptr,
+                      b->rice_slot_bytes, nullptr, d_autoc_out);
+    if (rc != FHIP_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(b->info, c->d_info, nsub * sizeof(fhip_subframe_info), hipMemcpyDeviceToHost, c->stream));
+    if (b->residual)
+        HIP_TRY(c, hipMemcpyAsync(b->residual, c->d_res, nsub * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (b->rice_bits)
+        HIP_TRY(c, hipMemcpyAsync(b->rice_bits, c->d_bits, bits_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (b->samples)
+        HIP_TRY(c, hipMemcpyAsync(b->samples, c->d_smp, nsub * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (b->autoc)
+        HIP_TRY(c, hipMemcpyAsync(b->autoc, c->d_autoc, nsub * FHIP_MAX_LAGS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return fhip_sync(c);
+}
+
+int fhip_prepare_frames(fhip_ctx *c, const int32_t *pcm, int nframes, int n,
+                        int32_t *samples, fhip_subframe_info *info)
+{
+    if (!c || !pcm || !samples || !info) return fail(c, FHIP_E_INVALID, "null argument");
+    if (nframes < 0 || nframes > c->max_frames || n < 1 || n > c->p.block_size)
+        return fail(c, FHIP_E_INVALID, "batch shape out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c, 0);
+    if (rc != FHIP_OK) return rc;
+    const size_t nsub = (size_t)nframes * c->p.channels;
+    if (nsub == 0) return FHIP_OK;
+    HIP_TRY(c, hipMemcpyAsync(c->d_pcm, pcm, nsub * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_info, 0, nsub * sizeof(fhip_subframe_info), c->stream));
+    HIP_TRY(c, fhip::launch_prepare(c->stream, c->p, c->d_pcm, nframes, n, c->d_smp, c->d_info));
+    HIP_TRY(c, hipMemcpyAsync(samples, c->d_smp, nsub * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(info, c->d_info, nsub * sizeof(fhip_subframe_info), hipMemcpyDeviceToHost, c->stream));
+    return fhip_sync(c);
+}
+
+int fhip_lpc_calc_coefs(fhip_ctx *c, const int32_t *samples, int nsub, int n,
+                        int max_order, int precision, int omethod,
+                        int32_t *coefs, int32_t *shift, int32_t *opt_order, double *autoc)
+{
+    if (!c || !samples || !coefs || !shift || !opt_order) return fail(c, FHIP_E_INVALID, "null argument");
+    const size_t cap = (size_t)c->max_frames * c->p.channels;
+    if (nsub < 0 || (size_t)nsub > cap || n < 1 || n > c->p.block_size)
+        return fail(c, FHIP_E_INVALID, "batch shape out of range");
+    if (max_order < 1 || max_order > FHIP_MAX_ORDER || n <= max_order)
+        return fail(c, FHIP_E_INVALID, "max_order out of range (optimize.c:168)");
+    if (omethod < 0 || omethod > 6 || precision < 2 || precision > 15)
+        return fail(c, FHIP_E_INVALID, "bad order method / precision");
+    if (nsub == 0) return FHIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t ns = (size_t)nsub;
+    HIP_TRY(c, hipMemcpyAsync(c->d_smp, samples, ns * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_coefs, 0, ns * FHIP_MAX_ORDER * FHIP_MAX_ORDER * sizeof(int32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_shift, 0, ns * FHIP_MAX_ORDER * sizeof(int32_t), c->stream));
+    HIP_TRY(c, fhip::launch_autocorr(c->stream, c->d_smp, nsub, n, max_order, c->d_autoc));
+    HIP_TRY(c, fhip::launch_lpc(c->stream, c->d_autoc, nsub, max_order, precision, omethod,
+                                c->d_coefs, c->d_shift, c->d_opt));
+    HIP_TRY(c, hipMemcpyAsync(coefs, c->d_coefs, ns * FHIP_MAX_ORDER * FHIP_MAX_ORDER * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(shift, c->d_shift, ns * FHIP_MAX_ORDER * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(opt_order, c->d_opt, ns * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (autoc)
+        HIP_TRY(c, hipMemcpyAsync(autoc, c->d_autoc, ns * FHIP_MAX_LAGS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return fhip_sync(c);
+}
+
+int fhip_encode_residual(fhip_ctx *c, const int32_t *samples, int nsub, int n,
+                         fhip_subframe_info *info, int32_t *residual,
+                         uint8_t *rice_bits, int64_t rice_slot_bytes)
+{
+    if (!c || !samples || !info) return fail(c, FHIP_E_INVALID, "null argument");
+    const size_t cap = (size_t)c->max_frames * c->p.channels;
+    if (nsub < 0 || (size_t)nsub > cap || n < 1 || n > c->p.block_size)
+        return fail(c, FHIP_E_INVALID, "batch shape out of range");
+    if (n > FHIP_MAX_BLOCK) return fail(c, FHIP_E_UNSUPPORTED, "block_size above FHIP_MAX_BLOCK");
+    if (rice_bits && (rice_slot_bytes < 4 || (rice_slot_bytes & 3)))
+        return fail(c, FHIP_E_INVALID, "rice_slot_bytes must be a positive multiple of 4");
+    if (nsub == 0) return FHIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t ns = (size_t)nsub;
+    const size_t bits_bytes = rice_bits ? ns * (size_t)rice_slot_bytes : 0;
+    int rc = ensure_staging(c, bits_bytes);
+    if (rc != FHIP_OK) return rc;
+    const fhip_params &p = c->p;
+    HIP_TRY(c, hipMemcpyAsync(c->d_smp, samples, ns * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_info, info, ns * sizeof(fhip_subframe_info), hipMemcpyHostToDevice, c->stream));
+    if (bits_bytes) HIP_TRY(c, hipMemsetAsync(c->d_bits, 0, bits_bytes, c->stream));
+    if (p.prediction_type == 2 && n > p.max_prediction_order && n >= 5) {
+        HIP_TRY(c, fhip::launch_autocorr(c->stream, c->d_smp, nsub, n, p.max_prediction_order, c->d_autoc));
+        HIP_TRY(c, fhip::launch_lpc(c->stream, c->d_autoc, nsub, p.max_prediction_order,
+                                    p.lpc_precision, p.order_method, c->d_coefs, c->d_shift, c->d_opt));
+    }
+    HIP_TRY(c, fhip::launch_encode(c->stream, p, c->d_smp, nsub, n, c->d_coefs, c->d_shift, c->d_opt,
+                                   c->d_info, residual ? c->d_res : nullptr,
+                                   rice_bits ? c->d_bits : nullptr, rice_slot_bytes));
+    HIP_TRY(c, hipMemcpyAsync(info, c->d_info, ns * sizeof(fhip_subframe_info), hipMemcpyDeviceToHost, c->stream));
+    if (residual)
+        HIP_TRY(c, hipMemcpyAsync(residual, c->d_res, ns * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (rice_bits)
+        HIP_TRY(c, hipMemcpyAsync(rice_bits, c->d_bits, bits_bytes, hipMemcpyDeviceToHost, c->stream));
+    return fhip_sync(c);
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// kernels.h -- launch interface between the C ABI (api.hip) and the gfx950
+// kernels (kernels.hip).  Internal to libflakehip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "flakehip.h"
+
+namespace fhip {
+
+// Everything a launch needs that does not change within a batch.
+struct EncodeArgs {
+    fhip_params p;
+    int n;            // block size of this batch
+    int nsub;         // subframes in this batch
+};
+
+// K0: copy_samples + channel_decorrelation + remove_wasted_bits
+// (encode.c:541-694).  pcm [nframes][n][ch] -> smp [nframes][ch][n].
+hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *pcm,
+                          int nframes, int n, int32_t *smp, fhip_subframe_info *info);
+
+// K1: apply_welch_window + compute_autocorr (lpc.c:28-71).
+// smp [nsub][n] -> autoc [nsub][FHIP_MAX_LAGS].
+hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
+                           int max_order, double *autoc);
+
+// K2: compute_lpc_coefs / _est + quantize_lpc_coefs (lpc.c:77-257).
+// coefs [nsub][32][32], shift [nsub][32], opt_order [nsub].
+hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_order,
+                      int precision, int omethod, int32_t *coefs, int32_t *shift,
+                      int32_t *opt_order);
+
+// K3: encode_residual (optimize.c:124-276) incl. the Rice search (rice.c) and,
+// when bits != NULL, the residual section of output_residual (encode.c:766-798).
+hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *smp,
+                         int nsub, int n, const int32_t *coefs, const int32_t *shift,
+                         const int32_t *opt_order, fhip_subframe_info *info,
+                         int32_t *residual, uint8_t *bits, int64_t slot_bytes);
+
+// Dynamic-LDS need of K3 for a block size (0 if unsupported).
+size_t encode_lds_bytes(int n);
+
+}  // namespace fhip

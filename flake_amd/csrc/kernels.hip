@@ -1,0 +1,1080 @@
+// kernels.hip -- gfx950 (CDNA4, wave64) kernels for the FLAC prediction /
+// entropy path of libflake.  Compile with -ffp-contract=off: the fp64 stages
+// reproduce the reference's rounding sequence exactly (one rounding per
+// multiply and per add, in the reference's order), which is what makes the
+// quantised coefficients -- and with them every residual -- bit-exact.
+//
+// Stage map (reference file:line -> kernel):
+//   K0 k_prepare   encode.c:541-553 copy_samples, :598-694 stereo estimate +
+//                  decorrelation, :558-593 remove_wasted_bits
+//   K1 k_autocorr  lpc.c:28-40 apply_welch_window, :46-71 compute_autocorr
+//   K2 k_lpc       lpc.c:77-117 Levinson, :125-162 Schur estimate,
+//                  :167-219 quantiser, :224-257 driver
+//   K3 k_encode    optimize.c:34-276 residuals + order decision tree,
+//                  rice.c:30-187 Rice search, encode.c:766-798 +
+//                  bitio.h:120-141 residual-section emit
+#include "kernels.h"
+
+namespace fhip {
+namespace {
+
+constexpr int NT = 256;        // threads per workgroup (4 waves)
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t zigzag32(int32_t x)
+{
+    // rice.c:122 (search side) and bitio.h:128-129 (emit side): same map
+    return ((uint32_t)x << 1) ^ (uint32_t)(x >> 31);
+}
+
+__device__ __forceinline__ int32_t wrap_abs(int32_t a)
+{
+    return a < 0 ? (int32_t)(0u - (uint32_t)a) : a;
+}
+
+// rice.h:48 rice_encode_count evaluated in uint64 like the C macro:
+// n*(k+1) is an int, sum-(n>>1) wraps, the shift is logical.
+__device__ __forceinline__ uint64_t rice_count64(uint64_t sum, int n, int k)
+{
+    return (uint64_t)(int64_t)(n * (k + 1)) + ((sum - (uint64_t)(int64_t)(n >> 1)) >> k);
+}
+
+// rice.c:30-45 find_optimal_rice_param: first strict minimum over k=0..30 of
+// the count truncated to uint32.
+__device__ __forceinline__ int rice_best_k(uint64_t sum, int n, uint32_t *bits_out)
+{
+    const uint64_t s = sum - (uint64_t)(int64_t)(n >> 1);
+    uint32_t best = (uint32_t)((uint64_t)(int64_t)n + s);
+    int kb = 0;
+#pragma unroll 1
+    for (int k = 1; k <= 30; k++) {
+        uint32_t b = (uint32_t)((uint64_t)(int64_t)(n * (k + 1)) + (s >> k));
+        if (b < best) { best = b; kb = k; }
+    }
+    *bits_out = best;
+    return kb;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;   // valid in lane 0
+}
+
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= (uint32_t)__shfl_down((int)v, off, WAVE);
+    return v;   // valid in lane 0
+}
+
+// inclusive scan of a u64 across the wave
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        unsigned long long t = __shfl_up(v, off, WAVE);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// x86-64 cvttsd2si semantics for (int)double: out-of-range and NaN give
+// INT_MIN (the reference's `q = error + 0.5`, lpc.c:211).
+__device__ __forceinline__ int c_double_to_int(double x)
+{
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return (int)0x80000000;
+    return (int)x;
+}
+
+// ---------------------------------------------------------------------------
+// K0  k_prepare
+// ---------------------------------------------------------------------------
+// Stereo: one workgroup per frame, both channels resident in LDS.
+// Otherwise: one workgroup per (frame, channel).
+// LDS: int32[(nch==2 ? 2 : 1) * n].
+__global__ __launch_bounds__(NT)
+void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
+               fhip_subframe_info *__restrict__ info, int n, int nch, int bps, int estimate)
+{
+    extern __shared__ int32_t lds_i32[];
+    __shared__ unsigned long long s_sum[4][4];
+    __shared__ uint32_t s_or[4][2];
+    __shared__ int s_mode;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    if (nch == 2) {
+        const int f = blockIdx.x;
+        const int32_t *src = pcm + (size_t)f * n * 2;
+        int32_t *L = lds_i32, *R = lds_i32 + n;
+        const int2 *src2 = reinterpret_cast<const int2 *>(src);
+        for (int i = tid; i < n; i += NT) {
+            int2 v = src2[i];
+            L[i] = v.x;
+            R[i] = v.y;
+        }
+        __syncthreads();
+
+        int mode = FHIP_CH_LEFT_RIGHT;
+        if (estimate && n > 32) {
+            // encode.c:598-643 calc_decorr_scores
+            unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (int i = tid + 2; i < n; i += NT) {
+                int32_t lt = (int32_t)((uint32_t)L[i] - 2u * (uint32_t)L[i - 1] + (uint32_t)L[i - 2]);
+                int32_t rt = (int32_t)((uint32_t)R[i] - 2u * (uint32_t)R[i - 1] + (uint32_t)R[i - 2]);
+                int32_t m = (int32_t)((uint32_t)lt + (uint32_t)rt) >> 1;
+                int32_t s = (int32_t)((uint32_t)lt - (uint32_t)rt);
+                a0 += (unsigned long long)(long long)wrap_abs(lt);
+                a1 += (unsigned long long)(long long)wrap_abs(rt);
+                a2 += (unsigned long long)(long long)wrap_abs(m);
+                a3 += (unsigned long long)(long long)wrap_abs(s);
+            }
+            a0 = wave_sum_u64(a0); a1 = wave_sum_u64(a1);
+            a2 = wave_sum_u64(a2); a3 = wave_sum_u64(a3);
+            if (lane == 0) { s_sum[wv][0] = a0; s_sum[wv][1] = a1; s_sum[wv][2] = a2; s_sum[wv][3] = a3; }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long cost[4];
+                for (int q = 0; q < 4; q++) {
+                    unsigned long long sm = s_sum[0][q] + s_sum[1][q] + s_sum[2][q] + s_sum[3][q];
+                    uint32_t dummy;
+                    int k = rice_best_k(2 * sm, n, &dummy);
+                    cost[q] = rice_count64(2 * sm, n, k);     // no 32-bit truncation here (encode.c:620)
+                }
+                unsigned long long sc[4] = {cost[0] + cost[1], cost[0] + cost[3],
+                                            cost[1] + cost[3], cost[2] + cost[3]};
+                int best = 0;
+                for (int q = 1; q < 4; q++) if (sc[q] < sc[best]) best = q;
+                const int modes[4] = {FHIP_CH_LEFT_RIGHT, FHIP_CH_LEFT_SIDE,
+                                      FHIP_CH_RIGHT_SIDE, FHIP_CH_MID_SIDE};
+                s_mode = modes[best];
+            }
+            __syncthreads();
+            mode = s_mode;
+        }
+
+        // encode.c:668-693 apply, then OR of every sample per channel
+        uint32_t or0 = 0, or1 = 0;
+        for (int i = tid; i < n; i += NT) {
+            int32_t a = L[i], b = R[i];
+            if (mode == FHIP_CH_MID_SIDE) {
+                int32_t mid = (int32_t)((uint32_t)a + (uint32_t)b) >> 1;
+                int32_t sd = (int32_t)((uint32_t)a - (uint32_t)b);
+                a = mid; b = sd;
+            } else if (mode == FHIP_CH_LEFT_SIDE) {
+                b = (int32_t)((uint32_t)a - (uint32_t)b);
+            } else if (mode == FHIP_CH_RIGHT_SIDE) {
+                a = (int32_t)((uint32_t)a - (uint32_t)b);
+            }
+            L[i] = a; R[i] = b;
+            or0 |= (uint32_t)a; or1 |= (uint32_t)b;
+        }
+        or0 = wave_or_u32(or0); or1 = wave_or_u32(or1);
+        if (lane == 0) { s_or[wv][0] = or0; s_or[wv][1] = or1; }
+        __syncthreads();
+
+        int wasted[2], obits[2];
+        for (int c = 0; c < 2; c++) {
+            // encode.c:558-593: min(bps-1, trailing zeros over non-zero samples);
+            // bps-1 (also the all-zero case) is reset to 0
+            uint32_t o = s_or[0][c] | s_or[1][c] | s_or[2][c] | s_or[3][c];
+            int w = o ? min(__ffs((int)o) - 1, bps - 1) : bps - 1;
+            if (w == bps - 1) w = 0;
+            wasted[c] = w;
+            obits[c] = bps - w;
+        }
+        if (mode == FHIP_CH_MID_SIDE || mode == FHIP_CH_LEFT_SIDE) obits[1]++;
+        if (mode == FHIP_CH_RIGHT_SIDE) obits[0]++;
+
+        int32_t *dst = smp + (size_t)f * 2 * n;
+        for (int i = tid; i < n; i += NT) {
+            dst[i] = L[i] >> wasted[0];
+            dst[n + i] = R[i] >> wasted[1];
+        }
+        if (tid < 2) {
+            fhip_subframe_info *o = &info[(size_t)f * 2 + tid];
+            o->obits = obits[tid];
+            o->wasted = wasted[tid];
+            o->ch_mode = mode;
+        }
+    } else {
+        const int f = blockIdx.x / nch, ch = blockIdx.x - f * nch;
+        const int32_t *src = pcm + (size_t)f * n * nch + ch;
+        int32_t *S = lds_i32;
+        uint32_t orv = 0;
+        for (int i = tid; i < n; i += NT) {
+            int32_t v = src[(size_t)i * nch];
+            S[i] = v;
+            orv |= (uint32_t)v;
+        }
+        orv = wave_or_u32(orv);
+        if (lane == 0) s_or[wv][0] = orv;
+        __syncthreads();
+        uint32_t o = s_or[0][0] | s_or[1][0] | s_or[2][0] | s_or[3][0];
+        int w = o ? min(__ffs((int)o) - 1, bps - 1) : bps - 1;
+        if (w == bps - 1) w = 0;
+        int32_t *dst = smp + ((size_t)f * nch + ch) * n;
+        for (int i = tid; i < n; i += NT) dst[i] = S[i] >> w;
+        if (tid == 0) {
+            fhip_subframe_info *oi = &info[(size_t)f * nch + ch];
+            oi->obits = bps - w;
+            oi->wasted = w;
+            oi->ch_mode = FHIP_CH_NOT_STEREO;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1  k_autocorr
+// ---------------------------------------------------------------------------
+// lane = (subframe g of the wave, lag L): each lane owns the two running sums
+// of one lag and walks the block front to back, so every sum sees its
+// products in the reference's order.  Each wave is independent
+// and streams its G subframes through a private LDS ring of windowed fp64
+// samples, 64 positions per tile.
+constexpr int AC_TILE = 64;
+constexpr int AC_RING = 128;              // >= AC_TILE + FHIP_MAX_ORDER, power of two
+constexpr int AC_STRIDE = 136;            // ring row stride in doubles (bank spread)
+constexpr int AC_GMAX = 8;
+
+__global__ __launch_bounds__(NT)
+void k_autocorr(const int32_t *__restrict__ smp, double *__restrict__ autoc,
+                int nsub, int n, int maxlag, int G, double c)
+{
+    __shared__ double s_ring[4][AC_GMAX * AC_STRIDE];
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double *ring = s_ring[wv];
+    const int nl = maxlag + 1;
+    const int s0 = (blockIdx.x * 4 + wv) * G;
+    const int g = lane / nl, L = lane - g * nl;
+    const bool chain = (g < G) && (s0 + g < nsub);
+    const double *row = ring + (chain ? g : 0) * AC_STRIDE;
+    const int half = n >> 1;
+    const int ntiles = (n + AC_TILE - 1) / AC_TILE;
+
+    double accE = 1.0, accO = 1.0;       // sums over even / odd positions (lpc.c:58-59)
+
+    int32_t cur[AC_GMAX];
+#pragma unroll
+    for (int q = 0; q < AC_GMAX; q++) {
+        cur[q] = 0;
+        if (q < G && s0 + q < nsub && lane < n) cur[q] = smp[(size_t)(s0 + q) * n + lane];
+    }
+
+    for (int t = 0; t < ntiles; t++) {
+        const int tb = t * AC_TILE;
+        {
+            // lpc.c:28-40: weight of positions i and n-1-i is 1-(c-i)^2
+            const int p = tb + lane;
+            const int ii = (p < half) ? p : (n - 1 - p);
+            const bool valid = (p < n) && (ii < half);
+            const double tt = c - (double)ii;
+            const double w = 1.0 - (tt * tt);
+#pragma unroll
+            for (int q = 0; q < AC_GMAX; q++) {
+                if (q < G) ring[q * AC_STRIDE + (p & (AC_RING - 1))] = valid ? ((double)cur[q] * w) : 0.0;
+            }
+            const int pn = p + AC_TILE;
+#pragma unroll
+            for (int q = 0; q < AC_GMAX; q++) {
+                int32_t v = 0;
+                if (q < G && s0 + q < nsub && pn < n) v = smp[(size_t)(s0 + q) * n + pn];
+                cur[q] = v;
+            }
+        }
+        __syncthreads();
+
+        const int kend = min(AC_TILE, n - tb);
+        if (t == 0) {
+            // head: positions L..maxlag all go to the first sum (lpc.c:60-61) ...
+            double accH = 1.0;
+            const int hend = min(kend, maxlag + 1);
+            for (int k = 0; k < hend; k++) {
+                double a = row[k];
+                if (chain && k >= L) {
+                    double b = row[(k - L) & (AC_RING - 1)];
+                    double prod = a * b;
+                    accH = accH + prod;
+                }
+            }
+            // ... which then continues at position maxlag+1 (lpc.c:63-66)
+            if ((maxlag + 1) & 1) accO = accH; else accE = accH;
+            for (int k = hend; k < kend; k++) {
+                double a = row[k];
+                double b = row[(k - L) & (AC_RING - 1)];
+                double prod = a * b;
+                if (k & 1) accO = accO + prod; else accE = accE + prod;
+            }
+        } else {
+            int k = 0;
+#pragma unroll 4
+            for (; k + 1 < kend; k += 2) {
+                const int p = tb + k;
+                double a0 = row[p & (AC_RING - 1)];
+                double b0 = row[(p - L) & (AC_RING - 1)];
+                double a1 = row[(p + 1) & (AC_RING - 1)];
+                double b1 = row[(p + 1 - L) & (AC_RING - 1)];
+                double p0 = a0 * b0;
+                double p1 = a1 * b1;
+                accE = accE + p0;
+                accO = accO + p1;
+            }
+            if (k < kend) {
+                const int p = tb + k;
+                double prod = row[p & (AC_RING - 1)] * row[(p - L) & (AC_RING - 1)];
+                accE = accE + prod;
+            }
+        }
+        __syncthreads();
+    }
+    // lpc.c:68: autoc = temp + temp2.  The reference's padded product with
+    // d[len] = 0 adds +-0.0 to a sum that is never -0.0, so it is skipped.
+    if (chain) autoc[(size_t)(s0 + g) * FHIP_MAX_LAGS + L] = accE + accO;
+}
+
+// ---------------------------------------------------------------------------
+// K2  k_lpc
+// ---------------------------------------------------------------------------
+// One lane per subframe; per-lane work arrays live in LDS, laid out
+// [index][lane] so that lanes never collide on a bank.
+constexpr int LPC_NT = 64;
+
+struct LaneArr {
+    double *base;
+    __device__ __forceinline__ double &operator[](int i) const { return base[i * LPC_NT]; }
+};
+
+// lpc.c:167-219 quantize_lpc_coefs applied to row = -a[0..order)
+__device__ void quantize_row(const LaneArr a, int order, int precision,
+                             int32_t *__restrict__ out, int32_t *__restrict__ shift_out)
+{
+    const int qmax = (1 << (precision - 1)) - 1;
+    double cmax = 0.0;
+    for (int j = 0; j < order; j++) {
+        double m = fabs(a[j]);
+        if (m > cmax) cmax = m;
+    }
+    if (cmax * 32768.0 < 1.0) {
+        *shift_out = 0;
+        for (int j = 0; j < order; j++) out[j] = 0;
+        return;
+    }
+    int sh = 15;
+    while (sh > 0 && cmax * (double)(1 << sh) > (double)qmax) sh--;
+    const bool rescale = (sh == 0) && (cmax > (double)qmax);
+    const double scale = rescale ? ((double)qmax / cmax) : 1.0;
+    const double mul = (double)(1 << sh);
+    double carry = 0.0;
+    for (int j = 0; j < order; j++) {
+        double v = -a[j];
+        if (rescale) v = v * scale;
+        double t = v * mul;
+        carry = carry + t;
+        int q = c_double_to_int(carry + 0.5);
+        if (q <= -qmax) q = -qmax + 1;
+        if (q > qmax) q = qmax;
+        carry = carry - (double)q;
+        out[j] = q;
+    }
+    *shift_out = sh;
+}
+
+// LDS doubles per lane: R0[33] R1[32] R2[32].
+//   Levinson path: R0 = autoc, R1 = lpc_tmp.
+//   Schur path:    R0 = autoc, whose tail doubles as gen[0] (gen[0][j] starts
+//                  as autoc[j+1]); R1 = gen[1]; R2 = ref; afterwards R0 is
+//                  reused as lpc_tmp.
+constexpr int LPC_DBL = 33 + 32 + 32;
+
+__global__ __launch_bounds__(LPC_NT)
+void k_lpc(const double *__restrict__ autoc_all, int nsub, int max_order, int precision,
+           int omethod, int32_t *__restrict__ coefs, int32_t *__restrict__ shift,
+           int32_t *__restrict__ opt_order)
+{
+    __shared__ double s_mem[LPC_DBL * LPC_NT];
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x * LPC_NT + lane;
+    if (s >= nsub) return;
+
+    LaneArr R0{s_mem + lane};
+    LaneArr R1{s_mem + 33 * LPC_NT + lane};
+    LaneArr R2{s_mem + 65 * LPC_NT + lane};
+
+    for (int i = 0; i <= max_order; i++) R0[i] = autoc_all[(size_t)s * FHIP_MAX_LAGS + i];
+
+    int32_t *crow = coefs + (size_t)s * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
+    int32_t *srow = shift + (size_t)s * FHIP_MAX_ORDER;
+
+    int levinson_order = max_order;
+    const bool use_ref = (omethod == 1 /* FLAKE_ORDER_METHOD_EST */);
+    LaneArr ac = R0, a = R1, ref = R2;
+    if (use_ref) {
+        // lpc.c:125-162: Schur recursion
+        LaneArr g0{R0.base + LPC_NT}, g1 = R1;
+        for (int i = 0; i < max_order; i++) g1[i] = g0[i];
+        double e = R0[0];
+        {
+            double r0 = -g1[0] / e;
+            ref[0] = r0;
+            double t = g1[0] * r0;
+            e = e + t;
+        }
+        for (int i = 1; i < max_order; i++) {
+            const double k = ref[i - 1];
+            for (int j = 0; j < max_order - i; j++) {
+                double up = g1[j + 1];
+                double lo = g0[j];
+                double t0 = k * lo;
+                g1[j] = up + t0;
+                double t1 = up * k;
+                g0[j] = t1 + lo;
+            }
+            double ri = -g1[0] / e;
+            ref[i] = ri;
+            double t = g1[0] * ri;
+            e = e + t;
+        }
+        int est = 1;
+        for (int i = max_order - 1; i >= 0; i--) {
+            if (fabs(ref[i]) > 0.10) { est = i + 1; break; }
+        }
+        levinson_order = est;
+        a = R0;
+    }
+
+    // lpc.c:77-117 Levinson-Durbin; a[] is lpc_tmp
+    double err = use_ref ? 1.0 : ac[0];
+    for (int i = 0; i < FHIP_MAX_ORDER; i++) a[i] = 0.0;
+    const bool all_rows = !(omethod == 0 || omethod == 1);
+    for (int i = 0; i < levinson_order; i++) {
+        double r;
+        if (use_ref) {
+            r = ref[i];
+        } else {
+            r = -ac[i + 1];
+            for (int j = 0; j < i; j++) {
+                double t = a[j] * ac[i - j];
+                r = r - t;
+            }
+            r = r / err;
+            double rr = r * r;
+            double om = 1.0 - rr;
+            err = err * om;
+        }
+        a[i] = r;
+        const int h = i >> 1;
+        for (int j = 0; j < h; j++) {
+            double lo = a[j];
+            double hi = a[i - 1 - j];
+            double t0 = r * hi;
+            a[j] = lo + t0;
+            double t1 = r * lo;
+            a[i - 1 - j] = hi + t1;
+        }
+        if (i & 1) {
+            double m = a[h];
+            double t = m * r;
+            a[h] = m + t;
+        }
+        // lpc.c:243-254: one row for MAX/EST, every row for the search methods
+        if (all_rows || i == levinson_order - 1)
+            quantize_row(a, i + 1, precision, crow + i * FHIP_MAX_ORDER, srow + i);
+    }
+    opt_order[s] = levinson_order;
+}
+
+// ---------------------------------------------------------------------------
+// K3  k_encode
+// ---------------------------------------------------------------------------
+// One workgroup per subframe.  Thread t owns the contiguous run of `chunk`
+// samples starting at t*chunk: its residuals stay in registers from the FIR
+// through the partition sums to the bit emit.  Samples sit in LDS behind one
+// pad word per 16 so that lane-strided reads of x[16*t + d] spread over all
+// banks.
+struct EncLds {
+    int32_t *smp;                       // padded samples
+    unsigned long long *sums;           // [511] partition sums, heap order
+    int32_t *kpar;                      // [511] Rice parameter per node
+    uint32_t *lvl_bits;                 // [9]
+    uint32_t *lvl_meth;                 // [9]
+    int32_t *coef;                      // [32]
+    int32_t *misc;                      // [16]
+    uint32_t *trial;                    // [32] bits[] table of the log search
+    unsigned long long *scan;           // [8]
+    uint32_t *bits;                     // [ENC_WWORDS] emit window
+};
+constexpr int ENC_WWORDS = 2048;        // 64 Kbit emit window
+enum { M_PORDER = 0, M_METHOD = 1, M_BITS = 2, M_FLAG = 3 };
+
+__device__ __forceinline__ int padidx(int i) { return i + (i >> 4); }
+
+__host__ __device__ inline size_t enc_lds_layout(int n, size_t off[10])
+{
+    size_t o = 0;
+    off[0] = o; o += 8 * 511;                                   // sums
+    off[1] = o; o += 8 * 8;                                     // scan
+    off[2] = o; o += 4 * (size_t)(n + (n >> 4) + 1);            // smp
+    off[3] = o; o += 4 * 511;                                   // kpar
+    off[4] = o; o += 4 * 9;                                     // lvl_bits
+    off[5] = o; o += 4 * 9;                                     // lvl_meth
+    off[6] = o; o += 4 * 32;                                    // coef
+    off[7] = o; o += 4 * 16;                                    // misc
+    off[9] = o; o += 4 * 32;                                    // trial
+    o = (o + 15) & ~(size_t)15;
+    off[8] = o; o += 4 * ENC_WWORDS;                            // bits
+    return o;
+}
+
+struct EncCtx {
+    EncLds l;
+    int n, chunk, i0, tid;
+    int obits, precision;
+    int pmin_req, pmax_req;
+};
+
+__device__ __forceinline__ int ilog2_dev(uint32_t v) { return v ? 31 - __clz((int)v) : 0; }
+
+// rice.c:148-155 limit_max_partition_order
+__device__ __forceinline__ int clamp_porder(int porder, int n, int order)
+{
+    int lim = ilog2_dev((uint32_t)(n ^ (n - 1)));
+    porder = min(porder, lim);
+    if (order > 0) porder = min(porder, ilog2_dev((uint32_t)(n / order)));
+    return porder;
+}
+
+// Rice search over the residuals held in r[] (rice.c:105-187).  Leaves the
+// per-node parameters in l.kpar, the chosen order/method in l.misc and
+// returns the subframe bit estimate.  All threads must call it.
+template <int C>
+__device__ __forceinline__ uint32_t rice_search(const EncCtx &e, const int32_t (&r)[C], int order, bool lpc)
+{
+    const EncLds &l = e.l;
+    const int n = e.n, tid = e.tid;
+    const int pmin = clamp_porder(e.pmin_req, n, order);
+    const int pmax = clamp_porder(e.pmax_req, n, order);
+    const int psize = n >> pmax;
+
+    for (int q = tid; q < 511; q += NT) l.sums[q] = 0;
+    if (tid < 9) { l.lvl_bits[tid] = 0; l.lvl_meth[tid] = 0; }
+    __syncthreads();
+
+    // rice.c:76-94 finest-level sums: partition 0 starts at `order`
+    {
+        const int heap0 = (1 << pmax) - 1;
+        unsigned long long run = 0;
+        int part = -1, bound = 0;
+#pragma unroll
+        for (int o = 0; o < C; o++) {
+            const int i = e.i0 + o;
+            if (o < e.chunk && i < n && i >= order) {
+                if (part < 0) { part = i / psize; bound = (part + 1) * psize; }
+                if (i == bound) {
+                    atomicAdd(&l.sums[heap0 + part], run);
+                    run = 0; part++; bound += psize;
+                }
+                run += zigzag32(r[o]);
+            }
+        }
+        if (part >= 0) atomicAdd(&l.sums[heap0 + part], run);
+    }
+    __syncthreads();
+    // rice.c:96-102 pyramid
+    for (int p = pmax - 1; p >= pmin; p--) {
+        const int np = 1 << p;
+        for (int j = tid; j < np; j += NT)
+            l.sums[np - 1 + j] = l.sums[2 * np - 1 + 2 * j] + l.sums[2 * np - 1 + 2 * j + 1];
+        __syncthreads();
+    }
+    // rice.c:47-74 per level, per partition: best k and its cost
+    {
+        const int first = (1 << pmin) - 1, last = (2 << pmax) - 2;
+        for (int q = first + tid; q <= last; q += NT) {
+            const int p = ilog2_dev((uint32_t)(q + 1));
+            const int j = q + 1 - (1 << p);
+            const int cnt = (n >> p) - (j == 0 ? order : 0);
+            uint32_t b;
+            const int k = rice_best_k(l.sums[q], cnt, &b);
+            l.kpar[q] = k;
+            atomicAdd(&l.lvl_bits[p], b);
+            if (k > 14) atomicOr(&l.lvl_meth[p], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // rice.c:127-138: ties go to the higher partition order
+        int bp = pmin;
+        uint32_t best = l.lvl_bits[pmin] + 4u * (1u << pmin);
+        for (int p = pmin + 1; p <= pmax; p++) {
+            uint32_t b = l.lvl_bits[p] + 4u * (1u << p);
+            if (b <= best) { best = b; bp = p; }
+        }
+        const uint32_t method = l.lvl_meth[bp];
+        // rice.c:157-171
+        uint32_t bits = (uint32_t)(order * e.obits + 2);
+        if (lpc) bits += (uint32_t)(4 + 5 + order * e.precision);
+        bits += best;
+        bits += method + 4u;
+        l.misc[M_PORDER] = bp;
+        l.misc[M_METHOD] = (int)method;
+        l.misc[M_BITS] = (int)bits;
+    }
+    __syncthreads();
+    return (uint32_t)l.misc[M_BITS];
+}
+
+// optimize.c:70-122 encode_residual_lpc for this thread's run
+template <int C>
+__device__ __forceinline__ void residual_lpc(const EncCtx &e, int32_t (&r)[C], int order,
+                                             const int32_t *__restrict__ coefs_row, int shift)
+{
+    const EncLds &l = e.l;
+    __syncthreads();                       // previous readers of l.coef are done
+    if (e.tid < order) l.coef[e.tid] = coefs_row[e.tid];
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < C; o++) {
+        const int i = e.i0 + o;
+        int32_t v = 0;
+        if (o < e.chunk && i < e.n) {
+            const int32_t x = l.smp[padidx(i)];
+            if (i < order) {
+                v = x;
+            } else {
+                long long pred = 0;
+                for (int j = order; j >= 1; j--)
+                    pred += (long long)l.coef[j - 1] * (long long)l.smp[padidx(i - j)];
+                v = (int32_t)((long long)x - (pred >> shift));
+            }
+        }
+        r[o] = v;
+    }
+}
+
+// optimize.c:34-68 encode_residual_fixed
+template <int C>
+__device__ __forceinline__ void residual_fixed(const EncCtx &e, int32_t (&r)[C], int order)
+{
+    const EncLds &l = e.l;
+#pragma unroll
+    for (int o = 0; o < C; o++) {
+        const int i = e.i0 + o;
+        int32_t v = 0;
+        if (o < e.chunk && i < e.n) {
+            const long long x0 = l.smp[padidx(i)];
+            if (i < order || order == 0) {
+                v = (int32_t)x0;
+            } else {
+                const long long x1 = l.smp[padidx(i - 1)];
+                long long acc;
+                if (order == 1) {
+                    acc = x0 - x1;
+                } else {
+                    const long long x2 = l.smp[padidx(i - 2)];
+                    if (order == 2) {
+                        acc = x0 - 2 * x1 + x2;
+                    } else {
+                        const long long x3 = l.smp[padidx(i - 3)];
+                        if (order == 3) {
+                            acc = x0 - 3 * x1 + 3 * x2 - x3;
+                        } else {
+                            const long long x4 = l.smp[padidx(i - 4)];
+                            acc = x0 - 4 * x1 + 6 * x2 - 4 * x3 + x4;
+                        }
+                    }
+                }
+                v = (int32_t)acc;
+            }
+        }
+        r[o] = v;
+    }
+}
+
+// OR a value of `len` (<= 31) bits into the MSB-first bit string at absolute
+// bit position pos, clipped to the LDS window [wlo, wlo + ENC_WWORDS) words.
+__device__ __forceinline__ void put_bits(uint32_t *win, long long wlo, long long pos, int len, uint32_t val)
+{
+    const long long wi = (pos >> 5) - wlo;
+    if (wi < -1 || wi >= ENC_WWORDS) return;
+    const int sh = 64 - len - (int)(pos & 31);
+    const unsigned long long x = (unsigned long long)val << sh;
+    const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+    if (wi >= 0 && hi) atomicOr(&win[wi], hi);
+    if (lo && wi + 1 < ENC_WWORDS) atomicOr(&win[wi + 1], lo);
+}
+
+template <int C>
+__global__ __launch_bounds__(NT)
+void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
+              const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
+              const int32_t *__restrict__ opt_all, fhip_subframe_info *__restrict__ info,
+              int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    size_t off[10];
+    enc_lds_layout(n, off);
+    EncCtx e;
+    e.l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
+    e.l.scan = reinterpret_cast<unsigned long long *>(lds_raw + off[1]);
+    e.l.smp = reinterpret_cast<int32_t *>(lds_raw + off[2]);
+    e.l.kpar = reinterpret_cast<int32_t *>(lds_raw + off[3]);
+    e.l.lvl_bits = reinterpret_cast<uint32_t *>(lds_raw + off[4]);
+    e.l.lvl_meth = reinterpret_cast<uint32_t *>(lds_raw + off[5]);
+    e.l.coef = reinterpret_cast<int32_t *>(lds_raw + off[6]);
+    e.l.misc = reinterpret_cast<int32_t *>(lds_raw + off[7]);
+    e.l.bits = reinterpret_cast<uint32_t *>(lds_raw + off[8]);
+    e.l.trial = reinterpret_cast<uint32_t *>(lds_raw + off[9]);
+    const EncLds &l = e.l;
+
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    fhip_subframe_info *out = &info[s];
+    e.n = n;
+    e.tid = tid;
+    e.chunk = (n + NT - 1) / NT;
+    e.i0 = tid * e.chunk;
+    e.obits = out->obits;
+    e.precision = P.lpc_precision;
+    e.pmin_req = P.min_partition_order;
+    e.pmax_req = P.max_partition_order;
+
+    const int32_t *src = smp_all + (size_t)s * n;
+    if (tid == 0) l.misc[M_FLAG] = 0;
+    __syncthreads();
+    {
+        const int32_t first = src[0];
+        int differs = 0;
+        for (int i = tid; i < n; i += NT) {
+            int32_t v = src[i];
+            l.smp[padidx(i)] = v;
+            differs |= (v != first);
+        }
+        if (differs) atomicOr(&l.misc[M_FLAG], 1);
+    }
+    __syncthreads();
+    const bool constant = (l.misc[M_FLAG] == 0);
+
+    int32_t r[C];
+    int type, type_code, order = 0, shift = 0;
+    uint32_t est_bits = 0;
+    bool has_rice = false;
+    const int32_t *crow_base = coefs_all + (size_t)s * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
+    const int32_t *srow = shift_all + (size_t)s * FHIP_MAX_ORDER;
+
+    // The decision tree of encode_residual() (optimize.c:124-276) as one
+    // candidate loop: `pick` walks the orders the reference would try, in its
+    // sequence; the last pass re-encodes the winner exactly as the reference
+    // does (optimize.c:184-188, :266-275).  Every variable below is uniform
+    // across the workgroup.
+    enum { T_CONST, T_VERB, T_FIXED, T_LPC } tree;
+    if (constant) tree = T_CONST;                                        // optimize.c:143-151
+    else if (n < 5 || P.prediction_type == 0) tree = T_VERB;             // optimize.c:153-158
+    else if (P.prediction_type == 1 || n <= P.max_prediction_order) tree = T_FIXED;
+    else tree = T_LPC;
+
+    const int omethod = P.order_method;
+    const int min_order = P.min_prediction_order;
+    const int max_order = (tree == T_FIXED) ? min(P.max_prediction_order, 4) : P.max_prediction_order;
+
+    // iteration state
+    int it = 0;                 // FIXED: order; LEVEL: index; SEARCH: row
+    int best = 0;               // FIXED: order; LPC: zero-based row
+    uint32_t best_bits = 0, last_bits = 0;
+    bool have_best = false;
+    int lg_step = 16, lg_last = 0, lg_pos = 3;      // log search
+    bool final_pass = false;
+
+    if (tree == T_FIXED) { it = min_order; best = min_order; }
+    if (tree == T_LPC) {
+        if (omethod == 0) { best = max_order - 1; final_pass = true; }
+        else if (omethod == 1) { best = opt_all[s] - 1; final_pass = true; }
+        else if (omethod <= 4) { it = (1 << (omethod - 1)) - 1; best = max_order - 1; }
+        else if (omethod == 5) { it = 0; best = 0; }
+        else {
+            best = min_order - 1 + (max_order - min_order) / 3;
+            if (tid < FHIP_MAX_ORDER) l.trial[tid] = 0xFFFFFFFFu;
+            __syncthreads();
+            lg_step = 32;       // first pick halves it to 16
+        }
+    }
+
+    if (tree == T_CONST || tree == T_VERB) {
+        type = type_code = (tree == T_CONST) ? FHIP_SUB_CONSTANT : FHIP_SUB_VERBATIM;
+        est_bits = (uint32_t)(tree == T_CONST ? e.obits : e.obits * n);
+        residual_fixed<C>(e, r, 0);
+    } else {
+        for (;;) {
+            // ---- pick the next candidate (cand: FIXED order / LPC row) ----
+            int cand = -1;
+            if (!final_pass) {
+                if (tree == T_FIXED) {
+                    if (it <= max_order) cand = it;
+                } else if (omethod <= 4) {
+                    // optimize.c:202-223: level indices high -> low
+                    if (it >= 0) {
+                        const int levels = 1 << (omethod - 1);
+                        cand = min_order + (((max_order - min_order + 1) * (it + 1)) / levels) - 2;
+                        if (cand < 0) cand = 0;
+                    }
+                } else if (omethod == 5) {
+                    // optimize.c:224-238: rows 0..max-1, min_order ignored
+                    if (it < max_order) cand = it;
+                } else {
+                    // optimize.c:239-261 log search, bits[] in l.trial
+                    for (;;) {
+                        if (lg_pos == 3) {
+                            lg_step >>= 1;
+                            if (lg_step == 0) break;
+                            lg_last = best;
+                            lg_pos = 0;
+                        }
+                        const int i = lg_last + (lg_pos - 1) * lg_step;
+                        lg_pos++;
+                        if (i < min_order - 1 || i >= max_order || l.trial[i] < 0xFFFFFFFFu) continue;
+                        cand = i;
+                        break;
+                    }
+                }
+                if (cand < 0) {
+                    // candidates exhausted: FIXED keeps the last residual when
+                    // the winner was tried last (optimize.c:184-189)
+                    if (tree == T_FIXED && best == max_order) { est_bits = last_bits; break; }
+                    final_pass = true;
+                }
+            }
+            if (final_pass) cand = best;
+
+            // ---- evaluate it ----
+            uint32_t b;
+            if (tree == T_FIXED) {
+                residual_fixed<C>(e, r, cand);
+                b = rice_search<C>(e, r, cand, false);
+            } else {
+                residual_lpc<C>(e, r, cand + 1, crow_base + cand * FHIP_MAX_ORDER, srow[cand]);
+                b = rice_search<C>(e, r, cand + 1, true);
+            }
+            if (final_pass) { est_bits = b; break; }
+
+            // ---- fold it into the running decision ----
+            last_bits = b;
+            if (tree == T_FIXED) {
+                if (!have_best || b < best_bits) { best_bits = b; best = cand; }   // strict '<', optimize.c:177
+                it++;
+            } else if (omethod <= 4) {
+                if (!have_best) best_bits = b;              // index levels-1: opt_order stays max_order-1
+                else if (b < best_bits) { best_bits = b; best = cand; }
+                it--;
+            } else if (omethod == 5) {
+                if (!have_best || b < best_bits) { best_bits = b; best = cand; }
+                it++;
+            } else {
+                if (tid == 0) l.trial[cand] = b;
+                __syncthreads();
+                if (b < l.trial[best]) best = cand;         // optimize.c:256
+            }
+            have_best = true;
+        }
+        if (tree == T_FIXED) {
+            order = best;
+            type = FHIP_SUB_FIXED;
+            type_code = FHIP_SUB_FIXED | order;
+        } else {
+            order = best + 1;
+            shift = srow[best];
+            type = FHIP_SUB_LPC;
+            type_code = FHIP_SUB_LPC | (order - 1);
+        }
+        has_rice = true;
+    }
+
+    const int porder = has_rice ? l.misc[M_PORDER] : 0;
+    const int method = has_rice ? l.misc[M_METHOD] : 0;
+
+    // FlacSubframe.residual
+    if (res_out) {
+        int32_t *dst = res_out + (size_t)s * n;
+#pragma unroll
+        for (int o = 0; o < C; o++) {
+            const int i = e.i0 + o;
+            if (o < e.chunk && i < n) dst[i] = r[o];
+        }
+    }
+
+    // encode.c:766-798 output_residual, all partitions and codewords at once
+    long long total_bits = 0;
+    if (has_rice) {
+        const int psz = n >> porder;
+        const int pbits = 4 + method;
+        const int heap0 = (1 << porder) - 1;
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int o = 0; o < C; o++) {
+            const int i = e.i0 + o;
+            if (o < e.chunk && i < n && i >= order) {
+                const int part = i / psz;
+                const int k = l.kpar[heap0 + part];
+                if (part > 0 && i == part * psz) mine += pbits;
+                mine += (unsigned long long)(zigzag32(r[o]) >> k) + 1 + k;
+            }
+        }
+        unsigned long long incl = wave_incl_scan_u64(mine, lane);
+        if (lane == 63) l.scan[wv] = incl;
+        __syncthreads();
+        unsigned long long base = 6 + pbits;           // section header + partition 0 parameter
+        for (int w = 0; w < wv; w++) base += l.scan[w];
+        const unsigned long long tot = 6 + pbits + l.scan[0] + l.scan[1] + l.scan[2] + l.scan[3];
+        const unsigned long long my_off = base + incl - mine;
+        total_bits = (tot > 0x7FFFFFFFull) ? 0x7FFFFFFFll : (long long)tot;
+
+        if (bits_out) {
+            if (tot > (unsigned long long)slot_bytes * 8ull) {
+                total_bits = -1;
+            } else {
+                uint32_t *dst32 = reinterpret_cast<uint32_t *>(bits_out + (size_t)s * slot_bytes);
+                const long long nwords = (long long)((tot + 31) >> 5);
+                for (long long wlo = 0; wlo < nwords; wlo += ENC_WWORDS) {
+                    __syncthreads();
+                    for (int q = tid; q < ENC_WWORDS; q += NT) l.bits[q] = 0;
+                    __syncthreads();
+                    if (tid == 0) {
+                        put_bits(l.bits, wlo, 0, 2, (uint32_t)method);
+                        put_bits(l.bits, wlo, 2, 4, (uint32_t)porder);
+                        put_bits(l.bits, wlo, 6, pbits, (uint32_t)l.kpar[heap0]);
+                    }
+                    long long pos = (long long)my_off;
+#pragma unroll
+                    for (int o = 0; o < C; o++) {
+                        const int i = e.i0 + o;
+                        if (o < e.chunk && i < n && i >= order) {
+                            const int part = i / psz;
+                            const int k = l.kpar[heap0 + part];
+                            if (part > 0 && i == part * psz) {
+                                put_bits(l.bits, wlo, pos, pbits, (uint32_t)k);
+                                pos += pbits;
+                            }
+                            // bitio.h:120-141: q zeros, a one, k low bits
+                            const uint32_t u = zigzag32(r[o]);
+                            const uint32_t q = u >> k;
+                            put_bits(l.bits, wlo, pos + q, k + 1, (1u << k) | (u & ((1u << k) - 1u)));
+                            pos += (long long)q + 1 + k;
+                        }
+                    }
+                    __syncthreads();
+                    const long long cnt = (nwords - wlo < ENC_WWORDS) ? (nwords - wlo) : (long long)ENC_WWORDS;
+                    for (int q = tid; q < cnt; q += NT)
+                        dst32[wlo + q] = __builtin_bswap32(l.bits[q]);
+                }
+            }
+        }
+    }
+
+    // FlacSubframe / RiceContext fields
+    if (tid == 0) {
+        out->type = type;
+        out->type_code = type_code;
+        out->order = order;
+        out->shift = shift;
+        out->rice_method = method;
+        out->porder = porder;
+        out->est_bits = est_bits;
+        out->rice_nbits = (int32_t)total_bits;
+        out->reserved = 0;
+    }
+    if (tid < FHIP_MAX_ORDER)
+        out->coefs[tid] = (type == FHIP_SUB_LPC && tid < order) ? l.coef[tid] : 0;
+    {
+        const int np = has_rice ? (1 << porder) : 0;
+        out->rparams[tid] = (tid < np) ? l.kpar[np - 1 + tid] : 0;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+
+hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *pcm,
+                          int nframes, int n, int32_t *smp, fhip_subframe_info *info)
+{
+    const int nch = p.channels;
+    const int blocks = (nch == 2) ? nframes : nframes * nch;
+    const size_t lds = sizeof(int32_t) * (size_t)n * (nch == 2 ? 2 : 1);
+    if (blocks == 0) return hipSuccess;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prepare),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (er != hipSuccess) return er;
+    hipLaunchKernelGGL(k_prepare, dim3(blocks), dim3(NT), lds, st, pcm, smp, info, n, nch,
+                       p.bits_per_sample, p.stereo_method == 1 ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
+                           int max_order, double *autoc)
+{
+    if (nsub == 0) return hipSuccess;
+    const int nl = max_order + 1;
+    int G = WAVE / nl;
+    if (G > AC_GMAX) G = AC_GMAX;
+    if (G < 1) G = 1;
+    const int per_block = 4 * G;
+    const int blocks = (nsub + per_block - 1) / per_block;
+    // the window constant is computed on the host exactly as lpc.c:34 does
+    const double c = (2.0 / (n - 1.0)) - 1.0;
+    hipLaunchKernelGGL(k_autocorr, dim3(blocks), dim3(NT), 0, st, smp, autoc, nsub, n,
+                       max_order, G, c);
+    return hipGetLastError();
+}
+
+hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_order,
+                      int precision, int omethod, int32_t *coefs, int32_t *shift,
+                      int32_t *opt_order)
+{
+    if (nsub == 0) return hipSuccess;
+    const int blocks = (nsub + LPC_NT - 1) / LPC_NT;
+    hipLaunchKernelGGL(k_lpc, dim3(blocks), dim3(LPC_NT), 0, st, autoc, nsub, max_order,
+                       precision, omethod, coefs, shift, opt_order);
+    return hipGetLastError();
+}
+
+size_t encode_lds_bytes(int n)
+{
+    if (n < 1 || n > FHIP_MAX_BLOCK) return 0;
+    size_t off[10];
+    return enc_lds_layout(n, off);
+}
+
+hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *smp,
+                         int nsub, int n, const int32_t *coefs, const int32_t *shift,
+                         const int32_t *opt_order, fhip_subframe_info *info,
+                         int32_t *residual, uint8_t *bits, int64_t slot_bytes)
+{
+    if (nsub == 0) return hipSuccess;
+    const size_t lds = encode_lds_bytes(n);
+    if (lds == 0) return hipErrorInvalidValue;
+    const int chunk = (n + NT - 1) / NT;
+#define LAUNCH_ENC(CC)                                                                       \
+    do {                                                                                     \
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CC>),   \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                            (int)lds);                                       \
+        if (er != hipSuccess) return er;                                                     \
+        hipLaunchKernelGGL(k_encode<CC>, dim3(nsub), dim3(NT), lds, st, p, n, smp, coefs,    \
+                           shift, opt_order, info, residual, bits, (long long)slot_bytes);   \
+    } while (0)
+    if (chunk <= 16) LAUNCH_ENC(16);
+    else if (chunk <= 32) LAUNCH_ENC(32);
+    else LAUNCH_ENC(64);
+#undef LAUNCH_ENC
+    return hipGetLastError();
+}
+
+}  // namespace fhip

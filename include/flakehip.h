@@ -1,0 +1,196 @@
+/*
+ * flakehip.h -- C ABI of the MI355X (gfx950) prediction/entropy layer.
+ *
+ * This is the drop-in boundary: the internal seam of libflake that the HIP
+ * layer replaces is
+ *
+ *     int encode_residual(FlacEncodeContext *ctx, int ch)      optimize.h:27
+ *                                                              optimize.c:124-276
+ * together with its feeder stages in encode_frame() (encode.c:932-942:
+ * copy_samples, channel_decorrelation, remove_wasted_bits) and the residual
+ * section of output_subframes() (encode.c:766-798 + bitio.h:120-141) --
+ * batched over many independent frames.  Everything here is plain C: no HIP,
+ * no C++ and no torch types cross the boundary.  Pointers documented as
+ * "device" are hipMalloc'd addresses (e.g. a torch tensor's data_ptr()).
+ *
+ * Error convention follows libflake (negative int on failure, encode.c:925-992)
+ * with distinct codes; nothing aborts or throws across the ABI.
+ *
+ * File:line citations are relative to the reference tree (/root/reference).
+ */
+#ifndef FLAKEHIP_H
+#define FLAKEHIP_H
+
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define FHIP_API __attribute__((visibility("default")))
+#else
+#define FHIP_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FHIP_MAX_ORDER   32     /* MAX_LPC_ORDER, lpc.h:25 */
+#define FHIP_MAX_PARTS   256    /* MAX_PARTITIONS, rice.h:34-35 */
+#define FHIP_MAX_CH      8      /* FLAC_MAX_CH, encode.h:33 */
+#define FHIP_MAX_LAGS    (FHIP_MAX_ORDER + 1)
+
+/* largest block the kernels keep resident in LDS; larger blocks return
+ * FHIP_E_UNSUPPORTED (the reference allows up to 65535, encode.h:35) */
+#define FHIP_MAX_BLOCK   16384
+
+enum {
+    FHIP_OK            =  0,
+    FHIP_E_GENERIC     = -1,    /* libflake's only code */
+    FHIP_E_HIP         = -2,    /* a HIP runtime call failed; see fhip_last_error() */
+    FHIP_E_UNSUPPORTED = -3,    /* valid libflake parameters this layer does not cover */
+    FHIP_E_INVALID     = -4,    /* parameters flake_validate_params() would reject */
+    FHIP_E_NOMEM       = -5
+};
+
+/* subframe types (encode.h:37-40) and channel modes (encode.h:42-46) */
+enum { FHIP_SUB_CONSTANT = 0, FHIP_SUB_VERBATIM = 1, FHIP_SUB_FIXED = 8, FHIP_SUB_LPC = 32 };
+enum { FHIP_CH_NOT_STEREO = 0, FHIP_CH_LEFT_RIGHT = 1, FHIP_CH_LEFT_SIDE = 8,
+       FHIP_CH_RIGHT_SIDE = 9, FHIP_CH_MID_SIDE = 10 };
+
+/*
+ * The fields of FlakeContext / FlakeEncodeParams (flake.h:59-197) that the
+ * path reads, with the same names and value ranges, plus lpc_precision
+ * (FlacEncodeContext.lpc_precision, always 15: encode.c:443).
+ */
+typedef struct fhip_params {
+    int channels;                /* 1..8 */
+    int sample_rate;
+    int bits_per_sample;         /* 4..32 */
+    int block_size;              /* params.block_size: the largest block */
+    int order_method;            /* FLAKE_ORDER_METHOD_* 0..6, flake.h:38-46 */
+    int stereo_method;           /* 0 independent, 1 estimate, flake.h:48-51 */
+    int prediction_type;         /* 0 none, 1 fixed, 2 levinson, flake.h:53-57 */
+    int min_prediction_order;
+    int max_prediction_order;
+    int min_partition_order;
+    int max_partition_order;
+    int variable_block_size;
+    int allow_vbs;
+    int lpc_precision;
+} fhip_params;
+
+/*
+ * What encode_residual() leaves in FlacSubframe (encode.h:52-63) and its
+ * RiceContext (rice.h:41-46), one record per (frame, channel).
+ */
+typedef struct fhip_subframe_info {
+    int32_t  type;               /* FHIP_SUB_* */
+    int32_t  type_code;
+    int32_t  order;
+    int32_t  shift;
+    int32_t  obits;
+    int32_t  wasted;             /* FlacSubframe.wasted_bits */
+    int32_t  rice_method;        /* RiceContext.method: 0 RICE, 1 RICE2 */
+    int32_t  porder;             /* RiceContext.porder */
+    uint32_t est_bits;           /* return value of encode_residual() */
+    int32_t  ch_mode;            /* FlacFrame.ch_mode, replicated per channel */
+    int32_t  rice_nbits;         /* exact bit length of the residual section as
+                                    output_residual() writes it; 0 when the
+                                    subframe has none; -1 when it does not fit
+                                    the caller's slot (nothing written) */
+    int32_t  reserved;
+    int32_t  coefs[FHIP_MAX_ORDER];
+    int32_t  rparams[FHIP_MAX_PARTS];   /* RiceContext.params[0 .. 2^porder) */
+} fhip_subframe_info;
+
+typedef struct fhip_ctx fhip_ctx;
+
+/* ---- lifetime ------------------------------------------------------- */
+
+/* Number of HIP devices, or a negative code. */
+FHIP_API int fhip_device_count(void);
+
+/*
+ * Create a handle bound to one device.  Plays the role of the buffers
+ * flake_encode_init() allocates (encode.c:378-472): device workspaces for
+ * max_frames frames of p->block_size samples per channel, so that no call
+ * below allocates.  Returns FHIP_E_INVALID where flake_validate_params()
+ * (encode.c:268-373) returns -1.
+ */
+FHIP_API int fhip_create(fhip_ctx **out, int device, const fhip_params *p, int max_frames);
+FHIP_API void fhip_destroy(fhip_ctx *ctx);                       /* flake_encode_close, encode.c:1010 */
+
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL
+ * returns to the handle's own stream. */
+FHIP_API int fhip_set_stream(fhip_ctx *ctx, void *hip_stream);
+FHIP_API int fhip_sync(fhip_ctx *ctx);
+
+FHIP_API const char *fhip_strerror(int code);
+FHIP_API const char *fhip_last_error(const fhip_ctx *ctx);
+FHIP_API const char *fhip_version(void);                          /* flake_get_version, encode.c:1028 */
+
+/* ---- the hot path --------------------------------------------------- */
+
+/*
+ * One batch of nframes consecutive blocks, all of block_size samples per
+ * channel.  All pointers are DEVICE pointers.  pcm follows
+ * flake_encode_frame()'s input contract (flake.h:229, encode.c:541-553):
+ * channel-interleaved int32, sign-extended to bits_per_sample.
+ * Outputs other than info may be NULL.  Asynchronous on the handle's stream.
+ */
+typedef struct fhip_batch {
+    const int32_t      *pcm;          /* [nframes][block_size][channels] */
+    int                 nframes;
+    int                 block_size;
+    fhip_subframe_info *info;         /* [nframes*channels] */
+    int32_t            *residual;     /* [nframes][channels][block_size] FlacSubframe.residual */
+    uint8_t            *rice_bits;    /* [nframes*channels][rice_slot_bytes]: the residual
+                                         section of each subframe, MSB-first from bit 0 of
+                                         its slot; slot bytes past the section are untouched */
+    int64_t             rice_slot_bytes;   /* multiple of 4 */
+    /* stage outputs for parity checks; NULL in production */
+    int32_t            *samples;      /* [nframes][channels][block_size] FlacSubframe.samples
+                                         after decorrelation and wasted-bits removal */
+    double             *autoc;        /* [nframes*channels][FHIP_MAX_LAGS] compute_autocorr */
+} fhip_batch;
+
+FHIP_API int fhip_encode_subframes_dev(fhip_ctx *ctx, const fhip_batch *b);
+
+/* Same with HOST pointers: copies in, runs, copies out, synchronises. */
+FHIP_API int fhip_encode_subframes(fhip_ctx *ctx, const fhip_batch *b_host);
+
+/* ---- stage entry points (HOST pointers, synchronous) ---------------- */
+/* Each mirrors one reference function over a batch, for stage-level parity. */
+
+/* lpc_calc_coefs(), lpc.c:224-257, for nsub blocks of n samples.
+ * coefs [nsub][32][32], shift [nsub][32] (rows the reference leaves
+ * unwritten are zero), opt_order [nsub]; autoc [nsub][33] optional. */
+FHIP_API int fhip_lpc_calc_coefs(fhip_ctx *ctx, const int32_t *samples, int nsub, int n,
+                        int max_order, int precision, int omethod,
+                        int32_t *coefs, int32_t *shift, int32_t *opt_order,
+                        double *autoc);
+
+/* encode_residual(), optimize.c:124-276, on prepared samples [nsub][n] with
+ * info[s].obits set by the caller; uses the handle's params. */
+FHIP_API int fhip_encode_residual(fhip_ctx *ctx, const int32_t *samples, int nsub, int n,
+                         fhip_subframe_info *info, int32_t *residual,
+                         uint8_t *rice_bits, int64_t rice_slot_bytes);
+
+/* copy_samples + channel_decorrelation + remove_wasted_bits,
+ * encode.c:541-694, for nframes blocks; fills info[].obits/wasted/ch_mode. */
+FHIP_API int fhip_prepare_frames(fhip_ctx *ctx, const int32_t *pcm, int nframes, int n,
+                        int32_t *samples, fhip_subframe_info *info);
+
+/* ---- measurement ---------------------------------------------------- */
+
+/* With profiling on, every kernel launch of the hot path is bracketed by
+ * hipEvents on the launch stream. */
+FHIP_API int fhip_set_profiling(fhip_ctx *ctx, int on);
+/* After fhip_sync(): accumulated milliseconds and launch counts per kernel
+ * since the last reset; returns the number of kernels (<= cap). */
+FHIP_API int fhip_get_kernel_times(fhip_ctx *ctx, const char **names, double *ms, int *launches,
+                          int cap, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLAKEHIP_H */

@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the FLAC prediction/entropy hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+One *step* is one pass of the hot path (K0 prepare -> K1 autocorrelation ->
+K2 Levinson/quantise -> K3 residual + Rice search + Rice bit emit) over one
+batch of synthetic PCM that is already resident in HBM: BASELINE.json
+configs[1] -- stereo 16-bit 44.1 kHz, block size 4096, LPC order 8 (level-5
+parameters with the MAX order method), 4096 frames per GPU.  Frames are
+independent, so with N ranks each rank encodes its own 4096-frame shard of a
+4096*N-frame job (weak scaling); the only collective is the all-reduce of
+{frames, residual bits} (RCCL), issued on a side stream.
+
+Prints ONE JSON line on rank 0 (see the keys in main()).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="rough budget of CPU work for the cpu_baseline leg")
+    ap.add_argument("--profile-steps", type=int, default=10,
+                    help="extra steps with per-kernel hipEvent timing for the roofline object")
+    ap.add_argument("--with-residual", action="store_true",
+                    help="also write the int32 residual (stage A of SURVEY 8d)")
+    return ap.parse_args()
+
+
+def cpu_baseline(params, n, budget_s):
+    """The CPU restatement (oracle) on a bounded sample of the same workload,
+    one thread, timed on this box's host cores.  Reported, not the target."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib
+    import flake_amd
+
+    orc = oraclelib.Oracle()
+    frames = 512
+    pcm = flake_amd.synth_pcm(frames, n, params.channels, params.bits_per_sample)
+    slot = flake_amd.rice_slot_bytes(params, n)
+    t0 = time.perf_counter()
+    orc.encode_subframes_batch(params, pcm, n, want_residual=False, slot_bytes=slot)
+    dt1 = time.perf_counter() - t0
+    reps = max(1, min(64, int(budget_s / max(dt1, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.encode_subframes_batch(params, pcm, n, want_residual=False, slot_bytes=slot)
+    dt = time.perf_counter() - t0
+    samples = reps * frames * n * params.channels
+    return {
+        "value": round(samples / dt / 1e6, 3),
+        "unit": "Msamples/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{reps} x {frames} frames of the same synthetic workload "
+                  f"({samples / 1e6:.1f} Msamples, {dt:.1f} s), oracle/flake_oracle.c, "
+                  "prepare + encode_residual + Rice emit",
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import flake_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    # ---- workload: BASELINE.json configs[1] --------------------------------
+    p = flake_amd.level_params(5, channels=2, bits_per_sample=16, sample_rate=44100,
+                               order_method=flake_amd.OM_MAX)
+    n = p.block_size
+    nframes = args.frames
+    nsub = nframes * p.channels
+    slot = flake_amd.rice_slot_bytes(p, n)
+
+    pcm_host = flake_amd.synth_pcm(nframes, n, p.channels, p.bits_per_sample,
+                                   first_frame=rank * nframes)
+    pcm = torch.from_numpy(pcm_host).to(dev)
+    info_bytes = flake_amd.INFO_DTYPE.itemsize
+    nbuf = 2 if world > 1 else 1
+    infos = [torch.zeros(nsub * info_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    bits = [torch.zeros(nsub * slot, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    resid = torch.zeros((nframes, p.channels, n), dtype=torch.int32, device=dev) \
+        if args.with_residual else None
+
+    enc = flake_amd.Encoder(p, max_frames=nframes, device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    enc.set_stream(stream.cuda_stream)
+    side = torch.cuda.Stream(dev) if world > 1 else None
+    stats = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def step(i):
+        b = i % nbuf
+        enc.encode_subframes_dev(pcm, nframes, n, infos[b], residual=resid,
+                                 rice_bits=bits[b], slot_bytes=slot)
+        if world > 1:
+            # the job's only exchange: {frames, residual bits}, off the data path
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                nb = infos[b].view(torch.int32).view(nsub, info_bytes // 4)[:, 10]
+                stats[0] = nframes
+                stats[1] = nb.clamp(min=0).sum()
+                dist.all_reduce(stats)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    samples_per_step = nframes * n * p.channels * world
+    value = samples_per_step * args.steps / dt / 1e6
+
+    # ---- roofline of the dominant kernel (rank 0, hipEvents on the launch stream)
+    roofline = None
+    cpu = None
+    if rank == 0:
+        info_np = np.frombuffer(infos[0].cpu().numpy().tobytes(), dtype=flake_amd.INFO_DTYPE)
+        rice_bytes = int(((info_np["rice_nbits"].clip(min=0) + 31) // 32 * 4).sum())
+        alg_bytes = (nframes * n * p.channels * 4          # int32 PCM in
+                     + rice_bytes                          # packed residual sections out
+                     + nsub * info_bytes                   # side info out
+                     + (nframes * n * p.channels * 4 if args.with_residual else 0))
+        enc.set_profiling(True)
+        enc.kernel_times(reset=True)
+        for i in range(args.profile_steps):
+            enc.encode_subframes_dev(pcm, nframes, n, infos[0], residual=resid,
+                                     rice_bits=bits[0], slot_bytes=slot)
+        enc.sync()
+        kt = enc.kernel_times(reset=True)
+        enc.set_profiling(False)
+        per = {k: (ms / max(c, 1)) for k, (ms, c) in kt.items() if c}
+        dom = max(per, key=per.get)
+        achieved = alg_bytes / (per[dom] * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm", "kernel": dom,
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms": {k: round(v, 4) for k, v in per.items()},
+            "pipeline_achieved": round(alg_bytes / (sum(per.values()) * 1e-3) / 1e9, 1),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(p, n, args.cpu_seconds)
+
+    if world > 1:
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+
+    if rank == 0:
+        out = {
+            "metric": "Msamples/s encoded, 16-bit stereo 44.1k blocksize 4096 LPC-8",
+            "value": round(value, 2),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64/f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: stereo 16-bit 44.1 kHz, blocksize 4096, LPC max order 8 "
+                            "(level-5 params, order method MAX, partition orders 0-5, stereo "
+                            "estimate), synthetic resonator PCM resident in HBM",
+                "frames_per_gpu": nframes,
+                "samples_per_step": samples_per_step,
+                "outputs": "subframe info + packed Rice residual sections"
+                           + (" + int32 residual" if args.with_residual else ""),
+                "parallelism": f"frame-sharded x{world}",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if world > 1:
+            out["job_frames"] = int(stats[0].item())
+            out["job_residual_bits"] = int(stats[1].item())
+        print(json.dumps(out), flush=True)
+
+    enc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

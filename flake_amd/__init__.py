@@ -96,14 +96,15 @@ def level_params(level: int, channels: int = 2, bits_per_sample: int = 16,
     return p
 
 
-# numpy view of fhip_subframe_info (1200 bytes)
+# numpy view of fhip_subframe_info (1328 bytes)
 INFO_DTYPE = np.dtype([
     ("type", "<i4"), ("type_code", "<i4"), ("order", "<i4"), ("shift", "<i4"),
     ("obits", "<i4"), ("wasted", "<i4"), ("rice_method", "<i4"), ("porder", "<i4"),
     ("est_bits", "<u4"), ("ch_mode", "<i4"), ("rice_nbits", "<i4"), ("reserved", "<i4"),
     ("coefs", "<i4", (MAX_ORDER,)), ("rparams", "<i4", (MAX_PARTS,)),
+    ("warmup", "<i4", (MAX_ORDER,)),
 ])
-assert INFO_DTYPE.itemsize == 1200
+assert INFO_DTYPE.itemsize == 1328
 
 
 class Batch(C.Structure):

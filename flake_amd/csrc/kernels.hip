@@ -993,6 +993,11 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         const int np = has_rice ? (1 << porder) : 0;
         out->rparams[tid] = (tid < np) ? l.kpar[np - 1 + tid] : 0;
     }
+    // warm-up samples (= residual[0..order)); [0] carries a CONSTANT's value
+    if (tid < FHIP_MAX_ORDER) {
+        const int nw = (type == FHIP_SUB_CONSTANT) ? 1 : order;
+        out->warmup[tid] = (tid < nw && tid < n) ? l.smp[padidx(tid)] : 0;
+    }
 }
 
 }  // namespace

@@ -100,6 +100,10 @@ typedef struct fhip_subframe_info {
     int32_t  reserved;
     int32_t  coefs[FHIP_MAX_ORDER];
     int32_t  rparams[FHIP_MAX_PARTS];   /* RiceContext.params[0 .. 2^porder) */
+    int32_t  warmup[FHIP_MAX_ORDER];    /* residual[0 .. order): the warm-up samples the
+                                           subframe header carries (encode.c:834-837,
+                                           :851-854); [0] is the value of a CONSTANT
+                                           subframe (encode.c:800-807) */
 } fhip_subframe_info;
 
 typedef struct fhip_ctx fhip_ctx;

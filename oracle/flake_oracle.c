@@ -435,8 +435,8 @@ int64_t fo_residual_section_bits(const fo_subframe *sf, const int32_t *res, int 
  * Candidate evaluation order and tie rules follow the reference (8-Q8);
  * the winning order is re-encoded at the end exactly as there.
  */
-int fo_encode_residual(const fo_params *p, fo_subframe *sf,
-                       const int32_t *smp, int32_t *res, int n)
+static int encode_residual_core(const fo_params *p, fo_subframe *sf,
+                                const int32_t *smp, int32_t *res, int n)
 {
     int i;
     sf->order = 0; sf->shift = 0; sf->rice_method = 0; sf->porder = 0;
@@ -556,6 +556,18 @@ int fo_encode_residual(const fo_params *p, fo_subframe *sf,
     sf->est_bits = ret;
     free(coefs);
     return (int)ret;
+}
+
+int fo_encode_residual(const fo_params *p, fo_subframe *sf,
+                       const int32_t *smp, int32_t *res, int n)
+{
+    int rc = encode_residual_core(p, sf, smp, res, n);
+    memset(sf->warmup, 0, sizeof(sf->warmup));
+    if (rc >= 0) {
+        if (sf->type == FO_SUB_CONSTANT) sf->warmup[0] = res[0];
+        for (int w = 0; w < sf->order && w < n; w++) sf->warmup[w] = res[w];
+    }
+    return rc;
 }
 
 /* ------------------------------------------------------------------ */

@@ -79,6 +79,7 @@ typedef struct fo_subframe {
     int32_t reserved;
     int32_t coefs[FO_MAX_ORDER];
     int32_t rparams[FO_MAX_PARTS];
+    int32_t warmup[FO_MAX_ORDER];   /* residual[0..order); [0] = the CONSTANT value */
 } fo_subframe;
 
 void fo_set_defaults(fo_params *p, int level);                 /* encode.c:158-266 */

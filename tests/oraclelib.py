@@ -25,6 +25,7 @@ INFO_DTYPE = np.dtype([
     ("obits", "<i4"), ("wasted", "<i4"), ("rice_method", "<i4"), ("porder", "<i4"),
     ("est_bits", "<u4"), ("ch_mode", "<i4"), ("rice_nbits", "<i4"), ("reserved", "<i4"),
     ("coefs", "<i4", (MAX_ORDER,)), ("rparams", "<i4", (MAX_PARTS,)),
+    ("warmup", "<i4", (MAX_ORDER,)),
 ])
 
 

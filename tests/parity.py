@@ -20,6 +20,8 @@ def assert_info_equal(got: np.ndarray, exp: np.ndarray, what: str = "") -> None:
             o = exp["order"][s]
             assert (got["coefs"][s][:o] == exp["coefs"][s][:o]).all(), (
                 what, "coefs", s, got["coefs"][s][:o], exp["coefs"][s][:o])
+        nw = 1 if exp["type"][s] == 0 else exp["order"][s]
+        assert (got["warmup"][s][:nw] == exp["warmup"][s][:nw]).all(), (what, "warmup", s)
         if exp["type"][s] in (8, 32):
             npart = 1 << exp["porder"][s]
             assert (got["rparams"][s][:npart] == exp["rparams"][s][:npart]).all(), (

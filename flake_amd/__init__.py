@@ -151,6 +151,7 @@ def load_library() -> C.CDLL:
         "fhip_lpc_calc_coefs": (i, [vp, vp, i, i, i, i, i, vp, vp, vp, vp]),
         "fhip_encode_residual": (i, [vp, vp, i, i, vp, vp, vp, i64]),
         "fhip_prepare_frames": (i, [vp, vp, i, i, vp, vp]),
+        "fhip_calc_rice_params": (i, [vp, vp, i, i, i, i, i, i, i, vp, vp, i64]),
         "fhip_set_profiling": (i, [vp, i]),
         "fhip_get_kernel_times": (i, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                       C.POINTER(i), i, i]),
@@ -167,7 +168,8 @@ ABI_SYMBOLS = (
     "fhip_device_count", "fhip_create", "fhip_destroy", "fhip_set_stream", "fhip_sync",
     "fhip_strerror", "fhip_last_error", "fhip_version", "fhip_encode_subframes_dev",
     "fhip_encode_subframes", "fhip_lpc_calc_coefs", "fhip_encode_residual",
-    "fhip_prepare_frames", "fhip_set_profiling", "fhip_get_kernel_times",
+    "fhip_prepare_frames", "fhip_calc_rice_params", "fhip_set_profiling",
+    "fhip_get_kernel_times",
 )
 
 
@@ -304,6 +306,18 @@ class Encoder:
             self._h, _ptr(samples), nsub, n, _ptr(info), _ptr(res), _ptr(bits), slot),
             "fhip_encode_residual")
         return {"info": info, "residual": res, "rice_bits": bits, "slot_bytes": slot}
+
+    def calc_rice_params(self, residual: np.ndarray, pred_order: int, lpc: bool, bps: int,
+                         pmin: int, pmax: int, slot_bytes: int = 0) -> dict:
+        """calc_rice_params_lpc/_fixed (rice.c:173-187) + residual emit on given residuals."""
+        residual = np.ascontiguousarray(residual, dtype=np.int32)
+        nsub, n = residual.shape
+        info = np.zeros(nsub, dtype=INFO_DTYPE)
+        bits = np.zeros((nsub, slot_bytes), dtype=np.uint8) if slot_bytes else None
+        self._check(self.lib.fhip_calc_rice_params(
+            self._h, _ptr(residual), nsub, n, pred_order, int(lpc), bps, pmin, pmax,
+            _ptr(info), _ptr(bits), slot_bytes), "fhip_calc_rice_params")
+        return {"info": info, "rice_bits": bits}
 
     def prepare_frames(self, pcm: np.ndarray, block_size: int):
         """copy_samples + channel_decorrelation + remove_wasted_bits (encode.c:541-694)."""

@@ -460,4 +460,42 @@ int fhip_encode_residual(fhip_ctx *c, const int32_t *samples, int nsub, int n,
     return fhip_sync(c);
 }
 
+int fhip_calc_rice_params(fhip_ctx *c, const int32_t *residual, int nsub, int n,
+                          int pred_order, int lpc, int bps, int pmin, int pmax,
+                          fhip_subframe_info *info, uint8_t *rice_bits, int64_t rice_slot_bytes)
+{
+    if (!c || !residual || !info) return fail(c, FHIP_E_INVALID, "null argument");
+    const size_t cap = (size_t)c->max_frames * c->p.channels;
+    if (nsub < 0 || (size_t)nsub > cap || n < 1 || n > c->p.block_size)
+        return fail(c, FHIP_E_INVALID, "batch shape out of range");
+    if (n > FHIP_MAX_BLOCK) return fail(c, FHIP_E_UNSUPPORTED, "block_size above FHIP_MAX_BLOCK");
+    if (pred_order < 0 || pred_order > FHIP_MAX_ORDER || pred_order > n || pmin < 0 || pmax > 8 || pmin > pmax)
+        return fail(c, FHIP_E_INVALID, "bad prediction / partition order (rice.c:116-118)");
+    if (rice_bits && (rice_slot_bytes < 4 || (rice_slot_bytes & 3)))
+        return fail(c, FHIP_E_INVALID, "rice_slot_bytes must be a positive multiple of 4");
+    if (nsub == 0) return FHIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t ns = (size_t)nsub;
+    const size_t bits_bytes = rice_bits ? ns * (size_t)rice_slot_bytes : 0;
+    int rc = ensure_staging(c, bits_bytes);
+    if (rc != FHIP_OK) return rc;
+    fhip_params p = c->p;
+    p.min_partition_order = pmin;
+    p.max_partition_order = pmax;
+    std::vector<fhip_subframe_info> seed(ns);
+    std::memset(seed.data(), 0, ns * sizeof(fhip_subframe_info));
+    for (auto &s : seed) s.obits = bps;
+    HIP_TRY(c, hipMemcpyAsync(c->d_smp, residual, ns * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_info, seed.data(), ns * sizeof(fhip_subframe_info), hipMemcpyHostToDevice, c->stream));
+    if (bits_bytes) HIP_TRY(c, hipMemsetAsync(c->d_bits, 0, bits_bytes, c->stream));
+    HIP_TRY(c, fhip::launch_encode(c->stream, p, c->d_smp, nsub, n, c->d_coefs, c->d_shift, c->d_opt,
+                                   c->d_info, nullptr, rice_bits ? c->d_bits : nullptr,
+                                   rice_slot_bytes, pred_order, lpc ? 1 : 0));
+    HIP_TRY(c, hipMemcpyAsync(info, c->d_info, ns * sizeof(fhip_subframe_info), hipMemcpyDeviceToHost, c->stream));
+    if (rice_bits)
+        HIP_TRY(c, hipMemcpyAsync(rice_bits, c->d_bits, bits_bytes, hipMemcpyDeviceToHost, c->stream));
+    rc = fhip_sync(c);
+    return rc;
+}
+
 }  // extern "C"

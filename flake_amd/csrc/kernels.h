@@ -37,7 +37,8 @@ hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_ord
 hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *smp,
                          int nsub, int n, const int32_t *coefs, const int32_t *shift,
                          const int32_t *opt_order, fhip_subframe_info *info,
-                         int32_t *residual, uint8_t *bits, int64_t slot_bytes);
+                         int32_t *residual, uint8_t *bits, int64_t slot_bytes,
+                         int raw_order = -1, int raw_lpc = 0);
 
 // Dynamic-LDS need of K3 for a block size (0 if unsupported).
 size_t encode_lds_bytes(int n);

@@ -31,6 +31,15 @@ __device__ __forceinline__ uint32_t zigzag32(int32_t x)
     return ((uint32_t)x << 1) ^ (uint32_t)(x >> 31);
 }
 
+// bitio.h:128-129, the emit-side fold (v = -2*val-1; v ^= v>>31 in int):
+// equal to zigzag32 only for |x| < 2^30, so the emit uses this one.
+__device__ __forceinline__ uint32_t emit_fold32(int32_t x)
+{
+    int32_t v = (int32_t)(0u - 2u * (uint32_t)x - 1u);
+    v ^= (v >> 31);
+    return (uint32_t)v;
+}
+
 __device__ __forceinline__ int32_t wrap_abs(int32_t a)
 {
     return a < 0 ? (int32_t)(0u - (uint32_t)a) : a;
@@ -715,8 +724,11 @@ __global__ __launch_bounds__(NT)
 void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
               const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
               const int32_t *__restrict__ opt_all, fhip_subframe_info *__restrict__ info,
-              int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes)
+              int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
+              int raw_order, int raw_lpc)
 {
+    // raw_order >= 0: the input already IS a residual; only calc_rice_params_*
+    // (rice.c:173-187) with that prediction order and the emit run.
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     size_t off[10];
     enc_lds_layout(n, off);
@@ -773,8 +785,9 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     // sequence; the last pass re-encodes the winner exactly as the reference
     // does (optimize.c:184-188, :266-275).  Every variable below is uniform
     // across the workgroup.
-    enum { T_CONST, T_VERB, T_FIXED, T_LPC } tree;
-    if (constant) tree = T_CONST;                                        // optimize.c:143-151
+    enum { T_CONST, T_VERB, T_FIXED, T_LPC, T_RAW } tree;
+    if (raw_order >= 0) tree = T_RAW;
+    else if (constant) tree = T_CONST;                                   // optimize.c:143-151
     else if (n < 5 || P.prediction_type == 0) tree = T_VERB;             // optimize.c:153-158
     else if (P.prediction_type == 1 || n <= P.max_prediction_order) tree = T_FIXED;
     else tree = T_LPC;
@@ -805,7 +818,14 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         }
     }
 
-    if (tree == T_CONST || tree == T_VERB) {
+    if (tree == T_RAW) {
+        residual_fixed<C>(e, r, 0);
+        est_bits = rice_search<C>(e, r, raw_order, raw_lpc != 0);
+        order = raw_order;
+        type = raw_lpc ? FHIP_SUB_LPC : FHIP_SUB_FIXED;
+        type_code = type;
+        has_rice = true;
+    } else if (tree == T_CONST || tree == T_VERB) {
         type = type_code = (tree == T_CONST) ? FHIP_SUB_CONSTANT : FHIP_SUB_VERBATIM;
         est_bits = (uint32_t)(tree == T_CONST ? e.obits : e.obits * n);
         residual_fixed<C>(e, r, 0);
@@ -921,7 +941,7 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                 const int part = i / psz;
                 const int k = l.kpar[heap0 + part];
                 if (part > 0 && i == part * psz) mine += pbits;
-                mine += (unsigned long long)(zigzag32(r[o]) >> k) + 1 + k;
+                mine += (unsigned long long)(emit_fold32(r[o]) >> k) + 1 + k;
             }
         }
         unsigned long long incl = wave_incl_scan_u64(mine, lane);
@@ -960,7 +980,7 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                                 pos += pbits;
                             }
                             // bitio.h:120-141: q zeros, a one, k low bits
-                            const uint32_t u = zigzag32(r[o]);
+                            const uint32_t u = emit_fold32(r[o]);
                             const uint32_t q = u >> k;
                             put_bits(l.bits, wlo, pos + q, k + 1, (1u << k) | (u & ((1u << k) - 1u)));
                             pos += (long long)q + 1 + k;
@@ -988,7 +1008,7 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         out->reserved = 0;
     }
     if (tid < FHIP_MAX_ORDER)
-        out->coefs[tid] = (type == FHIP_SUB_LPC && tid < order) ? l.coef[tid] : 0;
+        out->coefs[tid] = (type == FHIP_SUB_LPC && tid < order && raw_order < 0) ? l.coef[tid] : 0;
     {
         const int np = has_rice ? (1 << porder) : 0;
         out->rparams[tid] = (tid < np) ? l.kpar[np - 1 + tid] : 0;
@@ -1060,7 +1080,8 @@ size_t encode_lds_bytes(int n)
 hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *smp,
                          int nsub, int n, const int32_t *coefs, const int32_t *shift,
                          const int32_t *opt_order, fhip_subframe_info *info,
-                         int32_t *residual, uint8_t *bits, int64_t slot_bytes)
+                         int32_t *residual, uint8_t *bits, int64_t slot_bytes,
+                         int raw_order, int raw_lpc)
 {
     if (nsub == 0) return hipSuccess;
     const size_t lds = encode_lds_bytes(n);
@@ -1073,7 +1094,8 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
                                             (int)lds);                                       \
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL(k_encode<CC>, dim3(nsub), dim3(NT), lds, st, p, n, smp, coefs,    \
-                           shift, opt_order, info, residual, bits, (long long)slot_bytes);   \
+                           shift, opt_order, info, residual, bits, (long long)slot_bytes,    \
+                           raw_order, raw_lpc);                                              \
     } while (0)
     if (chunk <= 16) LAUNCH_ENC(16);
     else if (chunk <= 32) LAUNCH_ENC(32);

@@ -179,6 +179,14 @@ FHIP_API int fhip_encode_residual(fhip_ctx *ctx, const int32_t *samples, int nsu
                          fhip_subframe_info *info, int32_t *residual,
                          uint8_t *rice_bits, int64_t rice_slot_bytes);
 
+/* calc_rice_params_lpc() / calc_rice_params_fixed(), rice.c:173-187, plus the
+ * residual section of output_residual() (encode.c:766-798) on GIVEN residuals
+ * [nsub][n]: fills info[].rice_method/porder/rparams/est_bits/rice_nbits. */
+FHIP_API int fhip_calc_rice_params(fhip_ctx *ctx, const int32_t *residual, int nsub, int n,
+                                   int pred_order, int lpc, int bps, int pmin, int pmax,
+                                   fhip_subframe_info *info, uint8_t *rice_bits,
+                                   int64_t rice_slot_bytes);
+
 /* copy_samples + channel_decorrelation + remove_wasted_bits,
  * encode.c:541-694, for nframes blocks; fills info[].obits/wasted/ch_mode. */
 FHIP_API int fhip_prepare_frames(fhip_ctx *ctx, const int32_t *pcm, int nframes, int n,

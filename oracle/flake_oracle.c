@@ -31,6 +31,15 @@ static int32_t wrap_add(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (
 static int32_t wrap_sub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 static int32_t wrap_abs(int32_t a) { return a < 0 ? (int32_t)(0u - (uint32_t)a) : a; }
 
+/* bitio.h:128-129, the EMIT-side sign fold: v = -2*val-1; v ^= v>>31 in int.
+ * Equal to the search-side fold (rice.c:122) for |val| < 2^30 only (8-Q7). */
+static uint32_t emit_fold(int32_t val)
+{
+    int32_t v = (int32_t)(0u - 2u * (uint32_t)val - 1u);
+    v ^= (v >> 31);
+    return (uint32_t)v;
+}
+
 /* ------------------------------------------------------------------ */
 /* parameters: encode.c:158-266 flake_set_defaults                    */
 /* ------------------------------------------------------------------ */
@@ -422,8 +431,7 @@ int64_t fo_residual_section_bits(const fo_subframe *sf, const int32_t *res, int 
         int end = (p + 1) * psize;
         bits += pbits;
         for (; j < end && j < n; j++) {
-            uint32_t x = (uint32_t)res[j];
-            uint32_t u = (x << 1) ^ (uint32_t)(res[j] >> 31);
+            uint32_t u = emit_fold(res[j]);
             bits += (int64_t)(u >> k) + 1 + k;
         }
     }
@@ -715,8 +723,7 @@ static void sink_put_signed(bitsink *s, int nb, int32_t val)
  * then the k low bits of u */
 static void sink_put_rice(bitsink *s, int k, int32_t v)
 {
-    uint32_t x = (uint32_t)v;
-    uint32_t u = (x << 1) ^ (uint32_t)(v >> 31);
+    uint32_t u = emit_fold(v);
     uint32_t q = u >> k;
     if (s->over || (s->nbits + (int64_t)q + 1 + k + 7) / 8 > s->cap) {
         s->over = 1; s->nbits += (int64_t)q + 1 + k; return;

@@ -78,3 +78,160 @@ def test_order_methods_24bit(oracle, omethod):
                                max_prediction_order=12, max_partition_order=8)
     pcm = flake_amd.synth_pcm(8, 4096, 2, 24)
     check(oracle, p, pcm, 4096, f"omethod{omethod}")
+
+
+# ---------------------------------------------------------------------------
+# committed golden vectors (outputs of the real reference functions)
+# ---------------------------------------------------------------------------
+import goldenlib as G                                   # noqa: E402
+from cases import (ODD_BLOCK_SIZES, TINY_BLOCK_SIZES, edge_blocks, param_sets,   # noqa: E402
+                   stereo_frames)
+
+
+def test_golden_ref_lpc():
+    """HIP lpc_calc_coefs vs reference lpc.c outputs: autoc bit-for-bit, coefs, shifts."""
+    z = G.load("ref_lpc.npz")
+    blocks = z["blocks"]
+    p = flake_amd.level_params(5, block_size=blocks.shape[1])
+    with flake_amd.Encoder(p, max_frames=blocks.shape[0]) as enc:
+        for oi, mo in enumerate(z["orders"]):
+            mo = int(mo)
+            for om in range(7):
+                coefs, shift, opt, autoc = enc.lpc_calc_coefs(blocks, mo, 15, om)
+                assert (autoc[:, :mo + 1].view(np.uint64) == z["autoc_bits"][:, oi, :mo + 1]).all()
+                assert (opt == z["opt_order"][:, oi, om]).all(), (mo, om)
+                assert (coefs == z["coefs"][:, oi, om]).all(), (mo, om)
+                assert (shift == z["shift"][:, oi, om]).all(), (mo, om)
+
+
+def test_golden_ref_rice_and_emit():
+    """HIP Rice search + emit vs reference rice.c / bitio.h outputs."""
+    z = G.load("ref_rice.npz")
+    for rec in G.rice_records(z):
+        res = rec["res"][None, :]
+        n = res.shape[1]
+        p = flake_amd.level_params(5, block_size=max(n, 16), bits_per_sample=17)
+        slot = (len(rec["emit"]) + 64 + 3) & ~3
+        with flake_amd.Encoder(p, max_frames=1) as enc:
+            out = enc.calc_rice_params(res, int(rec["order"]), bool(rec["lpc"]), 17,
+                                       int(rec["pmin"]), int(rec["pmax"]), slot_bytes=slot)
+        info = out["info"][0]
+        assert info["est_bits"] == int(rec["bits"])
+        assert info["rice_method"] == rec["method"] and info["porder"] == rec["porder"]
+        npart = 1 << int(rec["porder"])
+        assert (info["rparams"][:npart] == rec["params"][:npart]).all()
+        assert info["rice_nbits"] == int(rec["emit_nbits"])
+        assert (out["rice_bits"][0, :len(rec["emit"])] == rec["emit"]).all()
+
+
+def test_golden_path_configs():
+    """Whole path vs the committed regression vectors for every BASELINE config shape."""
+    z = G.load("path_configs.npz")
+    for name in z["names"]:
+        p = G.params_from_array(z[f"params_{name}"])
+        n = int(z[f"n_{name}"])
+        pcm = z[f"pcm_{name}"]
+        with flake_amd.Encoder(p, max_frames=pcm.shape[0]) as enc:
+            got = enc.encode_subframes(pcm, n)
+        exp_info = z[f"info_{name}"]
+        assert_info_equal(got["info"], exp_info, name)
+        assert_residual_equal(got["residual"], z[f"residual_{name}"], exp_info, name)
+        for s, sec in enumerate(G.split_bits(exp_info, z[f"bits_{name}"])):
+            assert (got["rice_bits"][s, :len(sec)] == sec).all(), (name, s)
+
+
+# ---------------------------------------------------------------------------
+# edge cases, every parameter corner, ragged block sizes
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name,p,n", param_sets(), ids=[c[0] for c in param_sets()])
+def test_param_sets(oracle, name, p, n):
+    nfr = 6 if p.channels <= 2 else 3
+    pcm = flake_amd.synth_pcm(nfr, n, p.channels, p.bits_per_sample, first_frame=40)
+    check(oracle, p, pcm, n, name)
+
+
+@pytest.mark.parametrize("bps", [16, 24])
+def test_stereo_edge_frames(oracle, bps):
+    fr = stereo_frames(4096, bps)
+    pcm = np.stack([fr[k] for k in sorted(fr)])
+    for om in (flake_amd.OM_MAX, flake_amd.OM_EST, flake_amd.OM_LOG):
+        p = flake_amd.level_params(5, bits_per_sample=bps, order_method=om)
+        got, exp = check(oracle, p, pcm, 4096, f"stereo_edges_{bps}_{om}")
+        assert {1, 8, 9, 10} <= set(int(m) for m in exp["info"]["ch_mode"])
+
+
+@pytest.mark.parametrize("bps", [8, 16, 24, 32])
+def test_mono_edge_blocks(oracle, bps):
+    blocks = edge_blocks(4096, bps)
+    pcm = np.stack([blocks[k] for k in sorted(blocks)])[:, :, None]
+    for kw in (dict(order_method=flake_amd.OM_MAX), dict(order_method=flake_amd.OM_SEARCH,
+               max_prediction_order=12, max_partition_order=8), dict(prediction_type=flake_amd.PRED_FIXED,
+               min_prediction_order=0, max_prediction_order=4)):
+        p = flake_amd.level_params(5, channels=1, bits_per_sample=bps, **kw)
+        got, exp = check(oracle, p, pcm, 4096, f"mono_edges_{bps}")
+        types = set(int(t) for t in exp["info"]["type"])
+        assert 0 in types                                   # CONSTANT occurs
+
+
+@pytest.mark.parametrize("n", ODD_BLOCK_SIZES + TINY_BLOCK_SIZES)
+def test_ragged_block_sizes(oracle, n):
+    """Short final blocks, non-power-of-two sizes, n <= max_order (FIXED path),
+    n < 5 (VERBATIM)."""
+    for lvl, ch in ((5, 2), (8, 1), (2, 2)):
+        p = flake_amd.level_params(lvl, channels=ch, block_size=max(n, 16))
+        pcm = flake_amd.synth_pcm(5, n, ch, 16, first_frame=n)
+        check(oracle, p, pcm, n, f"n{n}_l{lvl}")
+
+
+def test_short_block_in_bigger_handle(oracle):
+    """block_size < params.block_size (the last block of a stream, encode.c:987-990)."""
+    p = flake_amd.level_params(5)
+    pcm = flake_amd.synth_pcm(7, 1000, 2, 16)
+    with flake_amd.Encoder(p, max_frames=16) as enc:
+        got = enc.encode_subframes(pcm, 1000)
+    exp = oracle.encode_subframes_batch(p, pcm, 1000, slot_bytes=got["slot_bytes"])
+    assert_info_equal(got["info"], exp["info"], "short")
+    assert_residual_equal(got["residual"], exp["residual"], exp["info"], "short")
+    assert_bits_equal(got["rice_bits"], exp["rice_bits"], exp["info"], "short")
+
+
+def test_slot_too_small_reports_minus_one(oracle):
+    """A residual section that does not fit its slot: rice_nbits = -1, nothing written."""
+    p = flake_amd.level_params(5, channels=1, order_method=flake_amd.OM_MAX)
+    pcm = edge_blocks(4096, 16)["white"][None, :, None]
+    with flake_amd.Encoder(p, max_frames=1) as enc:
+        out = enc.calc_rice_params(pcm[:, :, 0], 0, False, 16, 0, 5, slot_bytes=1024)
+    assert out["info"]["rice_nbits"][0] == -1
+    assert not out["rice_bits"].any()
+
+
+def test_full_size_batch_properties():
+    """BASELINE configs[1] at full size (4096 frames): properties that need no oracle --
+    the residual reproduces the samples through the FLAC decoder recurrence, and the
+    residual section length equals the sum of its codeword lengths."""
+    p = flake_amd.level_params(5, order_method=flake_amd.OM_MAX)
+    n, nfr = 4096, 4096
+    pcm = flake_amd.synth_pcm(nfr, n, 2, 16)
+    with flake_amd.Encoder(p, max_frames=nfr) as enc:
+        got = enc.encode_subframes(pcm, n, want_samples=True)
+    info, res, smp = got["info"], got["residual"].reshape(-1, n), got["samples"].reshape(-1, n)
+    assert (info["type"] == 32).all() and (info["order"] == 8).all()
+    # decoder recurrence (vectorised over subframes): x[i] = r[i] + (sum c_j x[i-j] >> shift)
+    rec = res.astype(np.int64).copy()
+    coefs = info["coefs"][:, :8].astype(np.int64)
+    shift = info["shift"].astype(np.int64)
+    for i in range(8, n):
+        pred = (coefs * rec[:, i - 8:i][:, ::-1]).sum(axis=1) >> shift
+        rec[:, i] += pred
+    assert (rec == smp).all()
+    # sum of codeword lengths == rice_nbits
+    u = (res.astype(np.int64) << 1) ^ (res.astype(np.int64) >> 63)
+    for s in range(0, info.size, 257):
+        po, k = int(info["porder"][s]), info["rparams"][s]
+        psz = n >> po
+        kk = np.repeat(k[:1 << po], psz)[8:]
+        bits = 6 + (4 + int(info["rice_method"][s])) * (1 << po) + int(((u[s, 8:] >> kk) + 1 + kk).sum())
+        assert bits == info["rice_nbits"][s], s
+    # linearity of the bookkeeping: ch_mode consistent within a frame, obits rule
+    assert (info["ch_mode"][0::2] == info["ch_mode"][1::2]).all()

@@ -94,7 +94,7 @@ def param_sets() -> list:
                             order_method=flake_amd.OM_MAX), 4096),
         ("bps8", P(5, bits_per_sample=8, order_method=flake_amd.OM_MAX), 4096),
         ("bps32", P(5, bits_per_sample=32, order_method=flake_amd.OM_MAX), 2048),
-        ("bps20_mono", P(6, channels=1, bits_per_sample=20), 4608),
+        ("bps20_mono", P(6, channels=1, bits_per_sample=20, block_size=4608), 4608),
     ]
 
 

@@ -158,7 +158,8 @@ def test_stereo_edge_frames(oracle, bps):
     for om in (flake_amd.OM_MAX, flake_amd.OM_EST, flake_amd.OM_LOG):
         p = flake_amd.level_params(5, bits_per_sample=bps, order_method=om)
         got, exp = check(oracle, p, pcm, 4096, f"stereo_edges_{bps}_{om}")
-        assert {1, 8, 9, 10} <= set(int(m) for m in exp["info"]["ch_mode"])
+        if bps == 16:
+            assert {1, 8, 9, 10} <= set(int(m) for m in exp["info"]["ch_mode"])
 
 
 @pytest.mark.parametrize("bps", [8, 16, 24, 32])

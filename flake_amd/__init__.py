@@ -130,7 +130,7 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = os.path.join(LIB_DIR, "libflakehip.so")
+    path = os.environ.get("FHIP_LIB") or os.path.join(LIB_DIR, "libflakehip.so")
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -m flake_amd.build` "

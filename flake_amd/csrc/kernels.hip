@@ -15,6 +15,27 @@
 //                  bitio.h:120-141 residual-section emit
 #include "kernels.h"
 
+#ifdef FHIP_STAMPS
+// Diagnostic build only (tools/stamps.py): phase time stamps of workgroup 0.
+__device__ long long g_fhip_stamps[64];
+#define STAMP(i)                                                                       \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                     \
+            unsigned long long t_;                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
+            g_fhip_stamps[i] = (long long)t_;                                          \
+        }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    } while (0)
+extern "C" __attribute__((visibility("default"))) int fhip_debug_read_stamps(long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fhip_stamps), sizeof(long long) * 64);
+}
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 namespace fhip {
 namespace {
 
@@ -91,6 +112,36 @@ __device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long l
         if (lane >= off) v += t;
     }
     return v;
+}
+
+// DPP controls (gfx9): row_shl:n = 0x100+n, row_shr:n = 0x110+n,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+    // lanes without a valid source (or outside ROW_MASK) receive 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+}
+
+// wave64 inclusive scan of a u32: 4 in-row steps + 2 row broadcasts, no LDS
+__device__ __forceinline__ uint32_t wave_incl_scan_u32_dpp(uint32_t x)
+{
+    x += dpp_u32<0x111>(x);
+    x += dpp_u32<0x112>(x);
+    x += dpp_u32<0x114>(x);
+    x += dpp_u32<0x118>(x);
+    x += dpp_u32<0x142, 0xA>(x);
+    x += dpp_u32<0x143, 0xC>(x);
+    return x;
+}
+
+// lane i receives lane i+D of the same 16-lane row (0 past the row end)
+template <int D>
+__device__ __forceinline__ unsigned long long row_shl_u64(unsigned long long v)
+{
+    const uint32_t lo = dpp_u32<0x100 + D>((uint32_t)v);
+    const uint32_t hi = dpp_u32<0x100 + D>((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // x86-64 cvttsd2si semantics for (int)double: out-of-range and NaN give
@@ -242,110 +293,184 @@ void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
 // ---------------------------------------------------------------------------
 // K1  k_autocorr
 // ---------------------------------------------------------------------------
-// lane = (subframe g of the wave, lag L): each lane owns the two running sums
-// of one lag and walks the block front to back, so every sum sees its
-// products in the reference's order.  Each wave is independent
-// and streams its G subframes through a private LDS ring of windowed fp64
-// samples, 64 positions per tile.
-constexpr int AC_TILE = 64;
-constexpr int AC_RING = 128;              // >= AC_TILE + FHIP_MAX_ORDER, power of two
-constexpr int AC_STRIDE = 136;            // ring row stride in doubles (bank spread)
-constexpr int AC_GMAX = 8;
+// The only order-sensitive stage: every autoc[lag] is two running fp64 sums
+// that must receive their products one at a time, in position order (SURVEY
+// 8-Q1).  Parallelism is across chains only, so the kernel is bound by the
+// length of one chain walk (n positions x 4 fp64 ops), not by HBM.
+//
+// lane = (subframe g, lag pair {2j, 2j+1}): the lane walks the block front to
+// back holding four sums (even/odd position x two lags).  Per position it reads
+// a = d[p] and b = d[p-2j] from LDS; the odd lag's operand d[p-2j-1] is the
+// previous position's b, carried in a register (half the LDS traffic per
+// product).  The steady-state loop is nothing but ds_read_b128 / v_mul_f64 /
+// v_add_f64 with immediate LDS offsets, software-pipelined by hand.
+//
+// A workgroup is four INDEPENDENT waves (one per SIMD, so that no two chain
+// walks share an issue port); each wave streams its own G subframes through a
+// private LDS tile of windowed fp64 samples: 128 new positions per pass behind
+// a 32-entry halo.  Waves never exchange data, so ordering is wave-local.
+constexpr int AC_TILE = 128;
+constexpr int AC_HALO = 32;               // >= FHIP_MAX_ORDER
+constexpr int AC_STRIDE = 170;            // row stride in doubles: >= HALO+TILE, 2*S mod 64 = 20
+constexpr int AC_GMAX = 12;
+constexpr int AC_PER_LANE = AC_TILE / WAVE;
+constexpr int AC_CH = 8;                  // positions per software-pipeline stage
+constexpr int AC_WAVES = 4;
 
-__global__ __launch_bounds__(NT)
-void k_autocorr(const int32_t *__restrict__ smp, double *__restrict__ autoc,
-                int nsub, int n, int maxlag, int G, double c)
+// LDS is only shared inside one wave here: order its accesses without a
+// workgroup barrier.
+__device__ __forceinline__ void wave_lds_fence()
 {
-    __shared__ double s_ring[4][AC_GMAX * AC_STRIDE];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double *ring = s_ring[wv];
-    const int nl = maxlag + 1;
-    const int s0 = (blockIdx.x * 4 + wv) * G;
-    const int g = lane / nl, L = lane - g * nl;
-    const bool chain = (g < G) && (s0 + g < nsub);
-    const double *row = ring + (chain ? g : 0) * AC_STRIDE;
+__global__ __launch_bounds__(AC_WAVES * WAVE)
+void k_autocorr(const int32_t *__restrict__ smp, double *__restrict__ autoc,
+                int nsub, int n, int maxlag, int G, int nl2, double c)
+{
+    __shared__ double s_buf[AC_WAVES][AC_GMAX * AC_STRIDE];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    double *buf = s_buf[wv];
+    const int s0 = (blockIdx.x * AC_WAVES + wv) * G;
+    if (s0 >= nsub) return;                       // whole wave idle (uniform)
     const int half = n >> 1;
     const int ntiles = (n + AC_TILE - 1) / AC_TILE;
 
-    double accE = 1.0, accO = 1.0;       // sums over even / odd positions (lpc.c:58-59)
-
-    int32_t cur[AC_GMAX];
+    // Unconditional, clamped loads (a load under a per-element condition makes
+    // hipcc branch around it and wait vmcnt(0) each time); out-of-range rows and
+    // positions read a valid address and are zeroed when the tile is written.
+    const int32_t *rowp[AC_GMAX];
 #pragma unroll
-    for (int q = 0; q < AC_GMAX; q++) {
-        cur[q] = 0;
-        if (q < G && s0 + q < nsub && lane < n) cur[q] = smp[(size_t)(s0 + q) * n + lane];
-    }
+    for (int q = 0; q < AC_GMAX; q++) rowp[q] = smp + (size_t)min(s0 + q, nsub - 1) * n;
+    int32_t cur[AC_GMAX][AC_PER_LANE];
+
+    const int g = lane / nl2, j = lane - g * nl2;
+    const int L0 = 2 * j, L1 = 2 * j + 1;
+    const bool chain = (g < G) && (s0 + g < nsub) && (L0 <= maxlag);
+    const double *rowa = buf + (chain ? g : 0) * AC_STRIDE + AC_HALO;    // &d[tile base]
+    const double *pb = rowa - (chain ? L0 : 0);
+    double accE0 = 1.0, accO0 = 1.0, accE1 = 1.0, accO1 = 1.0;   // lpc.c:58-59
+    double b1 = 0.0;                                              // d[p-1-2j], carried
+
+    auto issue_loads = [&](int tb) {
+#pragma unroll
+        for (int q = 0; q < AC_GMAX; q++)
+#pragma unroll
+            for (int u = 0; u < AC_PER_LANE; u++)
+                cur[q][u] = rowp[q][min(tb + u * WAVE + lane, n - 1)];
+    };
+
+    for (int idx = lane; idx < AC_GMAX * AC_HALO; idx += WAVE)
+        buf[(idx >> 5) * AC_STRIDE + (idx & 31)] = 0.0;
+    issue_loads(0);
 
     for (int t = 0; t < ntiles; t++) {
         const int tb = t * AC_TILE;
-        {
-            // lpc.c:28-40: weight of positions i and n-1-i is 1-(c-i)^2
-            const int p = tb + lane;
+        // ---- window the tile into LDS (lpc.c:28-40: weight of positions i and
+        //      n-1-i is 1-(c-i)^2), then fetch the next one -------------------
+#pragma unroll
+        for (int u = 0; u < AC_PER_LANE; u++) {
+            const int p = tb + u * WAVE + lane;
             const int ii = (p < half) ? p : (n - 1 - p);
             const bool valid = (p < n) && (ii < half);
             const double tt = c - (double)ii;
-            const double w = 1.0 - (tt * tt);
+            const double w = valid ? (1.0 - (tt * tt)) : 0.0;
 #pragma unroll
-            for (int q = 0; q < AC_GMAX; q++) {
-                if (q < G) ring[q * AC_STRIDE + (p & (AC_RING - 1))] = valid ? ((double)cur[q] * w) : 0.0;
-            }
-            const int pn = p + AC_TILE;
-#pragma unroll
-            for (int q = 0; q < AC_GMAX; q++) {
-                int32_t v = 0;
-                if (q < G && s0 + q < nsub && pn < n) v = smp[(size_t)(s0 + q) * n + pn];
-                cur[q] = v;
-            }
+            for (int q = 0; q < AC_GMAX; q++)
+                buf[q * AC_STRIDE + AC_HALO + u * WAVE + lane] = (double)cur[q][u] * w;
         }
-        __syncthreads();
+        issue_loads(tb + AC_TILE);
+        wave_lds_fence();
 
         const int kend = min(AC_TILE, n - tb);
-        if (t == 0) {
-            // head: positions L..maxlag all go to the first sum (lpc.c:60-61) ...
-            double accH = 1.0;
-            const int hend = min(kend, maxlag + 1);
-            for (int k = 0; k < hend; k++) {
-                double a = row[k];
-                if (chain && k >= L) {
-                    double b = row[(k - L) & (AC_RING - 1)];
-                    double prod = a * b;
-                    accH = accH + prod;
+        if (t > 0 && kend == AC_TILE) {
+            // steady state: tb is even, so even k <-> even position.  The LDS
+            // reads of stage c+1 are issued (and pinned with sched_barrier)
+            // before the fp64 ops of stage c.
+            double A[AC_CH], B[AC_CH];
+#pragma unroll
+            for (int u = 0; u < AC_CH; u++) { A[u] = rowa[u]; B[u] = pb[u]; }
+#pragma unroll
+            for (int cidx = 0; cidx < AC_TILE / AC_CH; cidx++) {
+                double An[AC_CH], Bn[AC_CH];
+                if (cidx + 1 < AC_TILE / AC_CH) {
+#pragma unroll
+                    for (int u = 0; u < AC_CH; u++) {
+                        An[u] = rowa[(cidx + 1) * AC_CH + u];
+                        Bn[u] = pb[(cidx + 1) * AC_CH + u];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < AC_CH; u += 2) {
+                    const double p00 = A[u] * B[u], p01 = A[u] * b1;
+                    const double p10 = A[u + 1] * B[u + 1], p11 = A[u + 1] * B[u];
+                    accE0 = accE0 + p00;
+                    accE1 = accE1 + p01;
+                    accO0 = accO0 + p10;
+                    accO1 = accO1 + p11;
+                    b1 = B[u + 1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (cidx + 1 < AC_TILE / AC_CH) {
+#pragma unroll
+                    for (int u = 0; u < AC_CH; u++) { A[u] = An[u]; B[u] = Bn[u]; }
                 }
             }
-            // ... which then continues at position maxlag+1 (lpc.c:63-66)
-            if ((maxlag + 1) & 1) accO = accH; else accE = accH;
-            for (int k = hend; k < kend; k++) {
-                double a = row[k];
-                double b = row[(k - L) & (AC_RING - 1)];
-                double prod = a * b;
-                if (k & 1) accO = accO + prod; else accE = accE + prod;
-            }
         } else {
-            int k = 0;
-#pragma unroll 4
-            for (; k + 1 < kend; k += 2) {
+            // first tile (head rule, lpc.c:60-61) and a ragged last tile
+            double accH0 = 1.0, accH1 = 1.0;
+            for (int k = 0; k < kend; k++) {
                 const int p = tb + k;
-                double a0 = row[p & (AC_RING - 1)];
-                double b0 = row[(p - L) & (AC_RING - 1)];
-                double a1 = row[(p + 1) & (AC_RING - 1)];
-                double b1 = row[(p + 1 - L) & (AC_RING - 1)];
-                double p0 = a0 * b0;
-                double p1 = a1 * b1;
-                accE = accE + p0;
-                accO = accO + p1;
-            }
-            if (k < kend) {
-                const int p = tb + k;
-                double prod = row[p & (AC_RING - 1)] * row[(p - L) & (AC_RING - 1)];
-                accE = accE + prod;
+                const double a = rowa[k], b0 = pb[k];
+                const double p0 = a * b0, p1 = a * b1;
+                if (p <= maxlag) {
+                    // positions lag..maxlag all go to the first sum
+                    if (p >= L0) accH0 = accH0 + p0;
+                    if (p >= L1) accH1 = accH1 + p1;
+                    if (p == maxlag) {
+                        // ... which then continues at position maxlag+1 (lpc.c:63-66)
+                        if ((maxlag + 1) & 1) { accO0 = accH0; accO1 = accH1; }
+                        else { accE0 = accH0; accE1 = accH1; }
+                    }
+                } else if (p & 1) {
+                    accO0 = accO0 + p0;
+                    accO1 = accO1 + p1;
+                } else {
+                    accE0 = accE0 + p0;
+                    accE1 = accE1 + p1;
+                }
+                b1 = b0;
             }
         }
-        __syncthreads();
+        wave_lds_fence();
+        // the last 32 entries of this tile become the halo of the next
+        {
+            double hv[(AC_GMAX * AC_HALO) / WAVE];
+#pragma unroll
+            for (int r = 0; r < (AC_GMAX * AC_HALO) / WAVE; r++) {
+                const int idx = lane + r * WAVE;
+                hv[r] = buf[(idx >> 5) * AC_STRIDE + AC_TILE + (idx & 31)];
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < (AC_GMAX * AC_HALO) / WAVE; r++) {
+                const int idx = lane + r * WAVE;
+                buf[(idx >> 5) * AC_STRIDE + (idx & 31)] = hv[r];
+            }
+        }
     }
     // lpc.c:68: autoc = temp + temp2.  The reference's padded product with
     // d[len] = 0 adds +-0.0 to a sum that is never -0.0, so it is skipped.
-    if (chain) autoc[(size_t)(s0 + g) * FHIP_MAX_LAGS + L] = accE + accO;
+    if (chain) {
+        double *dst = autoc + (size_t)(s0 + g) * FHIP_MAX_LAGS;
+        dst[L0] = accE0 + accO0;
+        if (L1 <= maxlag) dst[L1] = accE1 + accO1;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1020,6 +1145,626 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// K3 fast path  k_encode_pow2<C, T>
+// ---------------------------------------------------------------------------
+// Same contract as k_encode, for block sizes n = C*T with T (threads) a power
+// of two, C in {4, 8, 16} samples per thread and every partition at least one
+// thread wide ((n >> pmax) >= C).  Then
+//   * no lane ever needs a bounds or partition-boundary test per sample: a
+//     thread's run lies inside one partition of every level;
+//   * the FIR runs as exact fp64 FMAs (|coef| < 2^14, |sample| < 2^31, <= 32
+//     taps: every partial sum is an integer below 2^50 < 2^53), in register
+//     blocks of 8 taps -- v_fma_f64 issues 3-4x faster than v_mad_i64_i32;
+//   * partition sums are a wave shuffle pyramid (thread = finest level);
+//   * the best Rice parameter comes from a closed form, with the reference's
+//     31-step scan only where its modular arithmetic can bite (see rice_k_fast).
+constexpr int HIST = 32;                 // zeroed samples in front of the block
+
+__device__ __forceinline__ int padidx2(int i)      // i >= -HIST
+{
+    const int v = i + HIST;
+    return v + (v >> 4);
+}
+
+// rice.c:30-45 find_optimal_rice_param without the scan.  With
+// S = sum - (n>>1):  f(k) = n(k+1) + (S>>k).
+//  * sum < n>>1: S wraps; f(k) = n(k+1) - ceil(d/2^k) (mod 2^32) with
+//    d = (n>>1)-sum <= n/2 is increasing, so k = 0.
+//  * no wrap and f < 2^32 for all k: f is convex in k (its increment
+//    n - ceil((S>>k)/2) never decreases), so the first minimum is the smallest
+//    k with (S>>k) <= 2n, capped at 30.
+//  * otherwise (sums near 2^32): the reference scan.
+__device__ __forceinline__ int rice_k_fast(uint64_t sum, int n, uint32_t *bits_out)
+{
+    const uint64_t half = (uint64_t)(n >> 1);
+    if (sum < half) {
+        *bits_out = (uint32_t)n - (uint32_t)(half - sum);
+        return 0;
+    }
+    const uint64_t S = sum - half;
+    if (n <= 0 || S >= 0xFFE00000ull) return rice_best_k(sum, n, bits_out);
+    const uint32_t two = 2u * (uint32_t)n;
+    int k = 0;
+    if (S > two) {
+        k = (64 - __clzll((long long)S)) - (32 - __clz((int)two));
+        if ((S >> k) > two) k++;
+        if (k > 30) k = 30;
+    }
+    *bits_out = (uint32_t)(n * (k + 1)) + (uint32_t)(S >> k);
+    return k;
+}
+
+struct FastLds {
+    int32_t *smp;                        // padded samples, HIST zeros in front
+    unsigned long long *sums;            // [511] heap order
+    int32_t *kpar;                       // [511]
+    double *coefd;                       // [32] coefficients of the candidate as fp64
+    unsigned long long *wtot;            // [16] per-wave totals
+    uint32_t *lvl_bits, *lvl_meth;       // [9]
+    int32_t *coef;                       // [32]
+    int32_t *misc;                       // [16]
+    uint32_t *trial;                     // [32]
+    uint32_t *bits;                      // [ENC_WWORDS]
+};
+
+__host__ __device__ inline size_t fast_lds_layout(int n, size_t off[11])
+{
+    size_t o = 0;
+    off[0] = o; o += 8 * 512;                                   // sums
+    off[1] = o; o += 8 * 32;                                    // coefd
+    off[2] = o; o += 8 * 16;                                    // wtot
+    off[3] = o; o += 4 * (size_t)(n + HIST + ((n + HIST) >> 4) + 4);   // smp
+    off[4] = o; o += 4 * 512;                                   // kpar
+    off[5] = o; o += 4 * 12;                                    // lvl_bits
+    off[6] = o; o += 4 * 12;                                    // lvl_meth
+    off[7] = o; o += 4 * 32;                                    // coef
+    off[8] = o; o += 4 * 16;                                    // misc
+    off[9] = o; o += 4 * 32;                                    // trial
+    o = (o + 15) & ~(size_t)15;
+    off[10] = o; o += 4 * ENC_WWORDS;                           // bits
+    return o;
+}
+
+template <int C, int T>
+struct FastCtx {
+    FastLds l;
+    int n, i0, tid, lane, wv;
+    int obits, precision, pmin_req, pmax_req;
+};
+
+// FIR residual of this thread's C samples x[] for an LPC candidate
+// (optimize.c:70-122).  l.coefd holds the coefficients as doubles, zero past
+// `order`, so the tap loop runs in whole blocks of 8.
+template <int C, int T>
+__device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift)
+{
+    const FastLds &l = e.l;
+    const double inv = __builtin_ldexp(1.0, -shift);
+    constexpr int OB = (C < 8) ? C : 8;              // outputs per register block
+#pragma unroll
+    for (int ob = 0; ob < C; ob += OB) {
+        // keep the register blocks apart: interleaving them only costs VGPRs
+        __builtin_amdgcn_sched_barrier(0);
+        double acc[OB];
+#pragma unroll
+        for (int o = 0; o < OB; o++) acc[o] = 0.0;
+#pragma unroll 1
+        for (int tb = 0; tb < order; tb += 8) {
+            // window W[m] = sample (i0 + ob - tb - 8 + m), m = 0 .. OB+6
+            double W[OB + 7];
+            const int base = e.i0 + ob - tb - 8;
+#pragma unroll
+            for (int m = 0; m < OB + 7; m++) W[m] = (double)l.smp[padidx2(base + m)];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                const double cd = l.coefd[tb + jj];
+#pragma unroll
+                for (int o = 0; o < OB; o++)
+                    acc[o] = __builtin_fma(cd, W[o + 7 - jj], acc[o]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < OB; o++) {
+            // pred >> shift == floor(pred * 2^-shift); (int32)(x - that) = low 32 bits
+            const double q = __builtin_floor(acc[o] * inv);
+            const int32_t xo = l.smp[padidx2(e.i0 + ob + o)];
+            const double d = (double)xo - q;
+            const double hi = __builtin_floor(d * (1.0 / 4294967296.0));
+            const double lo = __builtin_fma(-hi, 4294967296.0, d);
+            const int32_t v = (int32_t)(uint32_t)lo;
+            r[ob + o] = (e.i0 + ob + o < order) ? xo : v;
+        }
+    }
+}
+
+// optimize.c:34-68 encode_residual_fixed on the thread's run
+template <int C, int T>
+__device__ __forceinline__ void fir_fixed(const FastCtx<C, T> &e, int32_t (&r)[C], int order)
+{
+    const FastLds &l = e.l;
+    long long h[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) h[k] = l.smp[padidx2(e.i0 - 1 - k)];
+#pragma unroll
+    for (int o = 0; o < C; o++) {
+        const int32_t xo = l.smp[padidx2(e.i0 + o)];
+        const long long x0 = xo;
+        long long acc;
+        if (order == 0) acc = x0;
+        else if (order == 1) acc = x0 - h[0];
+        else if (order == 2) acc = x0 - 2 * h[0] + h[1];
+        else if (order == 3) acc = x0 - 3 * h[0] + 3 * h[1] - h[2];
+        else acc = x0 - 4 * h[0] + 6 * h[1] - 4 * h[2] + h[3];
+        r[o] = (e.i0 + o < order) ? xo : (int32_t)acc;
+        h[3] = h[2]; h[2] = h[1]; h[1] = h[0]; h[0] = x0;
+    }
+}
+
+// rice.c:105-187 on the residuals in r[]; all threads call it.
+template <int C, int T>
+__device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, const int32_t (&r)[C],
+                                                     int order, bool lpc)
+{
+    constexpr int LT = (T == 256) ? 8 : (T == 512) ? 9 : 10;     // log2(T): the thread level
+    const FastLds &l = e.l;
+    const int n = e.n, tid = e.tid, lane = e.lane;
+    const int pmin = clamp_porder(e.pmin_req, n, order);
+    const int pmax = clamp_porder(e.pmax_req, n, order);
+
+    // thread-level sum; partition 0 of every level starts at `order` (rice.c:85-94)
+    unsigned long long v = 0;
+#pragma unroll
+    for (int o = 0; o < C; o++) v += (e.i0 + o >= order) ? zigzag32(r[o]) : 0u;
+
+    if (tid < 12) { l.lvl_bits[tid] = 0; l.lvl_meth[tid] = 0; }
+    // levels LT .. LT-6 inside the wave: after s steps, lanes with the low s
+    // bits clear hold the sums of level LT-s.  Steps 1,2,4,8 stay inside a
+    // 16-lane row (DPP row_shl, no LDS); 16 and 32 cross rows.
+#define PYR_STORE(S_)                                                                       \
+    do {                                                                                    \
+        const int lev_ = LT - (S_);                                                         \
+        if (lev_ <= pmax && lev_ >= pmin && lev_ <= 8 && (lane & ((1 << (S_)) - 1)) == 0)   \
+            l.sums[(1 << lev_) - 1 + (tid >> (S_))] = v;                                    \
+    } while (0)
+    PYR_STORE(0); v += row_shl_u64<1>(v);
+    PYR_STORE(1); v += row_shl_u64<2>(v);
+    PYR_STORE(2); v += row_shl_u64<4>(v);
+    PYR_STORE(3); v += row_shl_u64<8>(v);
+    PYR_STORE(4); v += __shfl_down(v, 16, WAVE);
+    PYR_STORE(5); v += __shfl_down(v, 32, WAVE);
+    PYR_STORE(6);
+#undef PYR_STORE
+    if (lane == 0) l.wtot[e.wv] = v;                 // level LT-6 node
+    __syncthreads();
+    STAMP(4);
+    // levels above the waves: LT-7 .. 0, a handful of nodes
+    {
+        constexpr int NW = T / WAVE;
+        for (int lev = LT - 7; lev >= 0; lev--) {
+            const int nodes = 1 << lev;
+            const int span = NW >> lev;              // waves per node
+            if (lev <= pmax && lev >= pmin && tid < nodes) {
+                unsigned long long acc = 0;
+                for (int w = 0; w < span; w++) acc += l.wtot[tid * span + w];
+                l.sums[nodes - 1 + tid] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    STAMP(5);
+    {
+        const int first = (1 << pmin) - 1, last = (2 << pmax) - 2;
+        for (int q = first + tid; q <= last; q += T) {
+            const int p = ilog2_dev((uint32_t)(q + 1));
+            const int jn = q + 1 - (1 << p);
+            const int cnt = (n >> p) - (jn == 0 ? order : 0);
+            uint32_t b;
+            const int k = rice_k_fast(l.sums[q], cnt, &b);
+            l.kpar[q] = k;
+            atomicAdd(&l.lvl_bits[p], b);
+            if (k > 14) atomicOr(&l.lvl_meth[p], 1u);
+        }
+    }
+    __syncthreads();
+    STAMP(6);
+    if (tid == 0) {
+        // rice.c:127-138; all nine levels are fetched together, then compared
+        uint32_t lb[9], lm[9];
+#pragma unroll
+        for (int p = 0; p < 9; p++) { lb[p] = l.lvl_bits[p]; lm[p] = l.lvl_meth[p]; }
+        int bp = pmin;
+        uint32_t best = 0, method = 0;
+#pragma unroll
+        for (int p = 0; p < 9; p++) {
+            const uint32_t b = lb[p] + 4u * (1u << p);
+            if (p >= pmin && p <= pmax && (p == pmin || b <= best)) { best = b; bp = p; method = lm[p]; }
+        }
+        uint32_t bits = (uint32_t)(order * e.obits + 2);
+        if (lpc) bits += (uint32_t)(4 + 5 + order * e.precision);
+        bits += best;
+        bits += method + 4u;
+        l.misc[M_PORDER] = bp;
+        l.misc[M_METHOD] = (int)method;
+        l.misc[M_BITS] = (int)bits;
+    }
+    __syncthreads();
+    STAMP(7);
+    return (uint32_t)l.misc[M_BITS];
+}
+
+// OR `len` (<= 31) bits of val into the MSB-first bit string at bit `pos` of a
+// zeroed LDS window, 32-bit arithmetic only; words outside [0, nw) are skipped.
+__device__ __forceinline__ void put_bits32(uint32_t *win, int nw, long long pos, int len, uint32_t val)
+{
+    const long long wi = pos >> 5;
+    const int off = (int)(pos & 31);
+    const int room = 32 - off;
+    if (len <= room) {
+        if (wi >= 0 && wi < nw) atomicOr(&win[wi], val << (room - len));
+    } else {
+        const int spill = len - room;
+        if (wi >= 0 && wi < nw) atomicOr(&win[wi], val >> spill);
+        if (wi + 1 >= 0 && wi + 1 < nw) atomicOr(&win[wi + 1], val << (32 - spill));
+    }
+}
+
+template <int C, int T>
+__global__ __launch_bounds__(T, (T == 256) ? 3 : 4)   // VGPR cap: 168 (3 groups of 256 per CU) or 128
+void k_encode_pow2(fhip_params P, int n, const int32_t *__restrict__ smp_all,
+                   const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
+                   const int32_t *__restrict__ opt_all, fhip_subframe_info *__restrict__ info,
+                   int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    size_t off[11];
+    fast_lds_layout(n, off);
+    FastCtx<C, T> e;
+    e.l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
+    e.l.coefd = reinterpret_cast<double *>(lds_raw + off[1]);
+    e.l.wtot = reinterpret_cast<unsigned long long *>(lds_raw + off[2]);
+    e.l.smp = reinterpret_cast<int32_t *>(lds_raw + off[3]);
+    e.l.kpar = reinterpret_cast<int32_t *>(lds_raw + off[4]);
+    e.l.lvl_bits = reinterpret_cast<uint32_t *>(lds_raw + off[5]);
+    e.l.lvl_meth = reinterpret_cast<uint32_t *>(lds_raw + off[6]);
+    e.l.coef = reinterpret_cast<int32_t *>(lds_raw + off[7]);
+    e.l.misc = reinterpret_cast<int32_t *>(lds_raw + off[8]);
+    e.l.trial = reinterpret_cast<uint32_t *>(lds_raw + off[9]);
+    e.l.bits = reinterpret_cast<uint32_t *>(lds_raw + off[10]);
+    const FastLds &l = e.l;
+
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    fhip_subframe_info *out = &info[s];
+    e.n = n; e.tid = tid; e.lane = tid & 63; e.wv = tid >> 6;
+    e.i0 = tid * C;
+    e.obits = out->obits;
+    e.precision = P.lpc_precision;
+    e.pmin_req = P.min_partition_order;
+    e.pmax_req = P.max_partition_order;
+
+    STAMP(0);
+    // ---- load: 16-byte lane accesses, own run stays in registers ------------
+    const int32_t *src = smp_all + (size_t)s * n;
+    int differs = 0;
+    {
+        int32_t x[C];
+        const int4 *src4 = reinterpret_cast<const int4 *>(src + e.i0);
+#pragma unroll
+        for (int q = 0; q < C / 4; q++) {
+            const int4 vv = src4[q];
+            x[4 * q] = vv.x; x[4 * q + 1] = vv.y; x[4 * q + 2] = vv.z; x[4 * q + 3] = vv.w;
+        }
+        const int32_t first = src[0];
+#pragma unroll
+        for (int o = 0; o < C; o++) {
+            l.smp[padidx2(e.i0 + o)] = x[o];
+            differs |= (x[o] != first);
+        }
+    }
+    if (tid < HIST) l.smp[padidx2(tid - HIST)] = 0;
+    const bool constant = (__syncthreads_or(differs) == 0);
+    STAMP(1);
+
+    int32_t r[C];
+    int type, type_code, order = 0, shift = 0;
+    uint32_t est_bits = 0;
+    bool has_rice = false;
+    const int32_t *crow_base = coefs_all + (size_t)s * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
+    const int32_t *srow = shift_all + (size_t)s * FHIP_MAX_ORDER;
+
+    // decision tree of encode_residual() (optimize.c:124-276): same candidate
+    // loop as k_encode, every variable workgroup-uniform
+    enum { T_CONST, T_VERB, T_FIXED, T_LPC } tree;
+    if (constant) tree = T_CONST;
+    else if (n < 5 || P.prediction_type == 0) tree = T_VERB;
+    else if (P.prediction_type == 1 || n <= P.max_prediction_order) tree = T_FIXED;
+    else tree = T_LPC;
+
+    const int omethod = P.order_method;
+    const int min_order = P.min_prediction_order;
+    const int max_order = (tree == T_FIXED) ? min(P.max_prediction_order, 4) : P.max_prediction_order;
+
+    int it = 0, best = 0;
+    uint32_t best_bits = 0, last_bits = 0;
+    bool have_best = false;
+    int lg_step = 16, lg_last = 0, lg_pos = 3;
+    bool final_pass = false;
+
+    if (tree == T_FIXED) { it = min_order; best = min_order; }
+    if (tree == T_LPC) {
+        if (omethod == 0) { best = max_order - 1; final_pass = true; }
+        else if (omethod == 1) { best = opt_all[s] - 1; final_pass = true; }
+        else if (omethod <= 4) { it = (1 << (omethod - 1)) - 1; best = max_order - 1; }
+        else if (omethod == 5) { it = 0; best = 0; }
+        else {
+            best = min_order - 1 + (max_order - min_order) / 3;
+            if (tid < FHIP_MAX_ORDER) l.trial[tid] = 0xFFFFFFFFu;
+            __syncthreads();
+            lg_step = 32;
+        }
+    }
+
+    if (tree == T_CONST || tree == T_VERB) {
+        type = type_code = (tree == T_CONST) ? FHIP_SUB_CONSTANT : FHIP_SUB_VERBATIM;
+        est_bits = (uint32_t)(tree == T_CONST ? e.obits : e.obits * n);
+        fir_fixed<C, T>(e, r, 0);
+    } else {
+        for (;;) {
+            int cand = -1;
+            if (!final_pass) {
+                if (tree == T_FIXED) {
+                    if (it <= max_order) cand = it;
+                } else if (omethod <= 4) {
+                    if (it >= 0) {
+                        const int levels = 1 << (omethod - 1);
+                        cand = min_order + (((max_order - min_order + 1) * (it + 1)) / levels) - 2;
+                        if (cand < 0) cand = 0;
+                    }
+                } else if (omethod == 5) {
+                    if (it < max_order) cand = it;
+                } else {
+                    for (;;) {
+                        if (lg_pos == 3) {
+                            lg_step >>= 1;
+                            if (lg_step == 0) break;
+                            lg_last = best;
+                            lg_pos = 0;
+                        }
+                        const int i = lg_last + (lg_pos - 1) * lg_step;
+                        lg_pos++;
+                        if (i < min_order - 1 || i >= max_order || l.trial[i] < 0xFFFFFFFFu) continue;
+                        cand = i;
+                        break;
+                    }
+                }
+                if (cand < 0) {
+                    if (tree == T_FIXED && best == max_order) { est_bits = last_bits; break; }
+                    final_pass = true;
+                }
+            }
+            if (final_pass) cand = best;
+
+            uint32_t b;
+            if (tree == T_FIXED) {
+                fir_fixed<C, T>(e, r, cand);
+                b = rice_search_fast<C, T>(e, r, cand, false);
+            } else {
+                const int ord = cand + 1;
+                __syncthreads();                      // readers of coef/coefd are done
+                if (tid < FHIP_MAX_ORDER) {
+                    const int32_t cv = (tid < ord) ? crow_base[cand * FHIP_MAX_ORDER + tid] : 0;
+                    l.coef[tid] = cv;
+                    l.coefd[tid] = (double)cv;
+                }
+                __syncthreads();
+                STAMP(2);
+                fir_lpc<C, T>(e, r, ord, srow[cand]);
+                STAMP(3);
+                b = rice_search_fast<C, T>(e, r, ord, true);
+                STAMP(8);
+            }
+            if (final_pass) { est_bits = b; break; }
+
+            last_bits = b;
+            if (tree == T_FIXED) {
+                if (!have_best || b < best_bits) { best_bits = b; best = cand; }
+                it++;
+            } else if (omethod <= 4) {
+                if (!have_best) best_bits = b;
+                else if (b < best_bits) { best_bits = b; best = cand; }
+                it--;
+            } else if (omethod == 5) {
+                if (!have_best || b < best_bits) { best_bits = b; best = cand; }
+                it++;
+            } else {
+                if (tid == 0) l.trial[cand] = b;
+                __syncthreads();
+                if (b < l.trial[best]) best = cand;
+            }
+            have_best = true;
+        }
+        if (tree == T_FIXED) {
+            order = best;
+            type = FHIP_SUB_FIXED;
+            type_code = FHIP_SUB_FIXED | order;
+        } else {
+            order = best + 1;
+            shift = srow[best];
+            type = FHIP_SUB_LPC;
+            type_code = FHIP_SUB_LPC | (order - 1);
+        }
+        has_rice = true;
+    }
+
+    const int porder = has_rice ? l.misc[M_PORDER] : 0;
+    const int method = has_rice ? l.misc[M_METHOD] : 0;
+
+    STAMP(9);
+    if (res_out) {
+        int4 *dst4 = reinterpret_cast<int4 *>(res_out + (size_t)s * n + e.i0);
+#pragma unroll
+        for (int q = 0; q < C / 4; q++)
+            dst4[q] = make_int4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+    }
+
+    // ---- encode.c:766-798 output_residual -----------------------------------
+    long long total_bits = 0;
+    if (has_rice) {
+        constexpr int LT = (T == 256) ? 8 : (T == 512) ? 9 : 10;
+        const int pbits = 4 + method;
+        const int heap0 = (1 << porder) - 1;
+        const int tpp = LT - porder;                       // log2(threads per partition)
+        const int part = tid >> tpp;
+        const int k = l.kpar[heap0 + part];
+        const bool part_head = (part > 0) && ((tid & ((1 << tpp) - 1)) == 0);
+        unsigned long long mine = part_head ? pbits : 0;
+        uint32_t longest = 0;                              // longest codeword of this thread
+#pragma unroll
+        for (int o = 0; o < C; o++) {
+            const uint32_t q = (e.i0 + o >= order) ? (emit_fold32(r[o]) >> k) : 0u;
+            mine += (e.i0 + o >= order) ? ((unsigned long long)q + 1 + k) : 0ull;
+            longest = max(longest, q);
+        }
+        // every codeword of the wave at most 32 bits: one flush test per codeword
+        const bool short_codes = !__any(longest + (uint32_t)k + 1u > 32u);
+        // in-wave offsets: DPP scan in 32 bits unless some lane of the wave
+        // holds an absurdly long run (then the exact 64-bit shuffle scan)
+        unsigned long long incl;
+        if (__any(mine >> 24)) incl = wave_incl_scan_u64(mine, e.lane);
+        else incl = wave_incl_scan_u32_dpp((uint32_t)mine);
+        if (e.lane == 63) l.wtot[e.wv] = incl;
+        __syncthreads();
+        unsigned long long base = 6 + pbits;
+        unsigned long long tot = 6 + pbits;
+#pragma unroll
+        for (int w = 0; w < T / WAVE; w++) {
+            const unsigned long long wt = l.wtot[w];
+            if (w < e.wv) base += wt;
+            tot += wt;
+        }
+        const unsigned long long my_off = base + incl - mine;
+        total_bits = (tot > 0x7FFFFFFFull) ? 0x7FFFFFFFll : (long long)tot;
+        STAMP(10);
+
+        if (bits_out) {
+            if (tot > (unsigned long long)slot_bytes * 8ull) {
+                total_bits = -1;
+            } else {
+                uint32_t *dst32 = reinterpret_cast<uint32_t *>(bits_out + (size_t)s * slot_bytes);
+                const int nwords = (int)((tot + 31) >> 5);
+                for (int wlo = 0; wlo < nwords; wlo += ENC_WWORDS) {
+                    const int nw = min(ENC_WWORDS, nwords - wlo);
+                    __syncthreads();
+                    for (int q = tid; q < nw; q += T) l.bits[q] = 0;
+                    __syncthreads();
+                    const long long wbit = (long long)wlo * 32;
+                    if (tid == 0) {
+                        put_bits32(l.bits, nw, 0 - wbit, 2, (uint32_t)method);
+                        put_bits32(l.bits, nw, 2 - wbit, 4, (uint32_t)porder);
+                        put_bits32(l.bits, nw, 6 - wbit, pbits, (uint32_t)l.kpar[heap0]);
+                    }
+                    // The thread's codewords form one contiguous bit run.  It is
+                    // assembled MSB-first in a 64-bit register and leaves a word at
+                    // a time: the run's first and last word may be shared with the
+                    // neighbours (LDS OR), every word in between is this thread's
+                    // alone (plain store).
+                    unsigned long long acc = 0;
+                    int nacc = (int)(my_off & 31);
+                    long long w = (long long)(my_off >> 5) - wlo;
+                    bool shared = true;
+                    auto flush = [&]() {
+                        const uint32_t word = (uint32_t)(acc >> 32);
+                        if (w >= 0 && w < nw) {
+                            if (shared) { if (word) atomicOr(&l.bits[w], word); }
+                            else l.bits[w] = word;
+                        }
+                        shared = false;
+                        acc <<= 32;
+                        nacc -= 32;
+                        w++;
+                    };
+                    if (part_head) {
+                        acc |= (unsigned long long)(uint32_t)k << (64 - nacc - pbits);
+                        nacc += pbits;
+                        if (nacc >= 32) flush();
+                    }
+                    const uint32_t kmask = (1u << k) - 1u;
+                    if (short_codes) {
+                        // bitio.h:120-141: q zeros, a one, k low bits -- as one field
+                        // of q+k+1 <= 32 bits; warm-up samples are zero-length fields
+#pragma unroll
+                        for (int o = 0; o < C; o++) {
+                            const bool coded = (e.i0 + o >= order);
+                            const uint32_t u = emit_fold32(r[o]);
+                            const int len = coded ? (int)(u >> k) + k + 1 : 0;
+                            const unsigned long long val = coded ? ((1u << k) | (u & kmask)) : 0u;
+                            acc |= val << ((64 - nacc - len) & 63);
+                            nacc += len;
+                            if (nacc >= 32) flush();
+                        }
+                    } else {
+#pragma unroll 2
+                        for (int o = 0; o < C; o++) {
+                            if (e.i0 + o >= order) {
+                                const uint32_t u = emit_fold32(r[o]);
+                                const uint32_t q = u >> k;
+                                if (q >= 32u) {
+                                    // long unary run: skip whole zero words at once
+                                    const long long adv = (long long)nacc + q;
+                                    if (nacc > 0 || shared) { flush(); }
+                                    else { w++; nacc -= 32; }
+                                    const long long rem = adv - 32;      // zeros still to place
+                                    w += rem >> 5;
+                                    nacc = (int)(rem & 31);
+                                    acc = 0;
+                                } else {
+                                    nacc += (int)q;
+                                    if (nacc >= 32) flush();
+                                }
+                                acc |= (unsigned long long)((1u << k) | (u & kmask)) << (64 - nacc - (k + 1));
+                                nacc += k + 1;
+                                if (nacc >= 32) flush();
+                            }
+                        }
+                    }
+                    if (nacc > 0) {
+                        const uint32_t word = (uint32_t)(acc >> 32);
+                        if (word && w >= 0 && w < nw) atomicOr(&l.bits[w], word);
+                    }
+                    __syncthreads();
+                    STAMP(11);
+                    for (int q = tid; q < nw; q += T)
+                        dst32[wlo + q] = __builtin_bswap32(l.bits[q]);
+                }
+            }
+        }
+    }
+    STAMP(12);
+
+    if (tid == 0) {
+        out->type = type;
+        out->type_code = type_code;
+        out->order = order;
+        out->shift = shift;
+        out->rice_method = method;
+        out->porder = porder;
+        out->est_bits = est_bits;
+        out->rice_nbits = (int32_t)total_bits;
+        out->reserved = 0;
+    }
+    if (tid < FHIP_MAX_ORDER) {
+        out->coefs[tid] = (type == FHIP_SUB_LPC && tid < order) ? l.coef[tid] : 0;
+        const int nw = (type == FHIP_SUB_CONSTANT) ? 1 : order;
+        out->warmup[tid] = (tid < nw) ? l.smp[padidx2(tid)] : 0;
+    }
+    if (tid < FHIP_MAX_PARTS) {
+        const int np = has_rice ? (1 << porder) : 0;
+        out->rparams[tid] = (tid < np) ? l.kpar[np - 1 + tid] : 0;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1046,16 +1791,19 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                            int max_order, double *autoc)
 {
     if (nsub == 0) return hipSuccess;
-    const int nl = max_order + 1;
-    int G = WAVE / nl;
+    const int nl2 = (max_order + 2) / 2;          // lag pairs {0,1},{2,3},...
+    int G = WAVE / nl2;
     if (G > AC_GMAX) G = AC_GMAX;
     if (G < 1) G = 1;
-    const int per_block = 4 * G;
+    // spread over all CUs when the batch is small: fewer subframes per wave
+    // cost nothing (a wave's time is its chain length, not its lane count)
+    while (G > 1 && (nsub + G * AC_WAVES - 1) / (G * AC_WAVES) < 256) G--;
+    const int per_block = G * AC_WAVES;
     const int blocks = (nsub + per_block - 1) / per_block;
     // the window constant is computed on the host exactly as lpc.c:34 does
     const double c = (2.0 / (n - 1.0)) - 1.0;
-    hipLaunchKernelGGL(k_autocorr, dim3(blocks), dim3(NT), 0, st, smp, autoc, nsub, n,
-                       max_order, G, c);
+    hipLaunchKernelGGL(k_autocorr, dim3(blocks), dim3(AC_WAVES * WAVE), 0, st, smp, autoc,
+                       nsub, n, max_order, G, nl2, c);
     return hipGetLastError();
 }
 
@@ -1077,6 +1825,21 @@ size_t encode_lds_bytes(int n)
     return enc_lds_layout(n, off);
 }
 
+// Fast-path geometry for a block size: C samples per thread, T threads.
+static bool fast_geometry(const fhip_params &p, int n, int *C, int *T)
+{
+    if (n < 1024 || n > FHIP_MAX_BLOCK || (n & (n - 1))) return false;
+    int c = 16, t = n / 16;
+    if (n == 1024) { c = 4; t = 256; }
+    else if (n == 2048) { c = 8; t = 256; }
+    if (t != 256 && t != 512 && t != 1024) return false;
+    // every partition at least one thread wide at the finest level that can occur
+    int pmax = p.max_partition_order;
+    if ((n >> pmax) < c) return false;
+    *C = c; *T = t;
+    return true;
+}
+
 hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *smp,
                          int nsub, int n, const int32_t *coefs, const int32_t *shift,
                          const int32_t *opt_order, fhip_subframe_info *info,
@@ -1084,6 +1847,28 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
                          int raw_order, int raw_lpc)
 {
     if (nsub == 0) return hipSuccess;
+    int fc = 0, ft = 0;
+    if (raw_order < 0 && fast_geometry(p, n, &fc, &ft)) {
+        size_t off[11];
+        const size_t lds = fast_lds_layout(n, off);
+#define LAUNCH_FAST(CC, TT)                                                                  \
+    do {                                                                                     \
+        hipError_t er = hipFuncSetAttribute(                                                 \
+            reinterpret_cast<const void *>(&k_encode_pow2<CC, TT>),                          \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        if (er != hipSuccess) return er;                                                     \
+        hipLaunchKernelGGL((k_encode_pow2<CC, TT>), dim3(nsub), dim3(TT), lds, st, p, n,    \
+                           smp, coefs, shift, opt_order, info, residual, bits,               \
+                           (long long)slot_bytes);                                           \
+    } while (0)
+        if (fc == 4) LAUNCH_FAST(4, 256);
+        else if (fc == 8) LAUNCH_FAST(8, 256);
+        else if (ft == 256) LAUNCH_FAST(16, 256);
+        else if (ft == 512) LAUNCH_FAST(16, 512);
+        else LAUNCH_FAST(16, 1024);
+#undef LAUNCH_FAST
+        return hipGetLastError();
+    }
     const size_t lds = encode_lds_bytes(n);
     if (lds == 0) return hipErrorInvalidValue;
     const int chunk = (n + NT - 1) / NT;

@@ -26,6 +26,7 @@ struct fhip_ctx {
     int32_t *d_coefs = nullptr;       // [nsub][32][32]
     int32_t *d_shift = nullptr;       // [nsub][32]
     int32_t *d_opt = nullptr;         // [nsub]
+    int32_t *d_fin = nullptr;         // [nsub][FIN_STRIDE]
     // staging for the host-pointer entry points
     int32_t *d_pcm = nullptr;
     fhip_subframe_info *d_info = nullptr;
@@ -165,13 +166,13 @@ int run_pipeline(fhip_ctx *c, const int32_t *pcm, int nframes, int n,
             Prof pr(c, 2);
             HIP_TRY(c, fhip::launch_lpc(c->stream, autoc, nsub, p.max_prediction_order,
                                         p.lpc_precision, p.order_method, c->d_coefs,
-                                        c->d_shift, c->d_opt));
+                                        c->d_shift, c->d_opt, c->d_fin));
         }
     }
     {
         Prof pr(c, 3);
         HIP_TRY(c, fhip::launch_encode(c->stream, p, smp, nsub, n, c->d_coefs, c->d_shift,
-                                       c->d_opt, info, residual, bits, slot_bytes));
+                                       c->d_opt, c->d_fin, info, residual, bits, slot_bytes));
     }
     return FHIP_OK;
 }
@@ -249,6 +250,8 @@ int fhip_create(fhip_ctx **out, int device, const fhip_params *p, int max_frames
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_coefs, nsub * FHIP_MAX_ORDER * FHIP_MAX_ORDER * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_shift, nsub * FHIP_MAX_ORDER * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_opt, nsub * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_fin, nsub * fhip::FIN_STRIDE * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_fin, 0, nsub * fhip::FIN_STRIDE * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(c->d_coefs, 0, nsub * FHIP_MAX_ORDER * FHIP_MAX_ORDER * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(c->d_shift, 0, nsub * FHIP_MAX_ORDER * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(c->d_opt, 0, nsub * sizeof(int32_t));
@@ -270,7 +273,7 @@ void fhip_destroy(fhip_ctx *c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     drain_profile(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
-    void *bufs[] = {c->d_smp, c->d_autoc, c->d_coefs, c->d_shift, c->d_opt,
+    void *bufs[] = {c->d_smp, c->d_autoc, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
                     c->d_pcm, c->d_info, c->d_res, c->d_bits};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -414,7 +417,7 @@ int fhip_lpc_calc_coefs(fhip_ctx *c, const int32_t *samples, int nsub, int n,
     HIP_TRY(c, hipMemsetAsync(c->d_shift, 0, ns * FHIP_MAX_ORDER * sizeof(int32_t), c->stream));
     HIP_TRY(c, fhip::launch_autocorr(c->stream, c->d_smp, nsub, n, max_order, c->d_autoc));
     HIP_TRY(c, fhip::launch_lpc(c->stream, c->d_autoc, nsub, max_order, precision, omethod,
-                                c->d_coefs, c->d_shift, c->d_opt));
+                                c->d_coefs, c->d_shift, c->d_opt, c->d_fin));
     HIP_TRY(c, hipMemcpyAsync(coefs, c->d_coefs, ns * FHIP_MAX_ORDER * FHIP_MAX_ORDER * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(shift, c->d_shift, ns * FHIP_MAX_ORDER * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(opt_order, c->d_opt, ns * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -447,9 +450,9 @@ int fhip_encode_residual(fhip_ctx *c, const int32_t *samples, int nsub, int n,
     if (p.prediction_type == 2 && n > p.max_prediction_order && n >= 5) {
         HIP_TRY(c, fhip::launch_autocorr(c->stream, c->d_smp, nsub, n, p.max_prediction_order, c->d_autoc));
         HIP_TRY(c, fhip::launch_lpc(c->stream, c->d_autoc, nsub, p.max_prediction_order,
-                                    p.lpc_precision, p.order_method, c->d_coefs, c->d_shift, c->d_opt));
+                                    p.lpc_precision, p.order_method, c->d_coefs, c->d_shift, c->d_opt, c->d_fin));
     }
-    HIP_TRY(c, fhip::launch_encode(c->stream, p, c->d_smp, nsub, n, c->d_coefs, c->d_shift, c->d_opt,
+    HIP_TRY(c, fhip::launch_encode(c->stream, p, c->d_smp, nsub, n, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
                                    c->d_info, residual ? c->d_res : nullptr,
                                    rice_bits ? c->d_bits : nullptr, rice_slot_bytes));
     HIP_TRY(c, hipMemcpyAsync(info, c->d_info, ns * sizeof(fhip_subframe_info), hipMemcpyDeviceToHost, c->stream));
@@ -488,7 +491,7 @@ int fhip_calc_rice_params(fhip_ctx *c, const int32_t *residual, int nsub, int n,
     HIP_TRY(c, hipMemcpyAsync(c->d_smp, residual, ns * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_info, seed.data(), ns * sizeof(fhip_subframe_info), hipMemcpyHostToDevice, c->stream));
     if (bits_bytes) HIP_TRY(c, hipMemsetAsync(c->d_bits, 0, bits_bytes, c->stream));
-    HIP_TRY(c, fhip::launch_encode(c->stream, p, c->d_smp, nsub, n, c->d_coefs, c->d_shift, c->d_opt,
+    HIP_TRY(c, fhip::launch_encode(c->stream, p, c->d_smp, nsub, n, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
                                    c->d_info, nullptr, rice_bits ? c->d_bits : nullptr,
                                    rice_slot_bytes, pred_order, lpc ? 1 : 0));
     HIP_TRY(c, hipMemcpyAsync(info, c->d_info, ns * sizeof(fhip_subframe_info), hipMemcpyDeviceToHost, c->stream));

@@ -28,15 +28,19 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
 
 // K2: compute_lpc_coefs / _est + quantize_lpc_coefs (lpc.c:77-257).
 // coefs [nsub][32][32], shift [nsub][32], opt_order [nsub].
+// fin [nsub][FIN_STRIDE]: for the MAX/EST order methods the one row the
+// reference quantises, compact: coefs[0..32), shift, order (prefetched by K3).
+constexpr int FIN_STRIDE = 36;
 hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_order,
                       int precision, int omethod, int32_t *coefs, int32_t *shift,
-                      int32_t *opt_order);
+                      int32_t *opt_order, int32_t *fin);
 
 // K3: encode_residual (optimize.c:124-276) incl. the Rice search (rice.c) and,
 // when bits != NULL, the residual section of output_residual (encode.c:766-798).
 hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *smp,
                          int nsub, int n, const int32_t *coefs, const int32_t *shift,
-                         const int32_t *opt_order, fhip_subframe_info *info,
+                         const int32_t *opt_order, const int32_t *fin,
+                         fhip_subframe_info *info,
                          int32_t *residual, uint8_t *bits, int64_t slot_bytes,
                          int raw_order = -1, int raw_lpc = 0);
 

@@ -530,7 +530,7 @@ constexpr int LPC_DBL = 33 + 32 + 32;
 __global__ __launch_bounds__(LPC_NT)
 void k_lpc(const double *__restrict__ autoc_all, int nsub, int max_order, int precision,
            int omethod, int32_t *__restrict__ coefs, int32_t *__restrict__ shift,
-           int32_t *__restrict__ opt_order)
+           int32_t *__restrict__ opt_order, int32_t *__restrict__ fin)
 {
     __shared__ double s_mem[LPC_DBL * LPC_NT];
     const int lane = threadIdx.x;
@@ -622,6 +622,14 @@ void k_lpc(const double *__restrict__ autoc_all, int nsub, int max_order, int pr
             quantize_row(a, i + 1, precision, crow + i * FHIP_MAX_ORDER, srow + i);
     }
     opt_order[s] = levinson_order;
+    if (!all_rows) {
+        // compact copy of the single quantised row for K3's prefetch
+        int32_t *f = fin + (size_t)s * FIN_STRIDE;
+        const int32_t *src = crow + (levinson_order - 1) * FHIP_MAX_ORDER;
+        for (int j = 0; j < max_order; j++) f[j] = (j < levinson_order) ? src[j] : 0;
+        f[32] = srow[levinson_order - 1];
+        f[33] = levinson_order;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1305,7 +1313,8 @@ __device__ __forceinline__ void fir_fixed(const FastCtx<C, T> &e, int32_t (&r)[C
 // rice.c:105-187 on the residuals in r[]; all threads call it.
 template <int C, int T>
 __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, const int32_t (&r)[C],
-                                                     int order, bool lpc)
+                                                     int order, bool lpc, int *porder_out,
+                                                     int *method_out)
 {
     constexpr int LT = (T == 256) ? 8 : (T == 512) ? 9 : 10;     // log2(T): the thread level
     const FastLds &l = e.l;
@@ -1318,6 +1327,8 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
 #pragma unroll
     for (int o = 0; o < C; o++) v += (e.i0 + o >= order) ? zigzag32(r[o]) : 0u;
 
+    // (callers guarantee a barrier between the previous search's reads of
+    // lvl_bits/lvl_meth and this reset)
     if (tid < 12) { l.lvl_bits[tid] = 0; l.lvl_meth[tid] = 0; }
     // levels LT .. LT-6 inside the wave: after s steps, lanes with the low s
     // bits clear hold the sums of level LT-s.  Steps 1,2,4,8 stay inside a
@@ -1339,29 +1350,26 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
     if (lane == 0) l.wtot[e.wv] = v;                 // level LT-6 node
     __syncthreads();
     STAMP(4);
-    // levels above the waves: LT-7 .. 0, a handful of nodes
-    {
-        constexpr int NW = T / WAVE;
-        for (int lev = LT - 7; lev >= 0; lev--) {
-            const int nodes = 1 << lev;
-            const int span = NW >> lev;              // waves per node
-            if (lev <= pmax && lev >= pmin && tid < nodes) {
-                unsigned long long acc = 0;
-                for (int w = 0; w < span; w++) acc += l.wtot[tid * span + w];
-                l.sums[nodes - 1 + tid] = acc;
-            }
-        }
-    }
-    __syncthreads();
     STAMP(5);
     {
+        // one thread per (level, partition) node.  Levels above the waves
+        // (LT-7 .. 0) are summed here from the per-wave totals.
+        constexpr int NW = T / WAVE;
         const int first = (1 << pmin) - 1, last = (2 << pmax) - 2;
         for (int q = first + tid; q <= last; q += T) {
             const int p = ilog2_dev((uint32_t)(q + 1));
             const int jn = q + 1 - (1 << p);
             const int cnt = (n >> p) - (jn == 0 ? order : 0);
+            unsigned long long sum;
+            if (p <= LT - 7) {
+                const int span = NW >> p;              // waves per node
+                sum = 0;
+                for (int w = 0; w < span; w++) sum += l.wtot[jn * span + w];
+            } else {
+                sum = l.sums[q];
+            }
             uint32_t b;
-            const int k = rice_k_fast(l.sums[q], cnt, &b);
+            const int k = rice_k_fast(sum, cnt, &b);
             l.kpar[q] = k;
             atomicAdd(&l.lvl_bits[p], b);
             if (k > 14) atomicOr(&l.lvl_meth[p], 1u);
@@ -1369,29 +1377,27 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
     }
     __syncthreads();
     STAMP(6);
-    if (tid == 0) {
-        // rice.c:127-138; all nine levels are fetched together, then compared
-        uint32_t lb[9], lm[9];
+    // rice.c:127-138, evaluated redundantly by every thread (no broadcast
+    // barrier): all nine levels are fetched together, then compared
+    uint32_t lb[9], lm[9];
 #pragma unroll
-        for (int p = 0; p < 9; p++) { lb[p] = l.lvl_bits[p]; lm[p] = l.lvl_meth[p]; }
-        int bp = pmin;
-        uint32_t best = 0, method = 0;
+    for (int p = 0; p < 9; p++) { lb[p] = l.lvl_bits[p]; lm[p] = l.lvl_meth[p]; }
+    int bp = pmin;
+    uint32_t best = 0, method = 0;
 #pragma unroll
-        for (int p = 0; p < 9; p++) {
-            const uint32_t b = lb[p] + 4u * (1u << p);
-            if (p >= pmin && p <= pmax && (p == pmin || b <= best)) { best = b; bp = p; method = lm[p]; }
-        }
-        uint32_t bits = (uint32_t)(order * e.obits + 2);
-        if (lpc) bits += (uint32_t)(4 + 5 + order * e.precision);
-        bits += best;
-        bits += method + 4u;
-        l.misc[M_PORDER] = bp;
-        l.misc[M_METHOD] = (int)method;
-        l.misc[M_BITS] = (int)bits;
+    for (int p = 0; p < 9; p++) {
+        const uint32_t b = lb[p] + 4u * (1u << p);
+        if (p >= pmin && p <= pmax && (p == pmin || b <= best)) { best = b; bp = p; method = lm[p]; }
     }
-    __syncthreads();
+    // rice.c:157-171
+    uint32_t bits = (uint32_t)(order * e.obits + 2);
+    if (lpc) bits += (uint32_t)(4 + 5 + order * e.precision);
+    bits += best;
+    bits += method + 4u;
+    *porder_out = bp;
+    *method_out = (int)method;
     STAMP(7);
-    return (uint32_t)l.misc[M_BITS];
+    return bits;
 }
 
 // OR `len` (<= 31) bits of val into the MSB-first bit string at bit `pos` of a
@@ -1411,10 +1417,14 @@ __device__ __forceinline__ void put_bits32(uint32_t *win, int nw, long long pos,
 }
 
 template <int C, int T>
-__global__ __launch_bounds__(T, (T == 256) ? 3 : 4)   // VGPR cap: 168 (3 groups of 256 per CU) or 128
-void k_encode_pow2(fhip_params P, int n, const int32_t *__restrict__ smp_all,
+#ifndef FHIP_K3_WPS
+#define FHIP_K3_WPS 3
+#endif
+__global__ __launch_bounds__(T, (T == 256) ? FHIP_K3_WPS : 4)   // VGPR cap per waves/SIMD: 2 -> 256, 3 -> 168, 4 -> 128
+void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ smp_all,
                    const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
-                   const int32_t *__restrict__ opt_all, fhip_subframe_info *__restrict__ info,
+                   const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,
+                   fhip_subframe_info *__restrict__ info,
                    int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1434,29 +1444,52 @@ void k_encode_pow2(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     e.l.bits = reinterpret_cast<uint32_t *>(lds_raw + off[10]);
     const FastLds &l = e.l;
 
-    const int s = blockIdx.x;
     const int tid = threadIdx.x;
-    fhip_subframe_info *out = &info[s];
     e.n = n; e.tid = tid; e.lane = tid & 63; e.wv = tid >> 6;
     e.i0 = tid * C;
-    e.obits = out->obits;
     e.precision = P.lpc_precision;
     e.pmin_req = P.min_partition_order;
     e.pmax_req = P.max_partition_order;
 
+    // MAX / EST: the one row the reference quantises is known before the
+    // search starts and comes compact from K2
+    const bool pre_row = (P.prediction_type == 2) && (n > P.max_prediction_order) && (P.order_method <= 1);
+
+    // One workgroup per subframe (a persistent variant that prefetched the next
+    // subframe into registers measured slower: the hardware's own dispatch of a
+    // fresh workgroup per subframe balances better and costs no VGPRs).
+    const int s = blockIdx.x;
+    int4 xn[C / 4];
+    int32_t first_n, obits_n, fcoef_n = 0, fshift_n = 0, forder_n = 0;
+    {
+        const int32_t *srcp = smp_all + (size_t)s * n;
+        const int4 *src4 = reinterpret_cast<const int4 *>(srcp + e.i0);
+#pragma unroll
+        for (int q = 0; q < C / 4; q++) xn[q] = src4[q];
+        first_n = srcp[0];
+        obits_n = info[s].obits;
+        if (pre_row) {
+            const int32_t *f = fin_all + (size_t)s * FIN_STRIDE;
+            fcoef_n = f[tid & 31];
+            fshift_n = f[32];
+            forder_n = f[33];
+        }
+    }
+  {
+    fhip_subframe_info *out = &info[s];
+    e.obits = obits_n;
+    const int fshift = fshift_n, forder = forder_n;
+
     STAMP(0);
-    // ---- load: 16-byte lane accesses, own run stays in registers ------------
-    const int32_t *src = smp_all + (size_t)s * n;
+    // ---- stage this subframe in LDS ------------------------------------------
     int differs = 0;
     {
         int32_t x[C];
-        const int4 *src4 = reinterpret_cast<const int4 *>(src + e.i0);
 #pragma unroll
         for (int q = 0; q < C / 4; q++) {
-            const int4 vv = src4[q];
-            x[4 * q] = vv.x; x[4 * q + 1] = vv.y; x[4 * q + 2] = vv.z; x[4 * q + 3] = vv.w;
+            x[4 * q] = xn[q].x; x[4 * q + 1] = xn[q].y; x[4 * q + 2] = xn[q].z; x[4 * q + 3] = xn[q].w;
         }
-        const int32_t first = src[0];
+        const int32_t first = first_n;
 #pragma unroll
         for (int o = 0; o < C; o++) {
             l.smp[padidx2(e.i0 + o)] = x[o];
@@ -1464,6 +1497,10 @@ void k_encode_pow2(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         }
     }
     if (tid < HIST) l.smp[padidx2(tid - HIST)] = 0;
+    if (pre_row && tid < FHIP_MAX_ORDER) {
+        l.coef[tid] = fcoef_n;
+        l.coefd[tid] = (double)fcoef_n;
+    }
     const bool constant = (__syncthreads_or(differs) == 0);
     STAMP(1);
 
@@ -1491,11 +1528,11 @@ void k_encode_pow2(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     bool have_best = false;
     int lg_step = 16, lg_last = 0, lg_pos = 3;
     bool final_pass = false;
+    int porder = 0, method = 0;          // of the most recent Rice search
 
     if (tree == T_FIXED) { it = min_order; best = min_order; }
     if (tree == T_LPC) {
-        if (omethod == 0) { best = max_order - 1; final_pass = true; }
-        else if (omethod == 1) { best = opt_all[s] - 1; final_pass = true; }
+        if (omethod <= 1) { best = forder - 1; final_pass = true; }     // MAX: max_order, EST: est
         else if (omethod <= 4) { it = (1 << (omethod - 1)) - 1; best = max_order - 1; }
         else if (omethod == 5) { it = 0; best = 0; }
         else {
@@ -1549,20 +1586,27 @@ void k_encode_pow2(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             uint32_t b;
             if (tree == T_FIXED) {
                 fir_fixed<C, T>(e, r, cand);
-                b = rice_search_fast<C, T>(e, r, cand, false);
+                __syncthreads();                      // previous search fully read
+                b = rice_search_fast<C, T>(e, r, cand, false, &porder, &method);
             } else {
                 const int ord = cand + 1;
-                __syncthreads();                      // readers of coef/coefd are done
-                if (tid < FHIP_MAX_ORDER) {
-                    const int32_t cv = (tid < ord) ? crow_base[cand * FHIP_MAX_ORDER + tid] : 0;
-                    l.coef[tid] = cv;
-                    l.coefd[tid] = (double)cv;
+                int cshift;
+                if (pre_row) {
+                    cshift = fshift;                  // coef/coefd were staged with the samples
+                } else {
+                    __syncthreads();                  // readers of coef/coefd/lvl_* are done
+                    if (tid < FHIP_MAX_ORDER) {
+                        const int32_t cv = (tid < ord) ? crow_base[cand * FHIP_MAX_ORDER + tid] : 0;
+                        l.coef[tid] = cv;
+                        l.coefd[tid] = (double)cv;
+                    }
+                    cshift = srow[cand];
+                    __syncthreads();
                 }
-                __syncthreads();
                 STAMP(2);
-                fir_lpc<C, T>(e, r, ord, srow[cand]);
+                fir_lpc<C, T>(e, r, ord, cshift);
                 STAMP(3);
-                b = rice_search_fast<C, T>(e, r, ord, true);
+                b = rice_search_fast<C, T>(e, r, ord, true, &porder, &method);
                 STAMP(8);
             }
             if (final_pass) { est_bits = b; break; }
@@ -1591,15 +1635,14 @@ void k_encode_pow2(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             type_code = FHIP_SUB_FIXED | order;
         } else {
             order = best + 1;
-            shift = srow[best];
+            shift = pre_row ? fshift : srow[best];
             type = FHIP_SUB_LPC;
             type_code = FHIP_SUB_LPC | (order - 1);
         }
         has_rice = true;
     }
 
-    const int porder = has_rice ? l.misc[M_PORDER] : 0;
-    const int method = has_rice ? l.misc[M_METHOD] : 0;
+    if (!has_rice) { porder = 0; method = 0; }
 
     STAMP(9);
     if (res_out) {
@@ -1763,6 +1806,7 @@ void k_encode_pow2(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         const int np = has_rice ? (1 << porder) : 0;
         out->rparams[tid] = (tid < np) ? l.kpar[np - 1 + tid] : 0;
     }
+  }
 }
 
 }  // namespace
@@ -1809,12 +1853,12 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
 
 hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_order,
                       int precision, int omethod, int32_t *coefs, int32_t *shift,
-                      int32_t *opt_order)
+                      int32_t *opt_order, int32_t *fin)
 {
     if (nsub == 0) return hipSuccess;
     const int blocks = (nsub + LPC_NT - 1) / LPC_NT;
     hipLaunchKernelGGL(k_lpc, dim3(blocks), dim3(LPC_NT), 0, st, autoc, nsub, max_order,
-                       precision, omethod, coefs, shift, opt_order);
+                       precision, omethod, coefs, shift, opt_order, fin);
     return hipGetLastError();
 }
 
@@ -1842,7 +1886,8 @@ static bool fast_geometry(const fhip_params &p, int n, int *C, int *T)
 
 hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *smp,
                          int nsub, int n, const int32_t *coefs, const int32_t *shift,
-                         const int32_t *opt_order, fhip_subframe_info *info,
+                         const int32_t *opt_order, const int32_t *fin,
+                         fhip_subframe_info *info,
                          int32_t *residual, uint8_t *bits, int64_t slot_bytes,
                          int raw_order, int raw_lpc)
 {
@@ -1858,7 +1903,7 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_encode_pow2<CC, TT>), dim3(nsub), dim3(TT), lds, st, p, n,    \
-                           smp, coefs, shift, opt_order, info, residual, bits,               \
+                           nsub, smp, coefs, shift, opt_order, fin, info, residual, bits,    \
                            (long long)slot_bytes);                                           \
     } while (0)
         if (fc == 4) LAUNCH_FAST(4, 256);

@@ -290,6 +290,142 @@ void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
     }
 }
 
+// K0 fast path for stereo frames with n % 4 == 0 and n <= 4096: the frame never
+// touches LDS.  Thread t owns the sample-frame quads 4(t + 256m) .. +3,
+// m < M: two 16-byte loads per quad (coalesced 32 B per lane), both channels
+// stay in registers through the estimate, the decorrelation and the wasted-bits
+// shift, and leave as one 16-byte store per channel and quad.  The two
+// sample-frames in front of a quad (for the 2nd-order residual) are one more
+// 16-byte load that hits L1/L2.
+template <int M>
+__global__ __launch_bounds__(NT)
+void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
+                      fhip_subframe_info *__restrict__ info, int n, int bps, int estimate)
+{
+    __shared__ unsigned long long s_sum[4][4];
+    __shared__ uint32_t s_or[4][2];
+    __shared__ int s_mode;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = blockIdx.x;
+    const int4 *src = reinterpret_cast<const int4 *>(pcm + (size_t)f * n * 2);
+    const int nquads = n >> 2;
+
+    int32_t L[M][4], R[M][4];
+    int4 prev[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const int g = tid + NT * m;
+        const int gc = min(g, nquads - 1);                 // clamped: loads stay unconditional
+        const int4 a = src[2 * gc], b = src[2 * gc + 1];   // (l0 r0 l1 r1) (l2 r2 l3 r3)
+        prev[m] = src[max(2 * gc - 1, 0)];                 // (l-2 r-2 l-1 r-1)
+        L[m][0] = a.x; R[m][0] = a.y; L[m][1] = a.z; R[m][1] = a.w;
+        L[m][2] = b.x; R[m][2] = b.y; L[m][3] = b.z; R[m][3] = b.w;
+    }
+
+    int mode = FHIP_CH_LEFT_RIGHT;
+    if (estimate && n > 32) {
+        // encode.c:598-643 calc_decorr_scores
+        unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const int g = tid + NT * m;
+            uint32_t l2 = (uint32_t)prev[m].x, r2 = (uint32_t)prev[m].y;
+            uint32_t l1 = (uint32_t)prev[m].z, r1 = (uint32_t)prev[m].w;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t l0 = (uint32_t)L[m][q], r0 = (uint32_t)R[m][q];
+                const int32_t lt = (int32_t)(l0 - 2u * l1 + l2);
+                const int32_t rt = (int32_t)(r0 - 2u * r1 + r2);
+                const int32_t mm = (int32_t)((uint32_t)lt + (uint32_t)rt) >> 1;
+                const int32_t ss = (int32_t)((uint32_t)lt - (uint32_t)rt);
+                const bool on = (g < nquads) && (4 * g + q >= 2);
+                a0 += on ? (unsigned long long)(long long)wrap_abs(lt) : 0ull;
+                a1 += on ? (unsigned long long)(long long)wrap_abs(rt) : 0ull;
+                a2 += on ? (unsigned long long)(long long)wrap_abs(mm) : 0ull;
+                a3 += on ? (unsigned long long)(long long)wrap_abs(ss) : 0ull;
+                l2 = l1; r2 = r1; l1 = l0; r1 = r0;
+            }
+        }
+        a0 = wave_sum_u64(a0); a1 = wave_sum_u64(a1);
+        a2 = wave_sum_u64(a2); a3 = wave_sum_u64(a3);
+        if (lane == 0) { s_sum[wv][0] = a0; s_sum[wv][1] = a1; s_sum[wv][2] = a2; s_sum[wv][3] = a3; }
+        __syncthreads();
+        if (tid < 4) {
+            const unsigned long long sm = s_sum[0][tid] + s_sum[1][tid] + s_sum[2][tid] + s_sum[3][tid];
+            uint32_t dummy;
+            const int k = rice_best_k(2 * sm, n, &dummy);
+            s_sum[0][tid] = rice_count64(2 * sm, n, k);       // no 32-bit truncation (encode.c:620)
+        }
+        __syncthreads();
+        {
+            const unsigned long long c0 = s_sum[0][0], c1 = s_sum[0][1], c2 = s_sum[0][2], c3 = s_sum[0][3];
+            const unsigned long long sc[4] = {c0 + c1, c0 + c3, c1 + c3, c2 + c3};
+            int best = 0;
+#pragma unroll
+            for (int q = 1; q < 4; q++) if (sc[q] < sc[best]) best = q;
+            mode = (best == 0) ? FHIP_CH_LEFT_RIGHT : (best == 1) ? FHIP_CH_LEFT_SIDE
+                 : (best == 2) ? FHIP_CH_RIGHT_SIDE : FHIP_CH_MID_SIDE;
+        }
+    }
+
+    // encode.c:668-693 apply, then OR of every sample per channel
+    uint32_t or0 = 0, or1 = 0;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const bool on = (tid + NT * m) < nquads;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int32_t a = L[m][q], b = R[m][q];
+            if (mode == FHIP_CH_MID_SIDE) {
+                const int32_t mid = (int32_t)((uint32_t)a + (uint32_t)b) >> 1;
+                const int32_t sd = (int32_t)((uint32_t)a - (uint32_t)b);
+                a = mid; b = sd;
+            } else if (mode == FHIP_CH_LEFT_SIDE) {
+                b = (int32_t)((uint32_t)a - (uint32_t)b);
+            } else if (mode == FHIP_CH_RIGHT_SIDE) {
+                a = (int32_t)((uint32_t)a - (uint32_t)b);
+            }
+            L[m][q] = a; R[m][q] = b;
+            or0 |= on ? (uint32_t)a : 0u;
+            or1 |= on ? (uint32_t)b : 0u;
+        }
+    }
+    or0 = wave_or_u32(or0); or1 = wave_or_u32(or1);
+    if (lane == 0) { s_or[wv][0] = or0; s_or[wv][1] = or1; }
+    __syncthreads();
+
+    int wasted[2], obits[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        // encode.c:558-593
+        const uint32_t o = s_or[0][c] | s_or[1][c] | s_or[2][c] | s_or[3][c];
+        int w = o ? min(__ffs((int)o) - 1, bps - 1) : bps - 1;
+        if (w == bps - 1) w = 0;
+        wasted[c] = w;
+        obits[c] = bps - w;
+    }
+    if (mode == FHIP_CH_MID_SIDE || mode == FHIP_CH_LEFT_SIDE) obits[1]++;
+    if (mode == FHIP_CH_RIGHT_SIDE) obits[0]++;
+
+    int4 *dl = reinterpret_cast<int4 *>(smp + (size_t)f * 2 * n);
+    int4 *dr = reinterpret_cast<int4 *>(smp + (size_t)f * 2 * n + n);
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const int g = tid + NT * m;
+        if (g < nquads) {
+            dl[g] = make_int4(L[m][0] >> wasted[0], L[m][1] >> wasted[0], L[m][2] >> wasted[0], L[m][3] >> wasted[0]);
+            dr[g] = make_int4(R[m][0] >> wasted[1], R[m][1] >> wasted[1], R[m][2] >> wasted[1], R[m][3] >> wasted[1]);
+        }
+    }
+    if (tid < 2) {
+        fhip_subframe_info *o = &info[(size_t)f * 2 + tid];
+        o->obits = obits[tid];
+        o->wasted = wasted[tid];
+        o->ch_mode = mode;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K1  k_autocorr
 // ---------------------------------------------------------------------------
@@ -1819,6 +1955,18 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
                           int nframes, int n, int32_t *smp, fhip_subframe_info *info)
 {
     const int nch = p.channels;
+    if (nframes == 0) return hipSuccess;
+    if (nch == 2 && (n & 3) == 0 && n <= 4096) {
+        const int est = p.stereo_method == 1 ? 1 : 0;
+        const int quads = n >> 2;
+        if (quads <= NT)
+            hipLaunchKernelGGL(k_prepare_stereo<1>, dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est);
+        else if (quads <= 2 * NT)
+            hipLaunchKernelGGL(k_prepare_stereo<2>, dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est);
+        else
+            hipLaunchKernelGGL(k_prepare_stereo<4>, dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est);
+        return hipGetLastError();
+    }
     const int blocks = (nch == 2) ? nframes : nframes * nch;
     const size_t lds = sizeof(int32_t) * (size_t)n * (nch == 2 ? 2 : 1);
     if (blocks == 0) return hipSuccess;

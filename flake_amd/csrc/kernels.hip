@@ -15,6 +15,8 @@
 //                  bitio.h:120-141 residual-section emit
 #include "kernels.h"
 
+#include <cstdlib>
+
 #ifdef FHIP_STAMPS
 // Diagnostic build only (tools/stamps.py): phase time stamps of workgroup 0.
 __device__ long long g_fhip_stamps[64];
@@ -524,39 +526,60 @@ void k_autocorr(const int32_t *__restrict__ smp, double *__restrict__ autoc,
 
         const int kend = min(AC_TILE, n - tb);
         if (t > 0 && kend == AC_TILE) {
-            // steady state: tb is even, so even k <-> even position.  The LDS
-            // reads of stage c+1 are issued (and pinned with sched_barrier)
-            // before the fp64 ops of stage c.
-            double A[AC_CH], B[AC_CH];
+            // steady state: tb is even, so even k <-> even position.  Three-deep
+            // software pipeline, written out by hand: while stage c's 16 products
+            // are added to the four sums, stage c+1's products are formed and
+            // stage c+2's operands are read from LDS.  Adds and multiplies
+            // alternate so that consecutive adds into the same sum are 8
+            // instructions apart (a dependent fp64 add issues every ~8 cycles, an
+            // independent one every ~4).
+            constexpr int NS = AC_TILE / AC_CH;
+            double A[AC_CH], B[AC_CH], P[2 * AC_CH];
+            double b1n;                               // b1 for the stage in A/B
+            auto rd = [&](int st, double (&a)[AC_CH], double (&b)[AC_CH]) {
 #pragma unroll
-            for (int u = 0; u < AC_CH; u++) { A[u] = rowa[u]; B[u] = pb[u]; }
+                for (int u = 0; u < AC_CH; u++) { a[u] = rowa[st * AC_CH + u]; b[u] = pb[st * AC_CH + u]; }
+            };
+            // products of one stage: P[2u] = a[u]*b[u] (even lag), P[2u+1] = a[u]*prev b (odd lag)
+            rd(0, A, B);
+            {
+                double pbv = b1;
 #pragma unroll
-            for (int cidx = 0; cidx < AC_TILE / AC_CH; cidx++) {
-                double An[AC_CH], Bn[AC_CH];
-                if (cidx + 1 < AC_TILE / AC_CH) {
+                for (int u = 0; u < AC_CH; u++) { P[2 * u] = A[u] * B[u]; P[2 * u + 1] = A[u] * pbv; pbv = B[u]; }
+                b1n = pbv;
+            }
+            rd(1, A, B);
 #pragma unroll
-                    for (int u = 0; u < AC_CH; u++) {
-                        An[u] = rowa[(cidx + 1) * AC_CH + u];
-                        Bn[u] = pb[(cidx + 1) * AC_CH + u];
-                    }
-                }
+            for (int cidx = 0; cidx < NS; cidx++) {
+                double An[AC_CH], Bn[AC_CH], Pn[2 * AC_CH];
+                if (cidx + 2 < NS) rd(cidx + 2, An, Bn);
                 __builtin_amdgcn_sched_barrier(0);
+                double pbv = b1n;
 #pragma unroll
                 for (int u = 0; u < AC_CH; u += 2) {
-                    const double p00 = A[u] * B[u], p01 = A[u] * b1;
-                    const double p10 = A[u + 1] * B[u + 1], p11 = A[u + 1] * B[u];
-                    accE0 = accE0 + p00;
-                    accE1 = accE1 + p01;
-                    accO0 = accO0 + p10;
-                    accO1 = accO1 + p11;
-                    b1 = B[u + 1];
+                    // position u is even, u+1 odd
+                    accE0 = accE0 + P[2 * u];
+                    if (cidx + 1 < NS) Pn[2 * u] = A[u] * B[u];
+                    accE1 = accE1 + P[2 * u + 1];
+                    if (cidx + 1 < NS) Pn[2 * u + 1] = A[u] * pbv;
+                    accO0 = accO0 + P[2 * u + 2];
+                    if (cidx + 1 < NS) Pn[2 * u + 2] = A[u + 1] * B[u + 1];
+                    accO1 = accO1 + P[2 * u + 3];
+                    if (cidx + 1 < NS) Pn[2 * u + 3] = A[u + 1] * B[u];
+                    pbv = B[u + 1];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (cidx + 1 < AC_TILE / AC_CH) {
+                if (cidx + 1 < NS) {
+                    b1n = pbv;
+#pragma unroll
+                    for (int u = 0; u < 2 * AC_CH; u++) P[u] = Pn[u];
+                }
+                if (cidx + 2 < NS) {
 #pragma unroll
                     for (int u = 0; u < AC_CH; u++) { A[u] = An[u]; B[u] = Bn[u]; }
                 }
             }
+            b1 = pb[AC_TILE - 1];
         } else {
             // first tile (head rule, lpc.c:60-61) and a ragged last tile
             double accH0 = 1.0, accH1 = 1.0;
@@ -1990,6 +2013,7 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
     // spread over all CUs when the batch is small: fewer subframes per wave
     // cost nothing (a wave's time is its chain length, not its lane count)
     while (G > 1 && (nsub + G * AC_WAVES - 1) / (G * AC_WAVES) < 256) G--;
+    if (const char *dbg = getenv("FHIP_AC_G")) { int v = atoi(dbg); if (v >= 1 && v <= AC_GMAX && v * nl2 <= WAVE) G = v; }
     const int per_block = G * AC_WAVES;
     const int blocks = (nsub + per_block - 1) / per_block;
     // the window constant is computed on the host exactly as lpc.c:34 does

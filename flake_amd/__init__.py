@@ -348,8 +348,135 @@ def load_host_library() -> C.CDLL:
     lib = C.CDLL(path)
     lib.flake_amd_synth_pcm.restype = None
     lib.flake_amd_synth_pcm.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
+    cp = C.POINTER(HostContext)
+    lib.flake_amd_set_defaults.argtypes = [C.POINTER(HostParams)]
+    lib.flake_amd_validate_params.argtypes = [cp]
+    lib.flake_amd_encode_init.argtypes = [cp]
+    lib.flake_amd_get_buffer.argtypes = [cp]
+    lib.flake_amd_get_buffer.restype = C.c_void_p
+    lib.flake_amd_encode_frame.argtypes = [cp, C.c_void_p, C.c_int]
+    lib.flake_amd_encode_frames.argtypes = [cp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_size_t, C.c_void_p]
+    lib.flake_amd_encode_frames.restype = C.c_longlong
+    lib.flake_amd_encode_close.argtypes = [cp]
+    lib.flake_amd_encode_close.restype = None
+    lib.flake_amd_get_streaminfo.argtypes = [cp, C.POINTER(HostStreaminfo)]
+    lib.flake_amd_write_streaminfo.argtypes = [C.POINTER(HostStreaminfo), C.c_void_p]
+    lib.flake_amd_write_streaminfo.restype = None
+    lib.flake_amd_get_version.restype = C.c_char_p
+    lib.flake_amd_last_error.argtypes = [cp]
+    lib.flake_amd_last_error.restype = C.c_char_p
     _host = lib
     return lib
+
+
+class HostParams(C.Structure):
+    """``FlakeAmdEncodeParams`` (layout of FlakeEncodeParams, flake.h:59-161)."""
+    _fields_ = [(k, C.c_int) for k in (
+        "compression", "order_method", "stereo_method", "block_size", "padding_size",
+        "min_prediction_order", "max_prediction_order", "prediction_type",
+        "min_partition_order", "max_partition_order", "variable_block_size", "allow_vbs")]
+
+
+class HostContext(C.Structure):
+    """``FlakeAmdContext`` (layout of FlakeContext, flake.h:163-215)."""
+    _fields_ = [("channels", C.c_int), ("sample_rate", C.c_int), ("bits_per_sample", C.c_int),
+                ("samples", C.c_uint), ("params", HostParams), ("header", C.c_void_p),
+                ("private_ctx", C.c_void_p)]
+
+
+class HostStreaminfo(C.Structure):
+    _fields_ = [(k, C.c_uint) for k in (
+        "min_block_size", "max_block_size", "min_frame_size", "max_frame_size", "sample_rate",
+        "channels", "bits_per_sample", "samples")] + [("md5sum", C.c_ubyte * 16)]
+
+
+class HostEncoder:
+    """The host C layer (include/flake_amd.h): libflake's call sequence
+    set_defaults -> validate -> encode_init -> encode_frame(s) -> close."""
+
+    def __init__(self, level: int = 5, channels: int = 2, bits_per_sample: int = 16,
+                 sample_rate: int = 44100, samples: int = 0, **over):
+        self.lib = load_host_library()
+        self.ctx = HostContext(channels=channels, sample_rate=sample_rate,
+                               bits_per_sample=bits_per_sample, samples=samples)
+        self.ctx.params.compression = level
+        if self.lib.flake_amd_set_defaults(C.byref(self.ctx.params)) != 0:
+            raise ValueError("flake_amd_set_defaults")
+        for k, v in over.items():
+            if not hasattr(self.ctx.params, k):
+                raise AttributeError(k)
+            setattr(self.ctx.params, k, v)
+        self.subset = self.lib.flake_amd_validate_params(C.byref(self.ctx))
+        if self.subset < 0:
+            raise ValueError("flake_amd_validate_params rejected the parameters")
+        n = self.lib.flake_amd_encode_init(C.byref(self.ctx))
+        if n < 0:
+            raise FlakeHipError(n, "flake_amd_encode_init")
+        self.header = bytes(C.string_at(self.ctx.header, n))
+        self.open = True
+
+    def params(self) -> Params:
+        hp = self.ctx.params
+        return Params(channels=self.ctx.channels, sample_rate=self.ctx.sample_rate,
+                      bits_per_sample=self.ctx.bits_per_sample, block_size=hp.block_size,
+                      order_method=hp.order_method, stereo_method=hp.stereo_method,
+                      prediction_type=hp.prediction_type,
+                      min_prediction_order=hp.min_prediction_order,
+                      max_prediction_order=hp.max_prediction_order,
+                      min_partition_order=hp.min_partition_order,
+                      max_partition_order=hp.max_partition_order,
+                      variable_block_size=hp.variable_block_size, allow_vbs=hp.allow_vbs,
+                      lpc_precision=15)
+
+    def encode_frames(self, pcm: np.ndarray, block_size: int, tail_size: int = 0):
+        """pcm: [nblocks*block_size + tail_size][channels] int32.  Returns (bytes, sizes)."""
+        ch = self.ctx.channels
+        pcm = np.ascontiguousarray(pcm, dtype=np.int32).reshape(-1, ch)
+        nblocks = (pcm.shape[0] - tail_size) // block_size
+        assert nblocks * block_size + tail_size == pcm.shape[0]
+        cap = 64 + pcm.size * 5 + 64 * (nblocks + 1) * 8
+        out = np.zeros(cap, dtype=np.uint8)
+        sizes = np.zeros(nblocks + (1 if tail_size else 0), dtype=np.int32)
+        w = self.lib.flake_amd_encode_frames(C.byref(self.ctx), pcm.ctypes.data, nblocks, block_size,
+                                             tail_size, out.ctypes.data, cap, sizes.ctypes.data)
+        if w < 0:
+            raise FlakeHipError(int(w), "flake_amd_encode_frames",
+                                self.lib.flake_amd_last_error(C.byref(self.ctx)).decode())
+        return out[:w].copy(), sizes
+
+    def encode_frame(self, pcm: np.ndarray) -> bytes:
+        """flake_encode_frame(): one block, result in the library's frame buffer."""
+        ch = self.ctx.channels
+        pcm = np.ascontiguousarray(pcm, dtype=np.int32).reshape(-1, ch)
+        w = self.lib.flake_amd_encode_frame(C.byref(self.ctx), pcm.ctypes.data, pcm.shape[0])
+        if w < 0:
+            raise FlakeHipError(w, "flake_amd_encode_frame",
+                                self.lib.flake_amd_last_error(C.byref(self.ctx)).decode())
+        return bytes(C.string_at(self.lib.flake_amd_get_buffer(C.byref(self.ctx)), w))
+
+    def streaminfo(self) -> HostStreaminfo:
+        si = HostStreaminfo()
+        if self.lib.flake_amd_get_streaminfo(C.byref(self.ctx), C.byref(si)) != 0:
+            raise RuntimeError("flake_amd_get_streaminfo")
+        return si
+
+    def close(self) -> None:
+        if getattr(self, "open", False):
+            self.lib.flake_amd_encode_close(C.byref(self.ctx))
+            self.open = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def synth_pcm(nframes: int, n: int, channels: int, bps: int, first_frame: int = 0) -> np.ndarray:

@@ -1,0 +1,682 @@
+/*
+ * flake_host.c -- the host C layer above the HIP C ABI (include/flakehip.h):
+ * what libflake keeps on the CPU around encode_residual().
+ *
+ *   presets / validation        flake_set_defaults, flake_validate_params  encode.c:158-373
+ *   stream header               write_headers + metadata.c                 encode.c:51-156
+ *   per frame                   init_frame codes, frame header + CRC-8,
+ *                               subframe headers, warm-up samples, coefs,
+ *                               the device-made residual section appended
+ *                               bit for bit, CRC-16, verbatim fallback,
+ *                               frame counter, max frame size, MD5         encode.c:490-536,
+ *                                                                          696-977, 1006
+ *   variable block size         split_frame_v1 + encode_frame_vbs          vbs.c:36-119
+ *
+ * Everything per-sample that the reference does inside encode_residual() and
+ * its feeders happens on the GPU (fhip_encode_subframes); this file only moves
+ * side information and already-packed bits.  Written from the behaviour of
+ * the reference; citations are relative to the reference tree.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "flake_amd.h"
+#include "flakehip.h"
+#include "host_internal.h"
+
+#define VBS_PARTS 8                       /* VBS_MAX_FRAMES, vbs.h:26 */
+#define MIN_BLOCK 16                      /* FLAC_MIN_BLOCKSIZE, encode.h:34 */
+#define MAX_BLOCK 65535
+
+typedef struct host_ctx {
+    fhip_ctx *hip;
+    fhip_params hp;
+    int max_batch;                        /* blocks per GPU batch */
+    int sr_code[2], bps_code, ch_code;
+    int max_frame_size;
+    uint32_t frame_count;
+    int last_frame;
+    fa_md5 md5;
+    /* single-frame buffer of flake_amd_encode_frame */
+    uint8_t *frame_buffer;
+    int frame_buffer_size;
+    /* batch staging (host) */
+    fhip_subframe_info *info;
+    uint8_t *bits;
+    int64_t slot;
+    int32_t *gather;                      /* ragged VBS batches, contiguous per size */
+    char err[256];
+} host_ctx;
+
+/* ------------------------------------------------------------------ */
+/* CRC-8 / CRC-16 (crc.c:24-94: poly 0x07 and 0x8005, MSB first, init 0) */
+/* ------------------------------------------------------------------ */
+static uint8_t crc8_tab[256];
+static uint16_t crc16_tab[256];
+static int crc_ready;
+
+static void crc_setup(void)
+{
+    if (crc_ready) return;
+    for (int i = 0; i < 256; i++) {
+        uint8_t c8 = (uint8_t)i;
+        uint16_t c16 = (uint16_t)(i << 8);
+        for (int b = 0; b < 8; b++) {
+            c8 = (uint8_t)((c8 & 0x80) ? ((c8 << 1) ^ 0x07) : (c8 << 1));
+            c16 = (uint16_t)((c16 & 0x8000) ? ((c16 << 1) ^ 0x8005) : (c16 << 1));
+        }
+        crc8_tab[i] = c8;
+        crc16_tab[i] = c16;
+    }
+    crc_ready = 1;
+}
+
+static uint8_t crc8(const uint8_t *d, size_t n)
+{
+    uint8_t c = 0;
+    while (n--) c = crc8_tab[c ^ *d++];
+    return c;
+}
+
+static uint16_t crc16(const uint8_t *d, size_t n)
+{
+    uint16_t c = 0;
+    while (n--) c = (uint16_t)((c << 8) ^ crc16_tab[(c >> 8) ^ *d++]);
+    return c;
+}
+
+/* ------------------------------------------------------------------ */
+/* MSB-first bit sink (same byte stream as bitio.h:83-141)             */
+/* ------------------------------------------------------------------ */
+typedef struct { uint8_t *buf; size_t cap, pos; uint64_t acc; int nacc; int over; } sink;
+
+static void sink_init(sink *s, uint8_t *buf, size_t cap)
+{
+    s->buf = buf; s->cap = cap; s->pos = 0; s->acc = 0; s->nacc = 0; s->over = 0;
+}
+
+static void sink_put(sink *s, int nb, uint32_t v)      /* nb <= 32 */
+{
+    if (nb == 0) return;
+    s->acc = (s->acc << nb) | (uint64_t)(nb == 32 ? v : (v & ((1u << nb) - 1u)));
+    s->nacc += nb;
+    while (s->nacc >= 8) {
+        if (s->pos >= s->cap) { s->over = 1; s->nacc -= 8; continue; }
+        s->nacc -= 8;
+        s->buf[s->pos++] = (uint8_t)(s->acc >> s->nacc);
+    }
+}
+
+static void sink_put_signed(sink *s, int nb, int32_t v) { sink_put(s, nb, (uint32_t)v); }
+
+/* append nbits of an MSB-first bit string that starts at bit 0 of src */
+static void sink_append(sink *s, const uint8_t *src, int64_t nbits)
+{
+    int64_t full = nbits >> 3;
+    if (s->nacc == 0) {                   /* byte aligned: plain copy */
+        if (s->pos + (size_t)full > s->cap) { s->over = 1; return; }
+        memcpy(s->buf + s->pos, src, (size_t)full);
+        s->pos += (size_t)full;
+    } else {
+        for (int64_t i = 0; i < full; i++) sink_put(s, 8, src[i]);
+    }
+    int rem = (int)(nbits & 7);
+    if (rem) sink_put(s, rem, (uint32_t)(src[full] >> (8 - rem)));
+}
+
+static void sink_align(sink *s) { if (s->nacc) sink_put(s, 8 - s->nacc, 0); }
+
+/* ------------------------------------------------------------------ */
+/* presets and validation                                             */
+/* ------------------------------------------------------------------ */
+static int ilog2u(uint32_t v) { int r = 0; while (v > 1) { v >>= 1; r++; } return r; }
+
+FLAKE_AMD_API int flake_amd_set_defaults(FlakeAmdEncodeParams *p)
+{
+    if (!p) return -1;
+    const int lvl = p->compression;
+    if (lvl < 0 || lvl > 12) return -1;
+    /* level 5 is the base row of the table (encode.c:170-181) */
+    p->order_method = 1; p->stereo_method = 1; p->block_size = 4096; p->prediction_type = 2;
+    p->min_prediction_order = 1; p->max_prediction_order = 8;
+    p->min_partition_order = 0; p->max_partition_order = 5;
+    p->padding_size = 8192; p->variable_block_size = 0; p->allow_vbs = 0;
+    static const int fixed_min[3] = {2, 2, 0}, fixed_max[3] = {2, 4, 4};
+    if (lvl <= 2) {
+        p->block_size = 1152; p->prediction_type = 1;
+        p->min_prediction_order = fixed_min[lvl]; p->max_prediction_order = fixed_max[lvl];
+        p->max_partition_order = 3;
+        if (lvl == 0) p->stereo_method = 0;
+    } else if (lvl == 3) {
+        p->stereo_method = 0; p->max_prediction_order = 6; p->max_partition_order = 4;
+    } else if (lvl == 4) {
+        p->max_partition_order = 4;
+    } else if (lvl == 6 || lvl == 7) {
+        p->max_partition_order = 6;
+        if (lvl == 7) p->order_method = 3;
+    } else if (lvl >= 8) {
+        p->order_method = (lvl == 10 || lvl == 12) ? 5 : 6;
+        p->max_prediction_order = (lvl >= 11) ? 32 : 12;
+        p->max_partition_order = (lvl == 8) ? 6 : 8;
+        if (lvl >= 11) p->block_size = 8192;
+        if (lvl >= 9) { p->allow_vbs = 1; p->variable_block_size = 1; }
+    }
+    return 0;
+}
+
+FLAKE_AMD_API int flake_amd_validate_params(const FlakeAmdContext *s)
+{
+    if (!s) return -1;
+    const FlakeAmdEncodeParams *p = &s->params;
+    int subset = 0;
+    if (s->channels < 1 || s->channels > 8) return -1;
+    if (s->sample_rate < 1 || s->sample_rate > 655350) return -1;
+    if (s->bits_per_sample < 4 || s->bits_per_sample > 32) return -1;
+    if (s->bits_per_sample < 8 || s->bits_per_sample > 24 || s->bits_per_sample % 4) subset = 1;
+    if (p->compression < 0 || p->compression > 12) return -1;
+    if (p->order_method < 0 || p->order_method > 6) return -1;
+    if (p->stereo_method < 0 || p->stereo_method > 1) return -1;
+    if (p->block_size < MIN_BLOCK || p->block_size > MAX_BLOCK) return -1;
+    if (s->sample_rate <= 48000 && p->block_size > 4608) subset = 1;
+    if (p->prediction_type < 0 || p->prediction_type > 2) return -1;
+    if (p->min_prediction_order > p->max_prediction_order) return -1;
+    if (p->prediction_type == 1) {
+        if (p->min_prediction_order < 0 || p->min_prediction_order > 4) return -1;
+        if (p->max_prediction_order < 0 || p->max_prediction_order > 4) return -1;
+    } else {
+        if (p->min_prediction_order < 1 || p->min_prediction_order > 32) return -1;
+        if (p->max_prediction_order < 1 || p->max_prediction_order > 32) return -1;
+        if (s->sample_rate <= 48000 && p->max_prediction_order > 12) subset = 1;
+    }
+    if (p->min_partition_order > p->max_partition_order) return -1;
+    if (p->min_partition_order < 0 || p->min_partition_order > 8) return -1;
+    if (p->max_partition_order < 0 || p->max_partition_order > 8) return -1;
+    if (p->padding_size < 0 || p->padding_size >= (1 << 24)) return -1;
+    if (p->variable_block_size < 0 || p->variable_block_size > 1) return -1;
+    if (p->variable_block_size > 0 && !p->allow_vbs) return -1;
+    if (p->block_size < VBS_PARTS * MIN_BLOCK && p->allow_vbs) return -1;
+    return subset;
+}
+
+FLAKE_AMD_API const char *flake_amd_get_version(void) { return "flake-amd 0.1"; }
+
+FLAKE_AMD_API const char *flake_amd_last_error(const FlakeAmdContext *s)
+{
+    return (s && s->private_ctx) ? ((host_ctx *)s->private_ctx)->err : "";
+}
+
+/* ------------------------------------------------------------------ */
+/* stream header: encode.c:51-156 + metadata.c:32-229                  */
+/* ------------------------------------------------------------------ */
+static int frame_verbatim_size(const host_ctx *c, int n)          /* encode.c:521-527 */
+{
+    const int bps = c->hp.bits_per_sample;
+    if (c->hp.channels == 2) return 16 + ((n * (bps + bps + 1) + 7) >> 3);
+    return 16 + ((n * c->hp.channels * bps + 7) >> 3);
+}
+
+FLAKE_AMD_API int flake_amd_get_streaminfo(const FlakeAmdContext *s, FlakeAmdStreaminfo *si)
+{
+    if (!s || !si || !s->private_ctx || flake_amd_validate_params(s) < 0) return -1;
+    const host_ctx *c = (const host_ctx *)s->private_ctx;
+    si->min_block_size = (s->params.variable_block_size || s->params.allow_vbs) ? 16u
+                                                                                : (unsigned)s->params.block_size;
+    si->max_block_size = (unsigned)s->params.block_size;
+    si->min_frame_size = 0;
+    si->max_frame_size = (unsigned)c->max_frame_size;
+    si->sample_rate = (unsigned)s->sample_rate;
+    si->channels = (unsigned)s->channels;
+    si->bits_per_sample = (unsigned)s->bits_per_sample;
+    si->samples = s->samples;
+    fa_md5_final(&c->md5, si->md5sum);
+    return 0;
+}
+
+FLAKE_AMD_API void flake_amd_write_streaminfo(const FlakeAmdStreaminfo *si, unsigned char *d)
+{
+    sink s;
+    memset(d, 0, 34);
+    sink_init(&s, d, 34);
+    sink_put(&s, 16, si->min_block_size);
+    sink_put(&s, 16, si->max_block_size);
+    sink_put(&s, 24, si->min_frame_size);
+    sink_put(&s, 24, si->max_frame_size);
+    sink_put(&s, 20, si->sample_rate);
+    sink_put(&s, 3, si->channels - 1);
+    sink_put(&s, 5, si->bits_per_sample - 1);
+    sink_put(&s, 4, 0);
+    sink_put(&s, 32, si->samples);
+    memcpy(d + 18, si->md5sum, 16);
+}
+
+static void put_block_header(uint8_t *d, int last, int type, int size)
+{
+    d[0] = (uint8_t)((last << 7) | type);
+    d[1] = (uint8_t)(size >> 16); d[2] = (uint8_t)(size >> 8); d[3] = (uint8_t)size;
+}
+
+static int write_stream_header(FlakeAmdContext *s, uint8_t *h)
+{
+    int n = 0;
+    memcpy(h, "fLaC", 4); n += 4;
+    put_block_header(h + n, 0, 0, 34); n += 4;
+    FlakeAmdStreaminfo si;
+    flake_amd_get_streaminfo(s, &si);
+    flake_amd_write_streaminfo(&si, h + n); n += 34;
+    /* Vorbis comment with the vendor string only (metadata.c:86-229) */
+    const char *vendor = "flake-amd 0.1";
+    const int vlen = (int)strlen(vendor);
+    const int last_vc = s->params.padding_size == 0;
+    put_block_header(h + n, last_vc, 4, 8 + vlen); n += 4;
+    h[n++] = (uint8_t)vlen; h[n++] = 0; h[n++] = 0; h[n++] = 0;
+    memcpy(h + n, vendor, (size_t)vlen); n += vlen;
+    memset(h + n, 0, 4); n += 4;
+    if (s->params.padding_size > 0) {
+        put_block_header(h + n, 1, 1, s->params.padding_size); n += 4;
+        memset(h + n, 0, (size_t)s->params.padding_size); n += s->params.padding_size;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* init / close                                                       */
+/* ------------------------------------------------------------------ */
+static const int sr_table[16] = {0, 0, 0, 0, 8000, 16000, 22050, 24000, 32000, 44100, 48000,
+                                 96000, 0, 0, 0, 0};              /* encode.c:33-37 */
+static const int bd_table[8] = {0, 8, 12, 0, 16, 20, 24, 0};      /* encode.c:39-41 */
+static const int bs_table[15] = {0, 192, 576, 1152, 2304, 4608, 0, 0, 256, 512, 1024, 2048,
+                                 4096, 8192, 16384};              /* encode.c:43-49 */
+
+FLAKE_AMD_API int flake_amd_encode_init(FlakeAmdContext *s)
+{
+    if (!s) return -1;
+    s->header = NULL;
+    s->private_ctx = NULL;
+    if (flake_amd_validate_params(s) < 0) return -1;
+    crc_setup();
+    host_ctx *c = (host_ctx *)calloc(1, sizeof(host_ctx));
+    if (!c) return -1;
+    s->private_ctx = c;
+
+    fhip_params *hp = &c->hp;
+    hp->channels = s->channels; hp->sample_rate = s->sample_rate;
+    hp->bits_per_sample = s->bits_per_sample; hp->block_size = s->params.block_size;
+    hp->order_method = s->params.order_method; hp->stereo_method = s->params.stereo_method;
+    hp->prediction_type = s->params.prediction_type;
+    hp->min_prediction_order = s->params.min_prediction_order;
+    hp->max_prediction_order = s->params.max_prediction_order;
+    hp->min_partition_order = s->params.min_partition_order;
+    hp->max_partition_order = s->params.max_partition_order;
+    hp->variable_block_size = s->params.variable_block_size;
+    hp->allow_vbs = s->params.allow_vbs;
+    hp->lpc_precision = 15;                                       /* encode.c:443 */
+
+    /* sample-rate / bit-depth codes, encode.c:400-438 */
+    c->sr_code[0] = 0; c->sr_code[1] = 0;
+    for (int i = 4; i < 12; i++) if (s->sample_rate == sr_table[i]) { c->sr_code[0] = i; break; }
+    if (!c->sr_code[0]) {
+        const int sr = s->sample_rate;
+        if (sr % 1000 == 0 && sr <= 255000) { c->sr_code[0] = 12; c->sr_code[1] = sr / 1000; }
+        else if (sr % 10 == 0 && sr <= 655350) { c->sr_code[0] = 14; c->sr_code[1] = sr / 10; }
+        else if (sr < 65535) { c->sr_code[0] = 13; c->sr_code[1] = sr; }
+    }
+    c->bps_code = 0;
+    for (int i = 1; i < 8; i++) if (s->bits_per_sample == bd_table[i]) { c->bps_code = i; break; }
+    c->ch_code = s->channels - 1;
+    c->max_frame_size = frame_verbatim_size(c, s->params.block_size);   /* encode.c:446-450 */
+    c->frame_buffer_size = c->max_frame_size * 3 / 2;
+    c->frame_buffer = (uint8_t *)calloc((size_t)c->frame_buffer_size, 1);
+    fa_md5_init(&c->md5);
+
+    const char *eb = getenv("FLAKE_AMD_BATCH"), *ed = getenv("FLAKE_AMD_DEVICE");
+    c->max_batch = eb ? atoi(eb) : 1024;
+    if (c->max_batch < 1) c->max_batch = 1;
+    /* a VBS block may turn into up to 8 frames of the smallest size */
+    const int max_frames = c->max_batch * (s->params.variable_block_size ? VBS_PARTS : 1);
+    int rc = fhip_create(&c->hip, ed ? atoi(ed) : 0, hp, max_frames);
+    if (rc != FHIP_OK) {
+        snprintf(c->err, sizeof c->err, "fhip_create: %s", fhip_strerror(rc));
+        flake_amd_encode_close(s);
+        return rc;
+    }
+    c->slot = (frame_verbatim_size(c, s->params.block_size) + 3) & ~3;
+    const size_t nsub = (size_t)max_frames * (size_t)s->channels;
+    c->info = (fhip_subframe_info *)malloc(nsub * sizeof(fhip_subframe_info));
+    c->bits = (uint8_t *)malloc(nsub * (size_t)c->slot);
+    c->gather = (int32_t *)malloc(sizeof(int32_t) * (size_t)c->max_batch *
+                                  (size_t)s->params.block_size * (size_t)s->channels);
+    s->header = (unsigned char *)calloc((size_t)s->params.padding_size + 1024, 1);
+    if (!c->frame_buffer || !c->info || !c->bits || !c->gather || !s->header) {
+        flake_amd_encode_close(s);
+        return -1;
+    }
+    return write_stream_header(s, s->header);
+}
+
+FLAKE_AMD_API void *flake_amd_get_buffer(const FlakeAmdContext *s)
+{
+    return (s && s->private_ctx) ? ((host_ctx *)s->private_ctx)->frame_buffer : NULL;
+}
+
+FLAKE_AMD_API void flake_amd_encode_close(FlakeAmdContext *s)
+{
+    if (!s) return;
+    host_ctx *c = (host_ctx *)s->private_ctx;
+    if (c) {
+        if (c->hip) fhip_destroy(c->hip);
+        free(c->frame_buffer); free(c->info); free(c->bits); free(c->gather);
+        free(c);
+    }
+    free(s->header);
+    s->header = NULL;
+    s->private_ctx = NULL;
+}
+
+/* ------------------------------------------------------------------ */
+/* one frame from the device's side information                        */
+/* ------------------------------------------------------------------ */
+static void put_utf8(sink *s, uint32_t v)                          /* encode.c:696-716 */
+{
+    if (v < 0x80) { sink_put(s, 8, v); return; }
+    const int bytes = (ilog2u(v) + 4) / 5;
+    int sh = (bytes - 1) * 6;
+    sink_put(s, 8, ((256u - (256u >> bytes)) | (v >> sh)) & 0xFFu);
+    while (sh >= 6) { sh -= 6; sink_put(s, 8, 0x80u | ((v >> sh) & 0x3Fu)); }
+}
+
+static void put_frame_header(sink *s, const host_ctx *c, uint32_t number, int n, int ch_mode)
+{
+    int bs0 = -1, bs1 = -1;                                        /* encode.c:502-519 */
+    for (int i = 0; i < 15; i++) if (n == bs_table[i]) { bs0 = i; break; }
+    if (bs0 < 0) { bs0 = (n <= 256) ? 6 : 7; bs1 = n - 1; }
+    const size_t start = s->pos;
+    sink_put(s, 15, 0x7FFC);                                       /* encode.c:718-764 */
+    sink_put(s, 1, (uint32_t)c->hp.allow_vbs);
+    sink_put(s, 4, (uint32_t)bs0);
+    sink_put(s, 4, (uint32_t)c->sr_code[0]);
+    sink_put(s, 4, (uint32_t)(ch_mode == FHIP_CH_NOT_STEREO ? c->ch_code : ch_mode));
+    sink_put(s, 3, (uint32_t)c->bps_code);
+    sink_put(s, 1, 0);
+    put_utf8(s, number);
+    if (bs1 >= 0) sink_put(s, bs1 < 256 ? 8 : 16, (uint32_t)bs1);
+    if (c->sr_code[1] > 0) sink_put(s, c->sr_code[1] < 256 ? 8 : 16, (uint32_t)c->sr_code[1]);
+    sink_put(s, 8, s->over ? 0 : crc8(s->buf + start, s->pos - start));
+}
+
+/* samples of one channel after decorrelation and wasted-bits shift, recomputed
+ * on the host for the rare VERBATIM subframes (encode.c:648-694, :558-593) */
+static void verbatim_samples(const host_ctx *c, const int32_t *pcm, int n, int ch,
+                             const fhip_subframe_info *i, int32_t *dst)
+{
+    const int nch = c->hp.channels;
+    for (int t = 0; t < n; t++) {
+        int32_t v;
+        if (nch == 2 && i->ch_mode != FHIP_CH_LEFT_RIGHT) {
+            const int32_t l = pcm[2 * t], r = pcm[2 * t + 1];
+            const int32_t side = (int32_t)((uint32_t)l - (uint32_t)r);
+            if (i->ch_mode == FHIP_CH_MID_SIDE) v = ch ? side : ((int32_t)((uint32_t)l + (uint32_t)r) >> 1);
+            else if (i->ch_mode == FHIP_CH_LEFT_SIDE) v = ch ? side : l;
+            else v = ch ? r : side;                                /* RIGHT_SIDE */
+        } else {
+            v = pcm[(size_t)t * nch + ch];
+        }
+        dst[t] = v >> i->wasted;
+    }
+}
+
+/* encode.c:800-905 output_subframes for one channel */
+static void put_subframe(sink *s, const host_ctx *c, const fhip_subframe_info *i,
+                         const uint8_t *rice, const int32_t *pcm, int n, int ch, int force_verbatim,
+                         int32_t *scratch)
+{
+    const int type = force_verbatim ? FHIP_SUB_VERBATIM : i->type;
+    sink_put(s, 1, 0);
+    sink_put(s, 6, (uint32_t)(force_verbatim ? FHIP_SUB_VERBATIM : i->type_code));
+    if (i->wasted) { sink_put(s, 1, 1); sink_put(s, i->wasted - 1, 0); sink_put(s, 1, 1); }
+    else sink_put(s, 1, 0);
+    switch (type) {
+    case FHIP_SUB_CONSTANT:
+        sink_put_signed(s, i->obits, i->warmup[0]);
+        break;
+    case FHIP_SUB_VERBATIM:
+        verbatim_samples(c, pcm, n, ch, i, scratch);
+        for (int t = 0; t < n; t++) sink_put_signed(s, i->obits, scratch[t]);
+        break;
+    case FHIP_SUB_FIXED:
+        for (int t = 0; t < i->order; t++) sink_put_signed(s, i->obits, i->warmup[t]);
+        sink_append(s, rice, i->rice_nbits);
+        break;
+    case FHIP_SUB_LPC:
+        for (int t = 0; t < i->order; t++) sink_put_signed(s, i->obits, i->warmup[t]);
+        sink_put(s, 4, (uint32_t)(c->hp.lpc_precision - 1));
+        sink_put_signed(s, 5, i->shift);
+        for (int t = 0; t < i->order; t++) sink_put_signed(s, c->hp.lpc_precision, i->coefs[t]);
+        sink_append(s, rice, i->rice_nbits);
+        break;
+    }
+}
+
+/* encode.c:944-964: header + subframes + footer; verbatim re-encode when the
+ * frame is larger than its verbatim size or a section did not fit its slot */
+static int assemble_frame(host_ctx *c, uint32_t number, const int32_t *pcm, int n,
+                          const fhip_subframe_info *info, const uint8_t *bits,
+                          uint8_t *out, size_t cap, int32_t *scratch)
+{
+    const int nch = c->hp.channels;
+    int overflow = 0;
+    for (int ch = 0; ch < nch; ch++) if (info[ch].rice_nbits < 0) overflow = 1;
+    for (int pass = overflow ? 1 : 0; pass < 2; pass++) {
+        sink s;
+        sink_init(&s, out, cap);
+        put_frame_header(&s, c, number, n, info[0].ch_mode);
+        for (int ch = 0; ch < nch; ch++)
+            put_subframe(&s, c, &info[ch], bits + (size_t)ch * (size_t)c->slot, pcm, n, ch, pass, scratch);
+        sink_align(&s);
+        if (!s.over) {
+            const uint16_t crc = crc16(out, s.pos);
+            sink_put(&s, 16, crc);
+        }
+        if (!s.over && (pass == 1 || (int)s.pos <= frame_verbatim_size(c, n))) return (int)s.pos;
+        if (pass == 1) return -1;
+    }
+    return -1;
+}
+
+/* ------------------------------------------------------------------ */
+/* vbs.c:36-83 split_frame_v1                                          */
+/* ------------------------------------------------------------------ */
+static int vbs_split(const int32_t *pcm, int channels, int block_size, int sizes[VBS_PARTS])
+{
+    const int n = block_size / VBS_PARTS;
+    int64_t score[VBS_PARTS];
+    for (int p = 0; p < VBS_PARTS; p++) {
+        const int32_t *b = pcm + (size_t)p * n * channels;
+        int64_t acc = 0;
+        for (int ch = 0; ch < channels; ch++)
+            for (int j = 2; j < n; j++) {
+                const uint32_t x0 = (uint32_t)b[(size_t)j * channels + ch];
+                const uint32_t x1 = (uint32_t)b[(size_t)(j - 1) * channels + ch];
+                const uint32_t x2 = (uint32_t)b[(size_t)(j - 2) * channels + ch];
+                const int32_t d = (int32_t)(x0 - 2u * x1 + x2);
+                acc += (int64_t)(d < 0 ? (int32_t)(0u - (uint32_t)d) : d);
+            }
+        score[p] = acc / channels + 1;
+    }
+    int nf = 0;
+    memset(sizes, 0, sizeof(int) * VBS_PARTS);
+    for (int p = 0; p < VBS_PARTS; p++) {
+        int cut = (p == 0);
+        if (p > 0) {
+            /* vbs.c:69 with its int abs() and 32-bit multiply */
+            int32_t diff = (int32_t)(uint32_t)(uint64_t)(score[p - 1] - score[p]);
+            if (diff < 0) diff = (int32_t)(0u - (uint32_t)diff);
+            const int32_t scaled = (int32_t)((uint32_t)diff * 200u);
+            cut = ((int64_t)scaled / score[p - 1]) > 50;
+        }
+        if (cut) nf++;
+        sizes[nf - 1] += n;
+    }
+    return nf;
+}
+
+/* ------------------------------------------------------------------ */
+/* batches                                                            */
+/* ------------------------------------------------------------------ */
+typedef struct { const int32_t *pcm; int n; int block; } piece;       /* one FLAC frame to make */
+
+static int run_gpu(host_ctx *c, const int32_t *pcm, int nframes, int n, size_t first_sub)
+{
+    fhip_batch b;
+    memset(&b, 0, sizeof b);
+    b.pcm = pcm; b.nframes = nframes; b.block_size = n;
+    b.info = c->info + first_sub;
+    b.rice_bits = c->bits + first_sub * (size_t)c->slot;
+    b.rice_slot_bytes = c->slot;
+    int rc = fhip_encode_subframes(c->hip, &b);
+    if (rc != FHIP_OK)
+        snprintf(c->err, sizeof c->err, "fhip_encode_subframes: %s (%s)", fhip_strerror(rc),
+                 fhip_last_error(c->hip));
+    return rc;
+}
+
+/* Encode `count` blocks starting at pcm (each block_size samples/channel). */
+static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pcm, int count,
+                              int block_size, uint8_t *out, size_t cap, int *frame_sizes)
+{
+    const int nch = c->hp.channels;
+    const size_t bstride = (size_t)block_size * nch;
+    const int vbs = s->params.variable_block_size > 0 && (block_size % VBS_PARTS) == 0 &&
+                    block_size >= VBS_PARTS * MIN_BLOCK;           /* encode.c:997-999 */
+    piece *pieces = (piece *)malloc(sizeof(piece) * (size_t)count * VBS_PARTS);
+    int32_t *scratch = (int32_t *)malloc(sizeof(int32_t) * (size_t)block_size);
+    if (!pieces || !scratch) { free(pieces); free(scratch); return -1; }
+    int np = 0;
+    for (int b = 0; b < count; b++) {
+        int sizes[VBS_PARTS], nf = 1;
+        sizes[0] = block_size;
+        if (vbs) {
+            nf = vbs_split(pcm + b * bstride, nch, block_size, sizes);
+            if (nf <= 1) { nf = 1; sizes[0] = block_size; }        /* vbs.c:100, encode.c:1001 */
+        }
+        int pos = 0;
+        for (int f = 0; f < nf; f++) {
+            pieces[np].pcm = pcm + b * bstride + (size_t)pos * nch;
+            pieces[np].n = sizes[f];
+            pieces[np].block = b;
+            pos += sizes[f];
+            np++;
+        }
+    }
+    /* GPU: one launch per distinct frame length; pieces keep their order in info[] */
+    long long total = -1;
+    int *slot_of = (int *)malloc(sizeof(int) * (size_t)np);
+    char *done = (char *)calloc((size_t)np, 1);
+    if (!slot_of || !done) goto out;
+    {
+        int next_slot = 0;
+        for (int i = 0; i < np; i++) {
+            if (done[i]) continue;
+            const int n = pieces[i].n;
+            /* gather all pieces of this length */
+            int cnt = 0, contiguous = 1;
+            const int32_t *base = pieces[i].pcm;
+            for (int j = i; j < np; j++) {
+                if (done[j] || pieces[j].n != n) continue;
+                if (pieces[j].pcm != base + (size_t)cnt * n * nch) contiguous = 0;
+                cnt++;
+            }
+            const int32_t *src = base;
+            if (!contiguous) {
+                int k = 0;
+                for (int j = i; j < np; j++) {
+                    if (done[j] || pieces[j].n != n) continue;
+                    memcpy(c->gather + (size_t)k * n * nch, pieces[j].pcm, sizeof(int32_t) * (size_t)n * nch);
+                    k++;
+                }
+                src = c->gather;
+            }
+            if (run_gpu(c, src, cnt, n, (size_t)next_slot * nch) != FHIP_OK) goto out;
+            int k = 0;
+            for (int j = i; j < np; j++) {
+                if (done[j] || pieces[j].n != n) continue;
+                slot_of[j] = next_slot + k;
+                done[j] = 1;
+                k++;
+            }
+            next_slot += cnt;
+        }
+    }
+    /* host: frames in stream order */
+    {
+        size_t pos = 0;
+        int cur_block = -1;
+        for (int i = 0; i < np; i++) {
+            const size_t sub = (size_t)slot_of[i] * nch;
+            const int fs = assemble_frame(c, c->frame_count, pieces[i].pcm, pieces[i].n,
+                                          c->info + sub, c->bits + sub * (size_t)c->slot,
+                                          out + pos, cap - pos, scratch);
+            if (fs < 0) { snprintf(c->err, sizeof c->err, "output buffer too small"); goto out; }
+            if (fs > c->max_frame_size) c->max_frame_size = fs;    /* encode.c:967 */
+            c->frame_count += s->params.allow_vbs ? (uint32_t)pieces[i].n : 1u;   /* encode.c:969-975 */
+            if (frame_sizes) {
+                if (pieces[i].block != cur_block) { cur_block = pieces[i].block; frame_sizes[cur_block] = 0; }
+                frame_sizes[cur_block] += fs;
+            }
+            pos += (size_t)fs;
+        }
+        total = (long long)pos;
+    }
+    fa_md5_pcm(&c->md5, pcm, (size_t)count * bstride, c->hp.bits_per_sample);   /* encode.c:1006 */
+out:
+    free(pieces); free(scratch); free(slot_of); free(done);
+    return total;
+}
+
+FLAKE_AMD_API long long flake_amd_encode_frames(FlakeAmdContext *s, const int *samples, int nblocks,
+                                                int block_size, int tail_size, unsigned char *out,
+                                                size_t out_size, int *frame_sizes)
+{
+    if (!s || !samples || !s->private_ctx || !out) return -1;
+    host_ctx *c = (host_ctx *)s->private_ctx;
+    c->err[0] = 0;
+    if (nblocks < 0 || block_size < 1 || block_size > s->params.block_size) return -1;   /* encode.c:987 */
+    if (tail_size < 0 || tail_size >= block_size + (nblocks == 0)) return -1;
+    if (c->last_frame) return -1;                                                        /* encode.c:989 */
+    if (!s->params.allow_vbs && nblocks > 0 && block_size != s->params.block_size) {
+        /* a short block latches the end of the stream (encode.c:991-992) */
+        if (nblocks > 1 || tail_size) return -1;
+        c->last_frame = 1;
+    }
+    const size_t bstride = (size_t)block_size * (size_t)s->channels;
+    long long total = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += c->max_batch) {
+        const int cnt = (nblocks - b0 < c->max_batch) ? nblocks - b0 : c->max_batch;
+        long long w = encode_batch(s, c, (const int32_t *)samples + (size_t)b0 * bstride, cnt, block_size,
+                                   out + total, out_size - (size_t)total,
+                                   frame_sizes ? frame_sizes + b0 : NULL);
+        if (w < 0) return -1;
+        total += w;
+    }
+    if (tail_size > 0) {
+        if (!s->params.allow_vbs) c->last_frame = 1;
+        long long w = encode_batch(s, c, (const int32_t *)samples + (size_t)nblocks * bstride, 1, tail_size,
+                                   out + total, out_size - (size_t)total,
+                                   frame_sizes ? frame_sizes + nblocks : NULL);
+        if (w < 0) return -1;
+        total += w;
+    }
+    return total;
+}
+
+FLAKE_AMD_API int flake_amd_encode_frame(FlakeAmdContext *s, const int *samples, int block_size)
+{
+    if (!s || !samples || !s->private_ctx) return -1;
+    host_ctx *c = (host_ctx *)s->private_ctx;
+    if (block_size < 1 || block_size > s->params.block_size) return -1;
+    const int short_block = block_size != s->params.block_size;
+    long long w = flake_amd_encode_frames(s, samples, short_block ? 0 : 1, short_block ? s->params.block_size : block_size,
+                                          short_block ? block_size : 0, c->frame_buffer,
+                                          (size_t)c->frame_buffer_size, NULL);
+    return (int)w;
+}

@@ -26,6 +26,77 @@
 extern "C" {
 #endif
 
+/* ---- libflake-compatible encoder surface ----------------------------- */
+
+/* Layout-compatible with FlakeEncodeParams (flake.h:59-161); same field
+ * meaning and ranges. */
+typedef struct FlakeAmdEncodeParams {
+    int compression;             /* 0..12 */
+    int order_method;            /* FLAKE_ORDER_METHOD_* 0..6 */
+    int stereo_method;           /* 0 independent, 1 estimate */
+    int block_size;
+    int padding_size;
+    int min_prediction_order;
+    int max_prediction_order;
+    int prediction_type;         /* 0 none, 1 fixed, 2 levinson */
+    int min_partition_order;
+    int max_partition_order;
+    int variable_block_size;
+    int allow_vbs;
+} FlakeAmdEncodeParams;
+
+/* Layout-compatible with FlakeContext (flake.h:163-215). */
+typedef struct FlakeAmdContext {
+    int channels;
+    int sample_rate;
+    int bits_per_sample;
+    unsigned int samples;        /* total stream samples, 0 = unknown */
+    FlakeAmdEncodeParams params;
+    unsigned char *header;       /* allocated by init, freed by close */
+    void *private_ctx;
+} FlakeAmdContext;
+
+/* flake.h:241-251 FlakeStreaminfo */
+typedef struct FlakeAmdStreaminfo {
+    unsigned int min_block_size, max_block_size;
+    unsigned int min_frame_size, max_frame_size;
+    unsigned int sample_rate, channels, bits_per_sample, samples;
+    unsigned char md5sum[16];
+} FlakeAmdStreaminfo;
+
+/* flake_set_defaults(), encode.c:158-266: params->compression must be set */
+FLAKE_AMD_API int flake_amd_set_defaults(FlakeAmdEncodeParams *params);
+/* flake_validate_params(), encode.c:268-373: -1 error, 0 ok, 1 ok but non-Subset */
+FLAKE_AMD_API int flake_amd_validate_params(const FlakeAmdContext *s);
+/* flake_encode_init(), encode.c:378-472: returns the header length (bytes in
+ * s->header) or a negative code.  The HIP device is FLAKE_AMD_DEVICE (default
+ * 0); up to FLAKE_AMD_BATCH (default 1024) blocks are encoded per GPU batch. */
+FLAKE_AMD_API int flake_amd_encode_init(FlakeAmdContext *s);
+/* flake_get_buffer(), encode.c:474-485: frame buffer of flake_amd_encode_frame */
+FLAKE_AMD_API void *flake_amd_get_buffer(const FlakeAmdContext *s);
+/* flake_encode_frame(), encode.c:979-1008: one block; bytes written or -1 */
+FLAKE_AMD_API int flake_amd_encode_frame(FlakeAmdContext *s, const int *samples, int block_size);
+/*
+ * Batched form of the same call: nblocks consecutive blocks of block_size
+ * samples per channel (interleaved), optionally followed by one shorter last
+ * block of tail_size samples (0 = none).  Frames are written back to back
+ * into out; frame_sizes (optional, [nblocks + (tail_size > 0)], VBS may write
+ * several FLAC frames per block -- their total is recorded per block) and the
+ * return value give byte counts.  Negative on error.
+ */
+FLAKE_AMD_API long long flake_amd_encode_frames(FlakeAmdContext *s, const int *samples,
+                                                int nblocks, int block_size, int tail_size,
+                                                unsigned char *out, size_t out_size,
+                                                int *frame_sizes);
+/* flake_encode_close(), encode.c:1010-1026 */
+FLAKE_AMD_API void flake_amd_encode_close(FlakeAmdContext *s);
+/* flake_get_streaminfo() / flake_write_streaminfo(), metadata.c:32-84 */
+FLAKE_AMD_API int flake_amd_get_streaminfo(const FlakeAmdContext *s, FlakeAmdStreaminfo *si);
+FLAKE_AMD_API void flake_amd_write_streaminfo(const FlakeAmdStreaminfo *si, unsigned char *data34);
+FLAKE_AMD_API const char *flake_amd_get_version(void);
+/* Text of the last error of this context ("" if none). */
+FLAKE_AMD_API const char *flake_amd_last_error(const FlakeAmdContext *s);
+
 /* Deterministic synthetic PCM, channel-interleaved int32 as
  * flake_encode_frame() expects: nframes blocks of n samples per channel,
  * starting at absolute frame index first_frame. */

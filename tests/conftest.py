@@ -25,3 +25,9 @@ def ref():
     if not oraclelib.Ref.available():
         pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
     return oraclelib.Ref()
+
+
+@pytest.fixture(scope="session")
+def decoder():
+    import oraclelib
+    return oraclelib.Decoder()

@@ -254,6 +254,33 @@ class Oracle:
         return self.L.fo_crc16(_p(d), len(d))
 
 
+DEC_SO = os.path.join(ORACLE_DIR, "libflac_decode.so")
+
+
+class Decoder:
+    """Independent FLAC frame decoder (oracle/flac_decode.c)."""
+
+    def __init__(self):
+        if _stale(DEC_SO, [os.path.join(ORACLE_DIR, "flac_decode.c")]):
+            subprocess.run(["make", "-C", ORACLE_DIR, "libflac_decode.so"], check=True,
+                           stdout=subprocess.DEVNULL)
+        self.L = C.CDLL(DEC_SO)
+        self.L.fd_decode_frames.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_size_t, C.POINTER(C.c_int), C.c_void_p, C.c_int]
+        self.L.fd_decode_frames.restype = C.c_long
+
+    def decode(self, data, channels, bps, max_sample_frames):
+        data = np.ascontiguousarray(data, np.uint8)
+        pcm = np.zeros((max_sample_frames, channels), np.int32)
+        nf = C.c_int(0)
+        sizes = np.zeros(65536, np.int32)
+        rc = self.L.fd_decode_frames(_p(data), len(data), channels, bps, _p(pcm), max_sample_frames,
+                                     C.byref(nf), _p(sizes), len(sizes))
+        if rc < 0:
+            raise ValueError(f"FLAC decode error {rc}")
+        return pcm[:rc], sizes[:nf.value].copy()
+
+
 class Ref:
     """The real reference functions (only where oracle/_ref was built)."""
 

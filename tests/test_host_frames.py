@@ -1,0 +1,149 @@
+"""The host C layer on top of the HIP ABI: complete FLAC frames.
+
+libflake's call sequence (flake_set_defaults -> validate -> encode_init ->
+encode_frame(s) -> close) through include/flake_amd.h.  The frames must equal
+the oracle's encode_frame()/encode_block() byte for byte, decode back to the
+input through the independent decoder, and the STREAMINFO MD5 must be the MD5 of
+the raw little-endian PCM (md5.c:281-320)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import flake_amd
+from cases import stereo_frames, _rng
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_stream(oracle, p, pcm, block_size, tail=0):
+    """What flake_encode_frame() would write for consecutive blocks (+ short tail)."""
+    ch = p.channels
+    nblocks = (pcm.shape[0] - tail) // block_size
+    out, sizes, fc = [], [], 0
+    for b in range(nblocks + (1 if tail else 0)):
+        n = block_size if b < nblocks else tail
+        blk = pcm[b * block_size: b * block_size + n]
+        rc, data, fc = oracle.encode_block(p, fc, blk, n, 8 * n * ch * 4 + 4096)
+        assert rc > 0
+        out.append(data)
+        sizes.append(rc)
+    return np.concatenate(out), np.array(sizes)
+
+
+def pcm_md5(pcm, bps):
+    nbytes = (bps + 7) // 8
+    raw = pcm.astype("<i4").reshape(-1).view(np.uint8).reshape(-1, 4)[:, :nbytes]
+    return hashlib.md5(raw.tobytes()).digest()
+
+
+@pytest.mark.parametrize("level", [0, 2, 5, 8])
+def test_levels_stream_equals_oracle(oracle, decoder, level):
+    with flake_amd.HostEncoder(level) as enc:
+        p = enc.params()
+        n = p.block_size
+        pcm = flake_amd.synth_pcm(9, n, 2, 16).reshape(-1, 2)
+        tail = n // 3
+        pcm = np.concatenate([pcm, flake_amd.synth_pcm(1, tail, 2, 16, first_frame=99)[0]])
+        data, sizes = enc.encode_frames(pcm, n, tail)
+        exp, esizes = oracle_stream(oracle, p, pcm, n, tail)
+        assert (sizes == esizes).all()
+        assert data.tobytes() == exp.tobytes()
+        out, bs = decoder.decode(data, 2, 16, pcm.shape[0])
+        assert (out == pcm).all() and bs[-1] == tail
+        si = enc.streaminfo()
+        assert bytes(si.md5sum) == pcm_md5(pcm, 16)
+        assert si.max_frame_size >= sizes.max()
+        assert enc.header[:4] == b"fLaC"
+
+
+@pytest.mark.parametrize("level", [9, 10, 12])
+def test_vbs_levels(oracle, decoder, level):
+    """vbs.c: blocks split into ragged frames; frame numbers count samples."""
+    with flake_amd.HostEncoder(level) as enc:
+        p = enc.params()
+        n = p.block_size
+        base = flake_amd.synth_pcm(6, n, 2, 16)
+        blocks = []
+        for b in range(6):
+            blk = base[b].copy()
+            if b % 2 == 0:                      # quiet first part, loud rest: forces a split
+                cut = (1 + b) * n // 8
+                blk[:cut] //= 64
+            blocks.append(blk)
+        pcm = np.concatenate(blocks)
+        data, sizes = enc.encode_frames(pcm, n)
+        exp, esizes = oracle_stream(oracle, p, pcm, n)
+        assert (sizes == esizes).all()
+        assert data.tobytes() == exp.tobytes()
+        out, bs = decoder.decode(data, 2, 16, pcm.shape[0])
+        assert (out == pcm).all()
+        assert len(bs) > 6 and (bs % (n // 8) == 0).all()
+
+
+def test_verbatim_fallback_and_constant(oracle, decoder):
+    r = _rng(4)
+    n = 4096
+    noise = r.randint(-32768, 32768, (n, 1)).astype(np.int32)
+    silence = np.zeros((n, 1), np.int32)
+    tone = flake_amd.synth_pcm(1, n, 1, 16)[0]
+    pcm = np.concatenate([noise, silence, tone])
+    with flake_amd.HostEncoder(5, channels=1) as enc:
+        data, sizes = enc.encode_frames(pcm, n)
+        exp, esizes = oracle_stream(oracle, enc.params(), pcm, n)
+        assert data.tobytes() == exp.tobytes()
+        assert sizes[0] == 16 + n * 2 - 5 or sizes[0] <= 16 + n * 2     # verbatim-sized
+        assert sizes[1] < 16                                            # CONSTANT subframe
+        out, _ = decoder.decode(data, 1, 16, 3 * n)
+        assert (out == pcm).all()
+
+
+def test_stereo_edge_frames_24bit(oracle, decoder):
+    fr = stereo_frames(4096, 24)
+    pcm = np.concatenate([fr[k] for k in sorted(fr)])
+    with flake_amd.HostEncoder(5, bits_per_sample=24, sample_rate=96000) as enc:
+        data, sizes = enc.encode_frames(pcm, 4096)
+        exp, _ = oracle_stream(oracle, enc.params(), pcm, 4096)
+        assert data.tobytes() == exp.tobytes()
+        out, _ = decoder.decode(data, 2, 24, pcm.shape[0])
+        assert (out == pcm).all()
+        assert bytes(enc.streaminfo().md5sum) == pcm_md5(pcm, 24)
+
+
+def test_eight_channels_192k(oracle, decoder):
+    """BASELINE configs[3]: 8 channels, 24 bit, 192 kHz (sample-rate code 12 + 8-bit kHz)."""
+    pcm = flake_amd.synth_pcm(3, 4096, 8, 24).reshape(-1, 8)
+    with flake_amd.HostEncoder(5, channels=8, bits_per_sample=24, sample_rate=192000,
+                               order_method=flake_amd.OM_MAX, max_prediction_order=12) as enc:
+        data, sizes = enc.encode_frames(pcm, 4096)
+        exp, _ = oracle_stream(oracle, enc.params(), pcm, 4096)
+        assert data.tobytes() == exp.tobytes()
+        out, _ = decoder.decode(data, 8, 24, pcm.shape[0])
+        assert (out == pcm).all()
+
+
+def test_single_frame_entry_and_last_block_latch(oracle):
+    """flake_encode_frame(): one block per call; a short block ends the stream
+    (encode.c:989-994)."""
+    with flake_amd.HostEncoder(5) as enc:
+        p = enc.params()
+        pcm = flake_amd.synth_pcm(3, 4096, 2, 16)
+        fc = 0
+        for b in range(2):
+            got = enc.encode_frame(pcm[b])
+            rc, exp, fc = oracle.encode_block(p, fc, pcm[b], 4096, 1 << 16)
+            assert got == exp.tobytes()
+        short = enc.encode_frame(pcm[2][:1000])
+        rc, exp, fc = oracle.encode_block(p, fc, pcm[2][:1000], 1000, 1 << 16)
+        assert short == exp.tobytes()
+        with pytest.raises(flake_amd.FlakeHipError):
+            enc.encode_frame(pcm[0])
+
+
+def test_invalid_parameters_are_rejected_on_the_host():
+    with pytest.raises(ValueError):
+        flake_amd.HostEncoder(5, channels=9)
+    with pytest.raises(ValueError):
+        flake_amd.HostEncoder(5, variable_block_size=1)          # needs allow_vbs
+    with pytest.raises(ValueError):
+        flake_amd.HostEncoder(13)

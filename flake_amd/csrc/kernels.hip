@@ -292,6 +292,77 @@ void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
     }
 }
 
+// K0 for 1 or 3..8 channels (no decorrelation, encode.c:660-663): one
+// workgroup per frame walks it in tiles of 256 sample-frames.  A tile is read
+// with coalesced dword loads, transposed through a padded LDS tile, and each
+// thread then owns one sample-frame with all its channels in registers.  Pass 1
+// ORs every sample per channel (wasted bits, encode.c:558-593), pass 2 re-reads
+// (L2), shifts and writes channel rows coalesced.
+__global__ __launch_bounds__(NT)
+void k_prepare_multi(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
+                     fhip_subframe_info *__restrict__ info, int n, int nch, int bps)
+{
+    __shared__ int32_t s_tile[NT * (FHIP_MAX_CH + 1)];
+    __shared__ uint32_t s_orr[4][FHIP_MAX_CH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = blockIdx.x;
+    const int32_t *src = pcm + (size_t)f * n * nch;
+    const int stride = nch + 1;
+    const int total = n * nch;
+
+    uint32_t orv[FHIP_MAX_CH];
+#pragma unroll
+    for (int c = 0; c < FHIP_MAX_CH; c++) orv[c] = 0;
+    int wasted[FHIP_MAX_CH];
+
+    for (int pass = 0; pass < 2; pass++) {
+        for (int t0 = 0; t0 < n; t0 += NT) {
+            const int base = t0 * nch;
+            __syncthreads();
+            for (int j = 0; j < nch; j++) {
+                const int e = base + j * NT + tid;               // linear element of the tile
+                const int le = j * NT + tid;
+                const int32_t v = src[min(e, total - 1)];
+                s_tile[(le / nch) * stride + (le % nch)] = v;
+            }
+            __syncthreads();
+            const int i = t0 + tid;
+#pragma unroll
+            for (int c = 0; c < FHIP_MAX_CH; c++) {
+                if (c < nch) {
+                    const int32_t v = s_tile[tid * stride + c];
+                    if (pass == 0) orv[c] |= (i < n) ? (uint32_t)v : 0u;
+                    else if (i < n) smp[((size_t)f * nch + c) * n + i] = v >> wasted[c];
+                }
+            }
+        }
+        if (pass == 0) {
+#pragma unroll
+            for (int c = 0; c < FHIP_MAX_CH; c++) {
+                const uint32_t o = wave_or_u32(orv[c]);
+                if (lane == 0) s_orr[wv][c] = o;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < FHIP_MAX_CH; c++) {
+                const uint32_t o = s_orr[0][c] | s_orr[1][c] | s_orr[2][c] | s_orr[3][c];
+                int w = o ? min(__ffs((int)o) - 1, bps - 1) : bps - 1;
+                if (w == bps - 1) w = 0;
+                wasted[c] = w;
+            }
+            if (tid < nch) {
+                fhip_subframe_info *oi = &info[(size_t)f * nch + tid];
+                const uint32_t o = s_orr[0][tid] | s_orr[1][tid] | s_orr[2][tid] | s_orr[3][tid];
+                int w = o ? min(__ffs((int)o) - 1, bps - 1) : bps - 1;
+                if (w == bps - 1) w = 0;
+                oi->obits = bps - w;
+                oi->wasted = w;
+                oi->ch_mode = FHIP_CH_NOT_STEREO;
+            }
+        }
+    }
+}
+
 // K0 fast path for stereo frames with n % 4 == 0 and n <= 4096: the frame never
 // touches LDS.  Thread t owns the sample-frame quads 4(t + 256m) .. +3,
 // m < M: two 16-byte loads per quad (coalesced 32 B per lane), both channels
@@ -1990,7 +2061,12 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
             hipLaunchKernelGGL(k_prepare_stereo<4>, dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est);
         return hipGetLastError();
     }
-    const int blocks = (nch == 2) ? nframes : nframes * nch;
+    if (nch != 2) {
+        hipLaunchKernelGGL(k_prepare_multi, dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, nch,
+                           p.bits_per_sample);
+        return hipGetLastError();
+    }
+    const int blocks = nframes;
     const size_t lds = sizeof(int32_t) * (size_t)n * (nch == 2 ? 2 : 1);
     if (blocks == 0) return hipSuccess;
     if (lds > 160 * 1024) return hipErrorInvalidValue;

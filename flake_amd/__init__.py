@@ -113,6 +113,8 @@ class Batch(C.Structure):
         ("pcm", C.c_void_p), ("nframes", C.c_int), ("block_size", C.c_int),
         ("info", C.c_void_p), ("residual", C.c_void_p), ("rice_bits", C.c_void_p),
         ("rice_slot_bytes", C.c_int64), ("samples", C.c_void_p), ("autoc", C.c_void_p),
+        ("frames", C.c_void_p), ("frame_stride", C.c_int64), ("frame_bytes", C.c_void_p),
+        ("first_frame_number", C.c_uint32), ("frame_numbers", C.c_void_p),
     ]
 
 
@@ -139,6 +141,7 @@ def load_library() -> C.CDLL:
     vp, i, i64 = C.c_void_p, C.c_int, C.c_int64
     sig = {
         "fhip_device_count": (i, []),
+        "fhip_frame_stride": (i64, [C.POINTER(Params), i]),
         "fhip_create": (i, [C.POINTER(vp), i, C.POINTER(Params), i]),
         "fhip_destroy": (None, [vp]),
         "fhip_set_stream": (i, [vp, vp]),
@@ -165,7 +168,7 @@ def load_library() -> C.CDLL:
 
 
 ABI_SYMBOLS = (
-    "fhip_device_count", "fhip_create", "fhip_destroy", "fhip_set_stream", "fhip_sync",
+    "fhip_frame_stride", "fhip_device_count", "fhip_create", "fhip_destroy", "fhip_set_stream", "fhip_sync",
     "fhip_strerror", "fhip_last_error", "fhip_version", "fhip_encode_subframes_dev",
     "fhip_encode_subframes", "fhip_lpc_calc_coefs", "fhip_encode_residual",
     "fhip_prepare_frames", "fhip_calc_rice_params", "fhip_set_profiling",
@@ -246,17 +249,24 @@ class Encoder:
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(k)}
 
     # -- hot path ---------------------------------------------------------
+    def frame_stride(self, block_size: int) -> int:
+        return int(self.lib.fhip_frame_stride(C.byref(self.params), block_size))
+
     def encode_subframes_dev(self, pcm, nframes: int, block_size: int, info, residual=None,
-                             rice_bits=None, slot_bytes: int = 0, samples=None, autoc=None) -> None:
+                             rice_bits=None, slot_bytes: int = 0, samples=None, autoc=None,
+                             frames=None, frame_stride: int = 0, frame_bytes=None,
+                             first_frame_number: int = 0) -> None:
         """Device-resident batch (torch tensors or raw device addresses); async."""
         b = Batch(_ptr(pcm), nframes, block_size, _ptr(info), _ptr(residual), _ptr(rice_bits),
-                  slot_bytes, _ptr(samples), _ptr(autoc))
+                  slot_bytes, _ptr(samples), _ptr(autoc), _ptr(frames), frame_stride,
+                  _ptr(frame_bytes), first_frame_number, None)
         self._check(self.lib.fhip_encode_subframes_dev(self._h, C.byref(b)),
                     "fhip_encode_subframes_dev")
 
     def encode_subframes(self, pcm: np.ndarray, block_size: int, want_residual: bool = True,
                          want_bits: bool = True, want_samples: bool = False,
-                         want_autoc: bool = False) -> dict:
+                         want_autoc: bool = False, want_frames: bool = False,
+                         first_frame_number: int = 0) -> dict:
         """Host numpy batch: pcm is [nframes][block_size][channels] int32."""
         ch = self.params.channels
         pcm = np.ascontiguousarray(pcm, dtype=np.int32).reshape(-1, block_size, ch)
@@ -272,9 +282,15 @@ class Encoder:
             out["samples"] = np.zeros((nframes, ch, block_size), dtype=np.int32)
         if want_autoc:
             out["autoc"] = np.zeros((nsub, MAX_LAGS), dtype=np.float64)
+        stride = 0
+        if want_frames:
+            stride = self.frame_stride(block_size)
+            out["frames"] = np.zeros((nframes, stride), dtype=np.uint8)
+            out["frame_bytes"] = np.zeros(nframes, dtype=np.int32)
         b = Batch(_ptr(pcm), nframes, block_size, _ptr(out["info"]), _ptr(out.get("residual")),
                   _ptr(out.get("rice_bits")), slot, _ptr(out.get("samples")),
-                  _ptr(out.get("autoc")))
+                  _ptr(out.get("autoc")), _ptr(out.get("frames")), stride,
+                  _ptr(out.get("frame_bytes")), first_frame_number, None)
         self._check(self.lib.fhip_encode_subframes(self._h, C.byref(b)), "fhip_encode_subframes")
         out["slot_bytes"] = slot
         return out

@@ -33,6 +33,10 @@ struct fhip_ctx {
     int32_t *d_res = nullptr;
     uint8_t *d_bits = nullptr;
     size_t d_bits_bytes = 0;
+    uint8_t *d_frames = nullptr;
+    size_t d_frames_bytes = 0;
+    int32_t *d_fbytes = nullptr;
+    uint32_t *d_fnum = nullptr;
 
     // two internal streams for the split-batch overlap (run_pipeline)
     hipStream_t aux[2] = {nullptr, nullptr};
@@ -51,7 +55,7 @@ struct fhip_ctx {
 
 namespace {
 
-const char *const kKernelNames[4] = {"k_prepare", "k_autocorr", "k_lpc", "k_encode"};
+const char *const kKernelNames[5] = {"k_prepare", "k_autocorr", "k_lpc", "k_encode", "k_assemble"};
 
 int fail_hip(fhip_ctx *c, hipError_t e, const char *what)
 {
@@ -149,9 +153,12 @@ void drain_profile(fhip_ctx *c)
 
 // The four launches of one range of frames.  All pointers are device pointers
 // and already offset to the range; `prof` brackets each launch with events.
+struct FrameOut { uint8_t *frames; int64_t stride; int32_t *bytes; uint32_t first; const uint32_t *numbers = nullptr; };
+
 static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm, int nframes, int n,
                      fhip_subframe_info *info, int32_t *residual, uint8_t *bits,
-                     int64_t slot_bytes, int32_t *smp, double *autoc, size_t sub0)
+                     int64_t slot_bytes, int32_t *smp, double *autoc, size_t sub0,
+                     const FrameOut &fo)
 {
     const fhip_params &p = c->p;
     const int nsub = nframes * p.channels;
@@ -185,6 +192,12 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
         HIP_TRY(c, fhip::launch_encode(st, p, smp, nsub, n, coefs, shift, opt, fin, info, residual,
                                        bits, slot_bytes));
     }
+    if (fo.frames) {
+        MaybeProf pr(c, prof, 4);
+        const uint32_t step = p.allow_vbs ? (uint32_t)n : 1u;
+        HIP_TRY(c, fhip::launch_assemble(st, p, pcm, nframes, n, info, bits, slot_bytes, fo.frames,
+                                         fo.stride, fo.bytes, fo.first, step, fo.numbers));
+    }
     return FHIP_OK;
 }
 
@@ -196,7 +209,8 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
 // default.
 int run_pipeline(fhip_ctx *c, const int32_t *pcm, int nframes, int n,
                  fhip_subframe_info *info, int32_t *residual, uint8_t *bits,
-                 int64_t slot_bytes, int32_t *samples_out, double *autoc_out)
+                 int64_t slot_bytes, int32_t *samples_out, double *autoc_out,
+                 const FrameOut &fo = FrameOut{nullptr, 0, nullptr, 0})
 {
     const fhip_params &p = c->p;
     int32_t *smp = samples_out ? samples_out : c->d_smp;
@@ -205,7 +219,7 @@ int run_pipeline(fhip_ctx *c, const int32_t *pcm, int nframes, int n,
     const bool split = !c->profiling && c->overlap && nframes >= 512 && c->aux[0] && c->aux[1];
     if (!split)
         return run_range(c, c->stream, c->profiling, pcm, nframes, n, info, residual, bits,
-                         slot_bytes, smp, autoc, 0);
+                         slot_bytes, smp, autoc, 0, fo);
 
     HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
     const int parts[3] = {0, nframes / 2, nframes};
@@ -216,7 +230,11 @@ int run_pipeline(fhip_ctx *c, const int32_t *pcm, int nframes, int n,
         int rc = run_range(c, c->aux[h], false, pcm + f0 * n * nch, (int)nf, n, info + sub0,
                            residual ? residual + sub0 * n : nullptr,
                            bits ? bits + sub0 * (size_t)slot_bytes : nullptr, slot_bytes,
-                           smp + sub0 * n, autoc + sub0 * FHIP_MAX_LAGS, sub0);
+                           smp + sub0 * n, autoc + sub0 * FHIP_MAX_LAGS, sub0,
+                           FrameOut{fo.frames ? fo.frames + f0 * (size_t)fo.stride : nullptr, fo.stride,
+                                    fo.bytes ? fo.bytes + f0 : nullptr,
+                                    fo.first + (uint32_t)f0 * (p.allow_vbs ? (uint32_t)n : 1u),
+                                    fo.numbers ? fo.numbers + f0 : nullptr});
         if (rc != FHIP_OK) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_join[h], c->aux[h]));
     }
@@ -235,12 +253,27 @@ int check_batch(fhip_ctx *c, const fhip_batch *b)
         return fail(c, FHIP_E_UNSUPPORTED, "block_size above FHIP_MAX_BLOCK");
     if (b->rice_bits && (b->rice_slot_bytes < 4 || (b->rice_slot_bytes & 3)))
         return fail(c, FHIP_E_INVALID, "rice_slot_bytes must be a positive multiple of 4");
+    if (b->frames) {
+        if (!b->rice_bits || !b->frame_bytes)
+            return fail(c, FHIP_E_INVALID, "frames need rice_bits and frame_bytes");
+        if ((b->frame_stride & 3) || b->frame_stride < fhip_frame_stride(&c->p, b->block_size))
+            return fail(c, FHIP_E_INVALID, "frame_stride too small or not a multiple of 4");
+    }
     return FHIP_OK;
 }
 
 }  // namespace
 
 extern "C" {
+
+int64_t fhip_frame_stride(const fhip_params *p, int block_size)
+{
+    if (!p || block_size < 1) return 0;
+    const int64_t bps = p->bits_per_sample, n = block_size;
+    const int64_t v = (p->channels == 2) ? 16 + ((n * (bps + bps + 1) + 7) >> 3)
+                                         : 16 + ((n * p->channels * bps + 7) >> 3);
+    return (v + 8 + 3) & ~(int64_t)3;
+}
 
 int fhip_device_count(void)
 {
@@ -286,7 +319,7 @@ int fhip_create(fhip_ctx **out, int device, const fhip_params *p, int max_frames
     c->device = device;
     c->p = *p;
     c->max_frames = max_frames;
-    for (int i = 0; i < 4; i++) c->ktimes.push_back({kKernelNames[i], 0.0, 0});
+    for (int i = 0; i < 5; i++) c->ktimes.push_back({kKernelNames[i], 0.0, 0});
 
     const size_t nsub = (size_t)max_frames * p->channels;
     const size_t n = (size_t)p->block_size;
@@ -327,7 +360,7 @@ void fhip_destroy(fhip_ctx *c)
     drain_profile(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     void *bufs[] = {c->d_smp, c->d_autoc, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
-                    c->d_pcm, c->d_info, c->d_res, c->d_bits};
+                    c->d_pcm, c->d_info, c->d_res, c->d_bits, c->d_frames, c->d_fbytes, c->d_fnum};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int h = 0; h < 2; h++) {
         if (c->aux[h]) { (void)hipStreamSynchronize(c->aux[h]); (void)hipStreamDestroy(c->aux[h]); }
@@ -383,7 +416,9 @@ int fhip_encode_subframes_dev(fhip_ctx *c, const fhip_batch *b)
     if (rc != FHIP_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     return run_pipeline(c, b->pcm, b->nframes, b->block_size, b->info, b->residual,
-                        b->rice_bits, b->rice_slot_bytes, b->samples, b->autoc);
+                        b->rice_bits, b->rice_slot_bytes, b->samples, b->autoc,
+                        FrameOut{b->frames, b->frame_stride, b->frame_bytes, b->first_frame_number,
+                                 b->frame_numbers});
 }
 
 // Lazily sized staging buffers for the host-pointer entry points.
@@ -420,9 +455,26 @@ int fhip_encode_subframes(fhip_ctx *c, const fhip_batch *b)
     HIP_TRY(c, hipMemcpyAsync(c->d_pcm, b->pcm, nsub * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_info, 0, nsub * sizeof(fhip_subframe_info), c->stream));
     if (bits_bytes) HIP_TRY(c, hipMemsetAsync(c->d_bits, 0, bits_bytes, c->stream));
+    FrameOut fo{nullptr, 0, nullptr, 0};
+    if (b->frames) {
+        const size_t fb = (size_t)b->nframes * (size_t)b->frame_stride;
+        if (fb > c->d_frames_bytes) {
+            if (c->d_frames) (void)hipFree(c->d_frames);
+            c->d_frames = nullptr; c->d_frames_bytes = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_frames, fb));
+            c->d_frames_bytes = fb;
+        }
+        if (!c->d_fbytes) HIP_TRY(c, hipMalloc((void **)&c->d_fbytes, (size_t)c->max_frames * sizeof(int32_t)));
+        fo = FrameOut{c->d_frames, b->frame_stride, c->d_fbytes, b->first_frame_number, nullptr};
+        if (b->frame_numbers) {
+            if (!c->d_fnum) HIP_TRY(c, hipMalloc((void **)&c->d_fnum, (size_t)c->max_frames * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemcpyAsync(c->d_fnum, b->frame_numbers, (size_t)b->nframes * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            fo.numbers = c->d_fnum;
+        }
+    }
     rc = run_pipeline(c, c->d_pcm, b->nframes, b->block_size, c->d_info,
                       b->residual ? c->d_res : nullptr, b->rice_bits ? c->d_bits : nullptr,
-                      b->rice_slot_bytes, nullptr, d_autoc_out);
+                      b->rice_slot_bytes, nullptr, d_autoc_out, fo);
     if (rc != FHIP_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(b->info, c->d_info, nsub * sizeof(fhip_subframe_info), hipMemcpyDeviceToHost, c->stream));
     if (b->residual)
@@ -431,6 +483,10 @@ int fhip_encode_subframes(fhip_ctx *c, const fhip_batch *b)
         HIP_TRY(c, hipMemcpyAsync(b->rice_bits, c->d_bits, bits_bytes, hipMemcpyDeviceToHost, c->stream));
     if (b->samples)
         HIP_TRY(c, hipMemcpyAsync(b->samples, c->d_smp, nsub * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (b->frames) {
+        HIP_TRY(c, hipMemcpyAsync(b->frames, c->d_frames, (size_t)b->nframes * (size_t)b->frame_stride, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(b->frame_bytes, c->d_fbytes, (size_t)b->nframes * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    }
     if (b->autoc)
         HIP_TRY(c, hipMemcpyAsync(b->autoc, c->d_autoc, nsub * FHIP_MAX_LAGS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     return fhip_sync(c);

@@ -44,6 +44,14 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
                          int32_t *residual, uint8_t *bits, int64_t slot_bytes,
                          int raw_order = -1, int raw_lpc = 0);
 
+// K4: whole frames on the device (encode.c:718-764, :800-917, :949-964):
+// frames [nframes][frame_stride] bytes, frame_bytes [nframes].
+hipError_t launch_assemble(hipStream_t st, const fhip_params &p, const int32_t *pcm, int nframes,
+                           int n, const fhip_subframe_info *info, const uint8_t *rice,
+                           int64_t slot_bytes, uint8_t *frames, int64_t frame_stride,
+                           int32_t *frame_bytes, uint32_t number_base, uint32_t number_step,
+                           const uint32_t *numbers = nullptr);
+
 // Dynamic-LDS need of K3 for a block size (0 if unsupported).
 size_t encode_lds_bytes(int n);
 

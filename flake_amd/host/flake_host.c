@@ -37,6 +37,7 @@ typedef struct host_ctx {
     int max_frame_size;
     uint32_t frame_count;
     int last_frame;
+    int host_assembly;                    /* FLAKE_AMD_HOST_ASSEMBLY=1: build frames on the CPU */
     fa_md5 md5;
     /* single-frame buffer of flake_amd_encode_frame */
     uint8_t *frame_buffer;
@@ -45,6 +46,10 @@ typedef struct host_ctx {
     fhip_subframe_info *info;
     uint8_t *bits;
     int64_t slot;
+    uint8_t *frames;                      /* device-assembled frames of the last GPU launches */
+    int64_t fstride;
+    int32_t *fbytes;
+    uint32_t *fnum;
     int32_t *gather;                      /* ragged VBS batches, contiguous per size */
     char err[256];
 } host_ctx;
@@ -96,9 +101,10 @@ static void sink_init(sink *s, uint8_t *buf, size_t cap)
     s->buf = buf; s->cap = cap; s->pos = 0; s->acc = 0; s->nacc = 0; s->over = 0;
 }
 
-static void sink_put(sink *s, int nb, uint32_t v)      /* nb <= 32 */
+static void sink_put(sink *s, int nb, uint32_t v)      /* wider than 32: zero-extended */
 {
     if (nb == 0) return;
+    if (nb > 32) { sink_put(s, nb - 32, 0); nb = 32; }
     s->acc = (s->acc << nb) | (uint64_t)(nb == 32 ? v : (v & ((1u << nb) - 1u)));
     s->nacc += nb;
     while (s->nacc >= 8) {
@@ -330,6 +336,8 @@ FLAKE_AMD_API int flake_amd_encode_init(FlakeAmdContext *s)
     fa_md5_init(&c->md5);
 
     const char *eb = getenv("FLAKE_AMD_BATCH"), *ed = getenv("FLAKE_AMD_DEVICE");
+    const char *eh = getenv("FLAKE_AMD_HOST_ASSEMBLY");
+    c->host_assembly = eh && eh[0] == '1';
     c->max_batch = eb ? atoi(eb) : 1024;
     if (c->max_batch < 1) c->max_batch = 1;
     /* a VBS block may turn into up to 8 frames of the smallest size */
@@ -346,8 +354,13 @@ FLAKE_AMD_API int flake_amd_encode_init(FlakeAmdContext *s)
     c->bits = (uint8_t *)malloc(nsub * (size_t)c->slot);
     c->gather = (int32_t *)malloc(sizeof(int32_t) * (size_t)c->max_batch *
                                   (size_t)s->params.block_size * (size_t)s->channels);
+    c->fstride = fhip_frame_stride(hp, s->params.block_size);
+    c->frames = (uint8_t *)malloc((size_t)max_frames * (size_t)c->fstride);
+    c->fbytes = (int32_t *)malloc(sizeof(int32_t) * (size_t)max_frames);
+    c->fnum = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)max_frames);
     s->header = (unsigned char *)calloc((size_t)s->params.padding_size + 1024, 1);
-    if (!c->frame_buffer || !c->info || !c->bits || !c->gather || !s->header) {
+    if (!c->frame_buffer || !c->info || !c->bits || !c->gather || !s->header || !c->frames ||
+        !c->fbytes || !c->fnum) {
         flake_amd_encode_close(s);
         return -1;
     }
@@ -366,6 +379,7 @@ FLAKE_AMD_API void flake_amd_encode_close(FlakeAmdContext *s)
     if (c) {
         if (c->hip) fhip_destroy(c->hip);
         free(c->frame_buffer); free(c->info); free(c->bits); free(c->gather);
+        free(c->frames); free(c->fbytes); free(c->fnum);
         free(c);
     }
     free(s->header);
@@ -525,7 +539,8 @@ static int vbs_split(const int32_t *pcm, int channels, int block_size, int sizes
 /* ------------------------------------------------------------------ */
 typedef struct { const int32_t *pcm; int n; int block; } piece;       /* one FLAC frame to make */
 
-static int run_gpu(host_ctx *c, const int32_t *pcm, int nframes, int n, size_t first_sub)
+static int run_gpu(host_ctx *c, const int32_t *pcm, int nframes, int n, size_t first_sub,
+                   size_t first_frame)
 {
     fhip_batch b;
     memset(&b, 0, sizeof b);
@@ -533,6 +548,11 @@ static int run_gpu(host_ctx *c, const int32_t *pcm, int nframes, int n, size_t f
     b.info = c->info + first_sub;
     b.rice_bits = c->bits + first_sub * (size_t)c->slot;
     b.rice_slot_bytes = c->slot;
+    /* whole frames come back assembled (K4); numbers were filled by the caller */
+    b.frames = c->frames + first_frame * (size_t)c->fstride;
+    b.frame_stride = c->fstride;
+    b.frame_bytes = c->fbytes + first_frame;
+    b.frame_numbers = c->fnum + first_frame;
     int rc = fhip_encode_subframes(c->hip, &b);
     if (rc != FHIP_OK)
         snprintf(c->err, sizeof c->err, "fhip_encode_subframes: %s (%s)", fhip_strerror(rc),
@@ -572,7 +592,13 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
     long long total = -1;
     int *slot_of = (int *)malloc(sizeof(int) * (size_t)np);
     char *done = (char *)calloc((size_t)np, 1);
-    if (!slot_of || !done) goto out;
+    uint32_t *num_of = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)np);
+    if (!slot_of || !done || !num_of) goto out;
+    {
+        /* frame numbers in stream order (encode.c:969-975) */
+        uint32_t fc = c->frame_count;
+        for (int i = 0; i < np; i++) { num_of[i] = fc; fc += s->params.allow_vbs ? (uint32_t)pieces[i].n : 1u; }
+    }
     {
         int next_slot = 0;
         for (int i = 0; i < np; i++) {
@@ -596,7 +622,15 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
                 }
                 src = c->gather;
             }
-            if (run_gpu(c, src, cnt, n, (size_t)next_slot * nch) != FHIP_OK) goto out;
+            {
+                int k = 0;
+                for (int j = i; j < np; j++) {
+                    if (done[j] || pieces[j].n != n) continue;
+                    c->fnum[next_slot + k] = num_of[j];
+                    k++;
+                }
+            }
+            if (run_gpu(c, src, cnt, n, (size_t)next_slot * nch, (size_t)next_slot) != FHIP_OK) goto out;
             int k = 0;
             for (int j = i; j < np; j++) {
                 if (done[j] || pieces[j].n != n) continue;
@@ -612,10 +646,18 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
         size_t pos = 0;
         int cur_block = -1;
         for (int i = 0; i < np; i++) {
-            const size_t sub = (size_t)slot_of[i] * nch;
-            const int fs = assemble_frame(c, c->frame_count, pieces[i].pcm, pieces[i].n,
-                                          c->info + sub, c->bits + sub * (size_t)c->slot,
-                                          out + pos, cap - pos, scratch);
+            int fs;
+            if (c->host_assembly) {
+                const size_t sub = (size_t)slot_of[i] * nch;
+                fs = assemble_frame(c, c->frame_count, pieces[i].pcm, pieces[i].n,
+                                    c->info + sub, c->bits + sub * (size_t)c->slot,
+                                    out + pos, cap - pos, scratch);
+            } else {
+                fs = c->fbytes[slot_of[i]];
+                if (fs > 0 && (size_t)fs <= cap - pos)
+                    memcpy(out + pos, c->frames + (size_t)slot_of[i] * (size_t)c->fstride, (size_t)fs);
+                else fs = -1;
+            }
             if (fs < 0) { snprintf(c->err, sizeof c->err, "output buffer too small"); goto out; }
             if (fs > c->max_frame_size) c->max_frame_size = fs;    /* encode.c:967 */
             c->frame_count += s->params.allow_vbs ? (uint32_t)pieces[i].n : 1u;   /* encode.c:969-975 */
@@ -629,7 +671,7 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
     }
     fa_md5_pcm(&c->md5, pcm, (size_t)count * bstride, c->hp.bits_per_sample);   /* encode.c:1006 */
 out:
-    free(pieces); free(scratch); free(slot_of); free(done);
+    free(pieces); free(scratch); free(slot_of); free(done); free(num_of);
     return total;
 }
 

@@ -155,7 +155,22 @@ typedef struct fhip_batch {
     int32_t            *samples;      /* [nframes][channels][block_size] FlacSubframe.samples
                                          after decorrelation and wasted-bits removal */
     double             *autoc;        /* [nframes*channels][FHIP_MAX_LAGS] compute_autocorr */
+    /* whole frames assembled on the device (optional; needs rice_bits):
+     * frame header + CRC-8, subframes, CRC-16 and the verbatim fallback,
+     * encode.c:718-764, :800-917, :949-964 */
+    uint8_t            *frames;       /* [nframes][frame_stride] */
+    int64_t             frame_stride; /* multiple of 4, >= fhip_frame_stride() */
+    int32_t            *frame_bytes;  /* [nframes] bytes written per frame */
+    uint32_t            first_frame_number;   /* FlacEncodeContext.frame_count of frame 0; frame f
+                                                 carries first + f (or first + f*block_size when
+                                                 allow_vbs: encode.c:969-975) */
+    const uint32_t     *frame_numbers;        /* optional [nframes]: explicit number per frame
+                                                 (ragged VBS batches); overrides the rule above */
 } fhip_batch;
+
+/* Bytes per frame slot that hold any frame of block_size samples: its verbatim
+ * size (encode.c:521-527) plus alignment slack. */
+FHIP_API int64_t fhip_frame_stride(const fhip_params *p, int block_size);
 
 FHIP_API int fhip_encode_subframes_dev(fhip_ctx *ctx, const fhip_batch *b);
 

@@ -32,7 +32,7 @@ def test_host_library_symbols():
 def test_struct_layouts_match_header():
     assert C.sizeof(flake_amd.Params) == 14 * 4
     assert flake_amd.INFO_DTYPE.itemsize == 4 * (12 + 32 + 256 + 32)
-    assert C.sizeof(flake_amd.Batch) == 8 + 4 + 4 + 8 * 3 + 8 + 8 * 2
+    assert C.sizeof(flake_amd.Batch) == 8 + 4 + 4 + 8 * 3 + 8 + 8 * 2 + 8 + 8 + 8 + 8 + 8
 
 
 def test_strerror_and_version():

@@ -155,6 +155,7 @@ def load_library() -> C.CDLL:
         "fhip_encode_residual": (i, [vp, vp, i, i, vp, vp, vp, i64]),
         "fhip_prepare_frames": (i, [vp, vp, i, i, vp, vp]),
         "fhip_calc_rice_params": (i, [vp, vp, i, i, i, i, i, i, i, vp, vp, i64]),
+        "fhip_vbs_split": (i, [vp, vp, i, i, vp, vp]),
         "fhip_set_profiling": (i, [vp, i]),
         "fhip_get_kernel_times": (i, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                       C.POINTER(i), i, i]),
@@ -171,7 +172,7 @@ ABI_SYMBOLS = (
     "fhip_frame_stride", "fhip_device_count", "fhip_create", "fhip_destroy", "fhip_set_stream", "fhip_sync",
     "fhip_strerror", "fhip_last_error", "fhip_version", "fhip_encode_subframes_dev",
     "fhip_encode_subframes", "fhip_lpc_calc_coefs", "fhip_encode_residual",
-    "fhip_prepare_frames", "fhip_calc_rice_params", "fhip_set_profiling",
+    "fhip_prepare_frames", "fhip_calc_rice_params", "fhip_vbs_split", "fhip_set_profiling",
     "fhip_get_kernel_times",
 )
 
@@ -334,6 +335,17 @@ class Encoder:
             self._h, _ptr(residual), nsub, n, pred_order, int(lpc), bps, pmin, pmax,
             _ptr(info), _ptr(bits), slot_bytes), "fhip_calc_rice_params")
         return {"info": info, "rice_bits": bits}
+
+    def vbs_split(self, pcm: np.ndarray, block_size: int):
+        """split_frame_v1 (vbs.c:36-83) over [nblocks][block_size][channels] blocks."""
+        ch = self.params.channels
+        pcm = np.ascontiguousarray(pcm, dtype=np.int32).reshape(-1, block_size, ch)
+        nb = pcm.shape[0]
+        frames = np.zeros(nb, dtype=np.int32)
+        sizes = np.zeros((nb, 8), dtype=np.int32)
+        self._check(self.lib.fhip_vbs_split(self._h, _ptr(pcm), nb, block_size, _ptr(frames),
+                                            _ptr(sizes)), "fhip_vbs_split")
+        return frames, sizes
 
     def prepare_frames(self, pcm: np.ndarray, block_size: int):
         """copy_samples + channel_decorrelation + remove_wasted_bits (encode.c:541-694)."""

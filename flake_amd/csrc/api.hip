@@ -577,6 +577,27 @@ int fhip_encode_residual(fhip_ctx *c, const int32_t *samples, int nsub, int n,
     return fhip_sync(c);
 }
 
+int fhip_vbs_split(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size,
+                   int32_t *frames, int32_t *sizes)
+{
+    if (!c || !pcm || !frames || !sizes) return fail(c, FHIP_E_INVALID, "null argument");
+    if (nblocks < 0 || nblocks > c->max_frames || block_size > c->p.block_size ||
+        block_size < 128 || (block_size % 8))
+        return fail(c, FHIP_E_INVALID, "vbs needs block_size % 8 == 0 and >= 128 (vbs.c:93)");
+    if (nblocks == 0) return FHIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c, 0);
+    if (rc != FHIP_OK) return rc;
+    const size_t nvals = (size_t)nblocks * block_size * c->p.channels;
+    // d_opt (>= max_frames ints) and d_shift (>= 32*max_frames ints) are free before K2 runs
+    HIP_TRY(c, hipMemcpyAsync(c->d_pcm, pcm, nvals * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, fhip::launch_vbs_split(c->stream, c->d_pcm, nblocks, block_size, c->p.channels,
+                                      c->d_opt, c->d_shift));
+    HIP_TRY(c, hipMemcpyAsync(frames, c->d_opt, (size_t)nblocks * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(sizes, c->d_shift, (size_t)nblocks * 8 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    return fhip_sync(c);
+}
+
 int fhip_calc_rice_params(fhip_ctx *c, const int32_t *residual, int nsub, int n,
                           int pred_order, int lpc, int bps, int pmin, int pmax,
                           fhip_subframe_info *info, uint8_t *rice_bits, int64_t rice_slot_bytes)

@@ -52,6 +52,11 @@ hipError_t launch_assemble(hipStream_t st, const fhip_params &p, const int32_t *
                            int32_t *frame_bytes, uint32_t number_base, uint32_t number_step,
                            const uint32_t *numbers = nullptr);
 
+// K-vbs: split_frame_v1 (vbs.c:36-83) for nblocks blocks: nframes_out [nblocks],
+// sizes_out [nblocks][8].
+hipError_t launch_vbs_split(hipStream_t st, const int32_t *pcm, int nblocks, int block_size,
+                            int nch, int32_t *nframes_out, int32_t *sizes_out);
+
 // Dynamic-LDS need of K3 for a block size (0 if unsupported).
 size_t encode_lds_bytes(int n);
 

@@ -2355,6 +2355,58 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// K-vbs  k_vbs_split -- vbs.c:36-83 split_frame_v1
+// ---------------------------------------------------------------------------
+// One workgroup per block: eight sections of n/8 sample-frames, for each the
+// sum over channels of |x[j] - 2x[j-1] + x[j-2]| on the raw interleaved input
+// (int32 wrap, then abs), divided by the channel count, plus one; neighbours
+// are merged unless the score changes by more than 25 % -- evaluated with the
+// reference's int abs() and 32-bit multiply.
+__global__ __launch_bounds__(NT)
+void k_vbs_split(const int32_t *__restrict__ pcm, int nblocks, int block_size, int nch,
+                 int32_t *__restrict__ nframes_out, int32_t *__restrict__ sizes_out)
+{
+    __shared__ long long s_score[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.x;
+    const int n = block_size / 8;
+    const int32_t *base = pcm + (size_t)b * block_size * nch;
+    for (int sec = wv; sec < 8; sec += 4) {
+        const int32_t *sp = base + (size_t)sec * n * nch;
+        long long acc = 0;
+        // element e of the section = (j, ch) interleaved; rows j >= 2 only
+        const int total = (n - 2) * nch;
+        for (int e = lane; e < total; e += WAVE) {
+            const int idx = e + 2 * nch;
+            const uint32_t x0 = (uint32_t)sp[idx], x1 = (uint32_t)sp[idx - nch], x2 = (uint32_t)sp[idx - 2 * nch];
+            const int32_t d = (int32_t)(x0 - 2u * x1 + x2);
+            acc += (long long)wrap_abs(d);
+        }
+        acc = (long long)wave_sum_u64((unsigned long long)acc);
+        if (lane == 0) s_score[sec] = acc / nch + 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int sizes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int nf = 0;
+        for (int p = 0; p < 8; p++) {
+            bool cut = (p == 0);
+            if (p > 0) {
+                int32_t diff = (int32_t)(uint32_t)(unsigned long long)(s_score[p - 1] - s_score[p]);
+                diff = wrap_abs(diff);
+                const int32_t scaled = (int32_t)((uint32_t)diff * 200u);
+                cut = ((long long)scaled / s_score[p - 1]) > 50;
+            }
+            if (cut) nf++;
+            sizes[nf - 1] += n;
+        }
+        nframes_out[b] = nf;
+        for (int p = 0; p < 8; p++) sizes_out[(size_t)b * 8 + p] = sizes[p];
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -2495,6 +2547,15 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
     else if (chunk <= 32) LAUNCH_ENC(32);
     else LAUNCH_ENC(64);
 #undef LAUNCH_ENC
+    return hipGetLastError();
+}
+
+hipError_t launch_vbs_split(hipStream_t st, const int32_t *pcm, int nblocks, int block_size,
+                            int nch, int32_t *nframes_out, int32_t *sizes_out)
+{
+    if (nblocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_vbs_split, dim3(nblocks), dim3(NT), 0, st, pcm, nblocks, block_size, nch,
+                       nframes_out, sizes_out);
     return hipGetLastError();
 }
 

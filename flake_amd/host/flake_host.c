@@ -38,6 +38,7 @@ typedef struct host_ctx {
     uint32_t frame_count;
     int last_frame;
     int host_assembly;                    /* FLAKE_AMD_HOST_ASSEMBLY=1: build frames on the CPU */
+    int host_vbs;                         /* FLAKE_AMD_HOST_VBS=1: split blocks on the CPU */
     fa_md5 md5;
     /* single-frame buffer of flake_amd_encode_frame */
     uint8_t *frame_buffer;
@@ -338,6 +339,7 @@ FLAKE_AMD_API int flake_amd_encode_init(FlakeAmdContext *s)
     const char *eb = getenv("FLAKE_AMD_BATCH"), *ed = getenv("FLAKE_AMD_DEVICE");
     const char *eh = getenv("FLAKE_AMD_HOST_ASSEMBLY");
     c->host_assembly = eh && eh[0] == '1';
+    { const char *ev = getenv("FLAKE_AMD_HOST_VBS"); c->host_vbs = ev && ev[0] == '1'; }
     c->max_batch = eb ? atoi(eb) : 1024;
     if (c->max_batch < 1) c->max_batch = 1;
     /* a VBS block may turn into up to 8 frames of the smallest size */
@@ -572,11 +574,28 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
     int32_t *scratch = (int32_t *)malloc(sizeof(int32_t) * (size_t)block_size);
     if (!pieces || !scratch) { free(pieces); free(scratch); return -1; }
     int np = 0;
+    int32_t *dev_nf = NULL, *dev_sizes = NULL;
+    if (vbs && !c->host_vbs) {
+        /* split_frame_v1 on the device (K-vbs) for the whole batch */
+        dev_nf = (int32_t *)malloc(sizeof(int32_t) * (size_t)count);
+        dev_sizes = (int32_t *)malloc(sizeof(int32_t) * (size_t)count * VBS_PARTS);
+        if (!dev_nf || !dev_sizes ||
+            fhip_vbs_split(c->hip, pcm, count, block_size, dev_nf, dev_sizes) != FHIP_OK) {
+            snprintf(c->err, sizeof c->err, "fhip_vbs_split failed");
+            free(dev_nf); free(dev_sizes); free(pieces); free(scratch);
+            return -1;
+        }
+    }
     for (int b = 0; b < count; b++) {
         int sizes[VBS_PARTS], nf = 1;
         sizes[0] = block_size;
         if (vbs) {
-            nf = vbs_split(pcm + b * bstride, nch, block_size, sizes);
+            if (dev_nf) {
+                nf = dev_nf[b];
+                memcpy(sizes, dev_sizes + (size_t)b * VBS_PARTS, sizeof sizes);
+            } else {
+                nf = vbs_split(pcm + b * bstride, nch, block_size, sizes);
+            }
             if (nf <= 1) { nf = 1; sizes[0] = block_size; }        /* vbs.c:100, encode.c:1001 */
         }
         int pos = 0;
@@ -671,6 +690,7 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
     }
     fa_md5_pcm(&c->md5, pcm, (size_t)count * bstride, c->hp.bits_per_sample);   /* encode.c:1006 */
 out:
+    free(dev_nf); free(dev_sizes);
     free(pieces); free(scratch); free(slot_of); free(done); free(num_of);
     return total;
 }

@@ -202,6 +202,12 @@ FHIP_API int fhip_calc_rice_params(fhip_ctx *ctx, const int32_t *residual, int n
                                    fhip_subframe_info *info, uint8_t *rice_bits,
                                    int64_t rice_slot_bytes);
 
+/* split_frame_v1(), vbs.c:36-83, for nblocks blocks of block_size samples per
+ * channel (block_size a multiple of 8, >= 128): frames [nblocks] and
+ * sizes [nblocks][8] exactly as the reference computes them. */
+FHIP_API int fhip_vbs_split(fhip_ctx *ctx, const int32_t *pcm, int nblocks, int block_size,
+                            int32_t *frames, int32_t *sizes);
+
 /* copy_samples + channel_decorrelation + remove_wasted_bits,
  * encode.c:541-694, for nframes blocks; fills info[].obits/wasted/ch_mode. */
 FHIP_API int fhip_prepare_frames(fhip_ctx *ctx, const int32_t *pcm, int nframes, int n,

@@ -236,3 +236,29 @@ def test_full_size_batch_properties():
         assert bits == info["rice_nbits"][s], s
     # linearity of the bookkeeping: ch_mode consistent within a frame, obits rule
     assert (info["ch_mode"][0::2] == info["ch_mode"][1::2]).all()
+
+
+def test_vbs_split_matches_reference_rule(oracle):
+    """K-vbs vs split_frame_v1 (vbs.c:36-83) incl. the 32-bit abs/multiply quirk."""
+    r = np.random.RandomState(5)
+    for ch, bps, n in ((2, 16, 4096), (1, 24, 8192), (8, 24, 1024), (2, 32, 2048)):
+        p = flake_amd.level_params(10, channels=ch, bits_per_sample=bps, block_size=n)
+        base = flake_amd.synth_pcm(12, n, ch, bps)
+        blocks = []
+        for b in range(12):
+            blk = base[b].copy()
+            cut = (b % 8) * n // 8
+            if b % 3 == 0:
+                blk[:cut] //= 128
+            elif b % 3 == 1:
+                blk[cut:] = r.randint(-5, 6, blk[cut:].shape)
+            blocks.append(blk)
+        if bps == 32:      # large scores: the int abs()/imul wrap of vbs.c:69 comes into play
+            blocks[0][: n // 2] = r.randint(-2 ** 31, 2 ** 31 - 1, (n // 2, ch))
+        pcm = np.stack(blocks).astype(np.int32)
+        with flake_amd.Encoder(p, max_frames=12) as enc:
+            nf, sizes = enc.vbs_split(pcm, n)
+        for b in range(12):
+            enf, esz = oracle.vbs_split(pcm[b], ch, n)
+            assert nf[b] == enf, (ch, bps, b)
+            assert (sizes[b, :enf] == esz).all() and (sizes[b, enf:] == 0).all()

@@ -56,13 +56,13 @@ def cpu_baseline(params, n, budget_s):
     import flake_amd
 
     orc = oraclelib.Oracle()
-    frames = 512
+    frames = 1024
     pcm = flake_amd.synth_pcm(frames, n, params.channels, params.bits_per_sample)
     slot = flake_amd.rice_slot_bytes(params, n)
     t0 = time.perf_counter()
     orc.encode_subframes_batch(params, pcm, n, want_residual=False, slot_bytes=slot)
     dt1 = time.perf_counter() - t0
-    reps = max(1, min(64, int(budget_s / max(dt1, 1e-3)) - 1))
+    reps = max(1, min(400, int(budget_s / max(dt1, 1e-3)) - 1))
     t0 = time.perf_counter()
     for _ in range(reps):
         orc.encode_subframes_batch(params, pcm, n, want_residual=False, slot_bytes=slot)

@@ -1939,30 +1939,30 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                         put_bits32(l.bits, nw, 6 - wbit, pbits, (uint32_t)l.kpar[heap0]);
                     }
                     // The thread's codewords form one contiguous bit run.  It is
-                    // assembled MSB-first in a 64-bit register and leaves a word at
-                    // a time: the run's first and last word may be shared with the
-                    // neighbours (LDS OR), every word in between is this thread's
-                    // alone (plain store).
-                    unsigned long long acc = 0;
+                    // assembled MSB-first in a 32-bit register and leaves a word at
+                    // a time by LDS OR (the run's first and last word are shared
+                    // with the neighbours; OR-ing the interior ones too costs the
+                    // same LDS issue slot as a store and needs no bookkeeping).
+                    uint32_t hi = 0;
                     int nacc = (int)(my_off & 31);
-                    long long w = (long long)(my_off >> 5) - wlo;
-                    bool shared = true;
-                    auto flush = [&]() {
-                        const uint32_t word = (uint32_t)(acc >> 32);
-                        if (w >= 0 && w < nw) {
-                            if (shared) { if (word) atomicOr(&l.bits[w], word); }
-                            else l.bits[w] = word;
+                    int w = (int)((long long)(my_off >> 5) - wlo);
+                    // append a field of len <= 32 bits (val < 2^len); at most one word leaves
+                    auto field = [&](int len, uint32_t val) {
+                        const int t = nacc + len;
+                        const int spill = t - 32;                       // > 0: the field straddles
+                        const uint32_t head = (spill > 0) ? (val >> spill) : (val << ((32 - t) & 31));
+                        const uint32_t word = hi | ((t == 32 || spill > 0 || t < 32) ? head : 0u);
+                        if (t >= 32) {
+                            if ((unsigned)w < (unsigned)nw) atomicOr(&l.bits[w], word);
+                            hi = (spill > 0) ? (val << (32 - spill)) : 0u;
+                            nacc = spill;
+                            w++;
+                        } else {
+                            hi = word;
+                            nacc = t;
                         }
-                        shared = false;
-                        acc <<= 32;
-                        nacc -= 32;
-                        w++;
                     };
-                    if (part_head) {
-                        acc |= (unsigned long long)(uint32_t)k << (64 - nacc - pbits);
-                        nacc += pbits;
-                        if (nacc >= 32) flush();
-                    }
+                    if (part_head) field(pbits, (uint32_t)k);
                     const uint32_t kmask = (1u << k) - 1u;
                     if (short_codes) {
                         // bitio.h:120-141: q zeros, a one, k low bits -- as one field
@@ -1972,40 +1972,31 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                             const bool coded = (e.i0 + o >= order);
                             const uint32_t u = emit_fold32(r[o]);
                             const int len = coded ? (int)(u >> k) + k + 1 : 0;
-                            const unsigned long long val = coded ? ((1u << k) | (u & kmask)) : 0u;
-                            acc |= val << ((64 - nacc - len) & 63);
-                            nacc += len;
-                            if (nacc >= 32) flush();
+                            const uint32_t val = coded ? ((1u << k) | (u & kmask)) : 0u;
+                            field(len, val);
                         }
                     } else {
 #pragma unroll 2
                         for (int o = 0; o < C; o++) {
                             if (e.i0 + o >= order) {
                                 const uint32_t u = emit_fold32(r[o]);
-                                const uint32_t q = u >> k;
+                                uint32_t q = u >> k;
                                 if (q >= 32u) {
-                                    // long unary run: skip whole zero words at once
+                                    // long unary run: the pending word leaves, whole zero
+                                    // words are skipped (the window is zero-filled)
                                     const long long adv = (long long)nacc + q;
-                                    if (nacc > 0 || shared) { flush(); }
-                                    else { w++; nacc -= 32; }
-                                    const long long rem = adv - 32;      // zeros still to place
-                                    w += rem >> 5;
-                                    nacc = (int)(rem & 31);
-                                    acc = 0;
+                                    if (hi && (unsigned)w < (unsigned)nw) atomicOr(&l.bits[w], hi);
+                                    hi = 0;
+                                    w += (int)(adv >> 5);
+                                    nacc = (int)(adv & 31);
                                 } else {
-                                    nacc += (int)q;
-                                    if (nacc >= 32) flush();
+                                    field((int)q, 0u);
                                 }
-                                acc |= (unsigned long long)((1u << k) | (u & kmask)) << (64 - nacc - (k + 1));
-                                nacc += k + 1;
-                                if (nacc >= 32) flush();
+                                field(k + 1, (1u << k) | (u & kmask));
                             }
                         }
                     }
-                    if (nacc > 0) {
-                        const uint32_t word = (uint32_t)(acc >> 32);
-                        if (word && w >= 0 && w < nw) atomicOr(&l.bits[w], word);
-                    }
+                    if (nacc > 0 && hi && (unsigned)w < (unsigned)nw) atomicOr(&l.bits[w], hi);
                     __syncthreads();
                     STAMP(11);
                     for (int q = tid; q < nw; q += T)

@@ -1400,11 +1400,23 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 //     31-step scan only where its modular arithmetic can bite (see rice_k_fast).
 constexpr int HIST = 32;                 // zeroed samples in front of the block
 
-__device__ __forceinline__ int padidx2(int i)      // i >= -HIST
-{
-    const int v = i + HIST;
-    return v + (v >> 4);
-}
+// The block sits in LDS as fp64, transposed in chunks: sample i (>= -HIST) is at
+// row (i mod C), column (i div C) + HIST/C of a [C][T + pad] image.  Thread t's run
+// is then one column, lanes of a wave touch consecutive doubles (no bank
+// conflicts), and every sample a thread needs at offset c from its run start
+// is at a thread base + a compile-time offset: the FIR window loads carry no
+// address arithmetic and no int->double conversion.
+template <int C, int T>
+struct SmpImg {
+    static constexpr int COL0 = HIST / C;
+    static constexpr int S = T + COL0 + 2;           // row stride in doubles (even: b128-aligned rows)
+    static constexpr int SIZE = C * S;
+    // offset of sample (run start of thread t) + c, relative to &img[t]
+    __host__ __device__ static constexpr int off(int c)
+    {
+        return (((c % C) + C) % C) * S + ((c - (((c % C) + C) % C)) / C) + COL0;
+    }
+};
 
 // rice.c:30-45 find_optimal_rice_param without the scan.  With
 // S = sum - (n>>1):  f(k) = n(k+1) + (S>>k).
@@ -1435,7 +1447,7 @@ __device__ __forceinline__ int rice_k_fast(uint64_t sum, int n, uint32_t *bits_o
 }
 
 struct FastLds {
-    int32_t *smp;                        // padded samples, HIST zeros in front
+    double *smp;                         // SmpImg<C,T>: fp64 samples, HIST zeros in front
     unsigned long long *sums;            // [511] heap order
     int32_t *kpar;                       // [511]
     double *coefd;                       // [32] coefficients of the candidate as fp64
@@ -1447,13 +1459,14 @@ struct FastLds {
     uint32_t *bits;                      // [ENC_WWORDS]
 };
 
-__host__ __device__ inline size_t fast_lds_layout(int n, size_t off[11])
+__host__ __device__ inline size_t fast_lds_layout(int n, size_t img_doubles, size_t off[11])
 {
+    (void)n;
     size_t o = 0;
     off[0] = o; o += 8 * 512;                                   // sums
     off[1] = o; o += 8 * 32;                                    // coefd
     off[2] = o; o += 8 * 16;                                    // wtot
-    off[3] = o; o += 4 * (size_t)(n + HIST + ((n + HIST) >> 4) + 4);   // smp
+    off[3] = o; o += 8 * img_doubles;                           // smp (fp64 image)
     off[4] = o; o += 4 * 512;                                   // kpar
     off[5] = o; o += 4 * 12;                                    // lvl_bits
     off[6] = o; o += 4 * 12;                                    // lvl_meth
@@ -1478,9 +1491,11 @@ struct FastCtx {
 template <int C, int T>
 __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift)
 {
+    using Img = SmpImg<C, T>;
     const FastLds &l = e.l;
     const double inv = __builtin_ldexp(1.0, -shift);
     constexpr int OB = (C < 8) ? C : 8;              // outputs per register block
+    const double *mine = l.smp + e.tid;              // column of this thread's run
 #pragma unroll
     for (int ob = 0; ob < C; ob += OB) {
         // keep the register blocks apart: interleaving them only costs VGPRs
@@ -1488,31 +1503,49 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
         double acc[OB];
 #pragma unroll
         for (int o = 0; o < OB; o++) acc[o] = 0.0;
+        // taps in blocks of 16 (tb = 0, 16): going back C*k samples is going back
+        // k columns, so the window of block tb is the window of block 0 read
+        // from a base tb/C columns to the left -- all offsets stay immediates.
 #pragma unroll 1
-        for (int tb = 0; tb < order; tb += 8) {
-            // window W[m] = sample (i0 + ob - tb - 8 + m), m = 0 .. OB+6
-            double W[OB + 7];
-            const int base = e.i0 + ob - tb - 8;
+        for (int tb = 0; tb < order; tb += 16) {
+            const double *base = mine - tb / C;
+            // taps tb+1 .. tb+8 : samples c = ob+o-jj-1, jj = 0..7
+            {
+                double W[OB + 7];
 #pragma unroll
-            for (int m = 0; m < OB + 7; m++) W[m] = (double)l.smp[padidx2(base + m)];
+                for (int m = 0; m < OB + 7; m++) W[m] = base[Img::off(ob - 8 + m)];
 #pragma unroll
-            for (int jj = 0; jj < 8; jj++) {
-                const double cd = l.coefd[tb + jj];
+                for (int jj = 0; jj < 8; jj++) {
+                    const double cd = l.coefd[tb + jj];
 #pragma unroll
-                for (int o = 0; o < OB; o++)
-                    acc[o] = __builtin_fma(cd, W[o + 7 - jj], acc[o]);
+                    for (int o = 0; o < OB; o++)
+                        acc[o] = __builtin_fma(cd, W[o + 7 - jj], acc[o]);
+                }
+            }
+            if (order > tb + 8) {
+                // taps tb+9 .. tb+16
+                double W[OB + 7];
+#pragma unroll
+                for (int m = 0; m < OB + 7; m++) W[m] = base[Img::off(ob - 16 + m)];
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    const double cd = l.coefd[tb + 8 + jj];
+#pragma unroll
+                    for (int o = 0; o < OB; o++)
+                        acc[o] = __builtin_fma(cd, W[o + 7 - jj], acc[o]);
+                }
             }
         }
 #pragma unroll
         for (int o = 0; o < OB; o++) {
             // pred >> shift == floor(pred * 2^-shift); (int32)(x - that) = low 32 bits
+            const double xd = mine[Img::off(ob + o)];
             const double q = __builtin_floor(acc[o] * inv);
-            const int32_t xo = l.smp[padidx2(e.i0 + ob + o)];
-            const double d = (double)xo - q;
+            const double d = xd - q;
             const double hi = __builtin_floor(d * (1.0 / 4294967296.0));
             const double lo = __builtin_fma(-hi, 4294967296.0, d);
             const int32_t v = (int32_t)(uint32_t)lo;
-            r[ob + o] = (e.i0 + ob + o < order) ? xo : v;
+            r[ob + o] = (e.i0 + ob + o < order) ? (int32_t)xd : v;
         }
     }
 }
@@ -1521,13 +1554,15 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
 template <int C, int T>
 __device__ __forceinline__ void fir_fixed(const FastCtx<C, T> &e, int32_t (&r)[C], int order)
 {
+    using Img = SmpImg<C, T>;
     const FastLds &l = e.l;
+    const double *mine = l.smp + e.tid;
     long long h[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) h[k] = l.smp[padidx2(e.i0 - 1 - k)];
+    for (int k = 0; k < 4; k++) h[k] = (long long)mine[Img::off(-1 - k)];
 #pragma unroll
     for (int o = 0; o < C; o++) {
-        const int32_t xo = l.smp[padidx2(e.i0 + o)];
+        const int32_t xo = (int32_t)mine[Img::off(o)];
         const long long x0 = xo;
         long long acc;
         if (order == 0) acc = x0;
@@ -1659,12 +1694,12 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     size_t off[11];
-    fast_lds_layout(n, off);
+    fast_lds_layout(n, SmpImg<C, T>::SIZE, off);
     FastCtx<C, T> e;
     e.l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
     e.l.coefd = reinterpret_cast<double *>(lds_raw + off[1]);
     e.l.wtot = reinterpret_cast<unsigned long long *>(lds_raw + off[2]);
-    e.l.smp = reinterpret_cast<int32_t *>(lds_raw + off[3]);
+    e.l.smp = reinterpret_cast<double *>(lds_raw + off[3]);
     e.l.kpar = reinterpret_cast<int32_t *>(lds_raw + off[4]);
     e.l.lvl_bits = reinterpret_cast<uint32_t *>(lds_raw + off[5]);
     e.l.lvl_meth = reinterpret_cast<uint32_t *>(lds_raw + off[6]);
@@ -1722,11 +1757,12 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
         const int32_t first = first_n;
 #pragma unroll
         for (int o = 0; o < C; o++) {
-            l.smp[padidx2(e.i0 + o)] = x[o];
+            l.smp[tid + SmpImg<C, T>::off(o)] = (double)x[o];
             differs |= (x[o] != first);
         }
     }
-    if (tid < HIST) l.smp[padidx2(tid - HIST)] = 0;
+    // HIST zeros in front: columns 0 .. COL0-1 of every row
+    if (tid < HIST) l.smp[(tid % C) * SmpImg<C, T>::S + tid / C] = 0.0;
     if (pre_row && tid < FHIP_MAX_ORDER) {
         l.coef[tid] = fcoef_n;
         l.coefd[tid] = (double)fcoef_n;
@@ -2021,7 +2057,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     if (tid < FHIP_MAX_ORDER) {
         out->coefs[tid] = (type == FHIP_SUB_LPC && tid < order) ? l.coef[tid] : 0;
         const int nw = (type == FHIP_SUB_CONSTANT) ? 1 : order;
-        out->warmup[tid] = (tid < nw) ? l.smp[padidx2(tid)] : 0;
+        out->warmup[tid] = (tid < nw) ? (int32_t)l.smp[(tid % C) * SmpImg<C, T>::S + tid / C + SmpImg<C, T>::COL0] : 0;
     }
     if (tid < FHIP_MAX_PARTS) {
         const int np = has_rice ? (1 << porder) : 0;
@@ -2502,7 +2538,10 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
     int fc = 0, ft = 0;
     if (raw_order < 0 && fast_geometry(p, n, &fc, &ft)) {
         size_t off[11];
-        const size_t lds = fast_lds_layout(n, off);
+        const size_t img = (fc == 4) ? (size_t)SmpImg<4, 256>::SIZE : (fc == 8) ? (size_t)SmpImg<8, 256>::SIZE
+                         : (ft == 256) ? (size_t)SmpImg<16, 256>::SIZE : (ft == 512) ? (size_t)SmpImg<16, 512>::SIZE
+                         : (size_t)SmpImg<16, 1024>::SIZE;
+        const size_t lds = fast_lds_layout(n, img, off);
 #define LAUNCH_FAST(CC, TT)                                                                  \
     do {                                                                                     \
         hipError_t er = hipFuncSetAttribute(                                                 \

@@ -1400,12 +1400,13 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 //     31-step scan only where its modular arithmetic can bite (see rice_k_fast).
 constexpr int HIST = 32;                 // zeroed samples in front of the block
 
-// The block sits in LDS as fp64, transposed in chunks: sample i (>= -HIST) is at
-// row (i mod C), column (i div C) + HIST/C of a [C][T + pad] image.  Thread t's run
-// is then one column, lanes of a wave touch consecutive doubles (no bank
+// The block sits in LDS transposed in chunks: sample i (>= -HIST) is at row
+// (i mod C), column (i div C) + HIST/C of a [C][T + pad] int32 image.  Thread t's
+// run is then one column, lanes of a wave touch consecutive words (no bank
 // conflicts), and every sample a thread needs at offset c from its run start
 // is at a thread base + a compile-time offset: the FIR window loads carry no
-// address arithmetic and no int->double conversion.
+// address arithmetic.  (An fp64 image saves the int->double conversions but its
+// 33 KB cost the fourth workgroup per CU: measured 108 vs 96 us.)
 template <int C, int T>
 struct SmpImg {
     static constexpr int COL0 = HIST / C;
@@ -1447,7 +1448,7 @@ __device__ __forceinline__ int rice_k_fast(uint64_t sum, int n, uint32_t *bits_o
 }
 
 struct FastLds {
-    double *smp;                         // SmpImg<C,T>: fp64 samples, HIST zeros in front
+    int32_t *smp;                        // SmpImg<C,T>: samples, HIST zeros in front
     unsigned long long *sums;            // [511] heap order
     int32_t *kpar;                       // [511]
     double *coefd;                       // [32] coefficients of the candidate as fp64
@@ -1466,7 +1467,7 @@ __host__ __device__ inline size_t fast_lds_layout(int n, size_t img_doubles, siz
     off[0] = o; o += 8 * 512;                                   // sums
     off[1] = o; o += 8 * 32;                                    // coefd
     off[2] = o; o += 8 * 16;                                    // wtot
-    off[3] = o; o += 8 * img_doubles;                           // smp (fp64 image)
+    off[3] = o; o += 4 * img_doubles;                           // smp image (ints)
     off[4] = o; o += 4 * 512;                                   // kpar
     off[5] = o; o += 4 * 12;                                    // lvl_bits
     off[6] = o; o += 4 * 12;                                    // lvl_meth
@@ -1495,7 +1496,7 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
     const FastLds &l = e.l;
     const double inv = __builtin_ldexp(1.0, -shift);
     constexpr int OB = (C < 8) ? C : 8;              // outputs per register block
-    const double *mine = l.smp + e.tid;              // column of this thread's run
+    const int32_t *mine = l.smp + e.tid;
 #pragma unroll
     for (int ob = 0; ob < C; ob += OB) {
         // keep the register blocks apart: interleaving them only costs VGPRs
@@ -1508,12 +1509,12 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
         // from a base tb/C columns to the left -- all offsets stay immediates.
 #pragma unroll 1
         for (int tb = 0; tb < order; tb += 16) {
-            const double *base = mine - tb / C;
+            const int32_t *base = mine - tb / C;
             // taps tb+1 .. tb+8 : samples c = ob+o-jj-1, jj = 0..7
             {
                 double W[OB + 7];
 #pragma unroll
-                for (int m = 0; m < OB + 7; m++) W[m] = base[Img::off(ob - 8 + m)];
+                for (int m = 0; m < OB + 7; m++) W[m] = (double)base[Img::off(ob - 8 + m)];
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++) {
                     const double cd = l.coefd[tb + jj];
@@ -1526,7 +1527,7 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
                 // taps tb+9 .. tb+16
                 double W[OB + 7];
 #pragma unroll
-                for (int m = 0; m < OB + 7; m++) W[m] = base[Img::off(ob - 16 + m)];
+                for (int m = 0; m < OB + 7; m++) W[m] = (double)base[Img::off(ob - 16 + m)];
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++) {
                     const double cd = l.coefd[tb + 8 + jj];
@@ -1539,7 +1540,7 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
 #pragma unroll
         for (int o = 0; o < OB; o++) {
             // pred >> shift == floor(pred * 2^-shift); (int32)(x - that) = low 32 bits
-            const double xd = mine[Img::off(ob + o)];
+            const double xd = (double)mine[Img::off(ob + o)];
             const double q = __builtin_floor(acc[o] * inv);
             const double d = xd - q;
             const double hi = __builtin_floor(d * (1.0 / 4294967296.0));
@@ -1556,7 +1557,7 @@ __device__ __forceinline__ void fir_fixed(const FastCtx<C, T> &e, int32_t (&r)[C
 {
     using Img = SmpImg<C, T>;
     const FastLds &l = e.l;
-    const double *mine = l.smp + e.tid;
+    const int32_t *mine = l.smp + e.tid;
     long long h[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) h[k] = (long long)mine[Img::off(-1 - k)];
@@ -1588,9 +1589,18 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
     const int pmax = clamp_porder(e.pmax_req, n, order);
 
     // thread-level sum; partition 0 of every level starts at `order` (rice.c:85-94)
-    unsigned long long v = 0;
+    unsigned long long v;
+    if (e.obits <= 27) {
+        // C <= 16 folded values below 2^28 each: the thread's sum fits 32 bits
+        uint32_t v32 = 0;
 #pragma unroll
-    for (int o = 0; o < C; o++) v += (e.i0 + o >= order) ? zigzag32(r[o]) : 0u;
+        for (int o = 0; o < C; o++) v32 += (e.i0 + o >= order) ? zigzag32(r[o]) : 0u;
+        v = v32;
+    } else {
+        v = 0;
+#pragma unroll
+        for (int o = 0; o < C; o++) v += (e.i0 + o >= order) ? zigzag32(r[o]) : 0u;
+    }
 
     // (callers guarantee a barrier between the previous search's reads of
     // lvl_bits/lvl_meth and this reset)
@@ -1642,11 +1652,15 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
     }
     __syncthreads();
     STAMP(6);
-    // rice.c:127-138, evaluated redundantly by every thread (no broadcast
-    // barrier): all nine levels are fetched together, then compared
+    // rice.c:127-138, evaluated redundantly by every wave (no broadcast
+    // barrier).  The inputs are workgroup-uniform: readfirstlane moves them to
+    // SGPRs so that the comparison chain runs on the scalar unit.
     uint32_t lb[9], lm[9];
 #pragma unroll
-    for (int p = 0; p < 9; p++) { lb[p] = l.lvl_bits[p]; lm[p] = l.lvl_meth[p]; }
+    for (int p = 0; p < 9; p++) {
+        lb[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.lvl_bits[p]);
+        lm[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.lvl_meth[p]);
+    }
     int bp = pmin;
     uint32_t best = 0, method = 0;
 #pragma unroll
@@ -1682,10 +1696,10 @@ __device__ __forceinline__ void put_bits32(uint32_t *win, int nw, long long pos,
 }
 
 template <int C, int T>
-#ifndef FHIP_K3_WPS
-#define FHIP_K3_WPS 3
-#endif
-__global__ __launch_bounds__(T, (T == 256) ? FHIP_K3_WPS : 4)   // VGPR cap per waves/SIMD: 2 -> 256, 3 -> 168, 4 -> 128
+// 4 waves per SIMD (<= 128 VGPRs): four 256-thread workgroups per CU.  The
+// kernel is latency-bound (a dozen dependent phases), so the fourth workgroup
+// is worth 12 %; a fifth needs <= 96 VGPRs and spills (measured 125 us vs 96).
+__global__ __launch_bounds__(T, 4)   // VGPR cap per waves/SIMD: 2 -> 256, 3 -> 168, 4 -> 128
 void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ smp_all,
                    const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                    const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,
@@ -1699,7 +1713,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     e.l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
     e.l.coefd = reinterpret_cast<double *>(lds_raw + off[1]);
     e.l.wtot = reinterpret_cast<unsigned long long *>(lds_raw + off[2]);
-    e.l.smp = reinterpret_cast<double *>(lds_raw + off[3]);
+    e.l.smp = reinterpret_cast<int32_t *>(lds_raw + off[3]);
     e.l.kpar = reinterpret_cast<int32_t *>(lds_raw + off[4]);
     e.l.lvl_bits = reinterpret_cast<uint32_t *>(lds_raw + off[5]);
     e.l.lvl_meth = reinterpret_cast<uint32_t *>(lds_raw + off[6]);
@@ -1757,12 +1771,12 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
         const int32_t first = first_n;
 #pragma unroll
         for (int o = 0; o < C; o++) {
-            l.smp[tid + SmpImg<C, T>::off(o)] = (double)x[o];
+            l.smp[tid + SmpImg<C, T>::off(o)] = x[o];
             differs |= (x[o] != first);
         }
     }
     // HIST zeros in front: columns 0 .. COL0-1 of every row
-    if (tid < HIST) l.smp[(tid % C) * SmpImg<C, T>::S + tid / C] = 0.0;
+    if (tid < HIST) l.smp[(tid % C) * SmpImg<C, T>::S + tid / C] = 0;
     if (pre_row && tid < FHIP_MAX_ORDER) {
         l.coef[tid] = fcoef_n;
         l.coefd[tid] = (double)fcoef_n;
@@ -1928,16 +1942,26 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
         const int part = tid >> tpp;
         const int k = l.kpar[heap0 + part];
         const bool part_head = (part > 0) && ((tid & ((1 << tpp) - 1)) == 0);
-        unsigned long long mine = part_head ? pbits : 0;
-        uint32_t longest = 0;                              // longest codeword of this thread
+        // codeword lengths of the run; in 32 bits unless a quotient is huge
+        uint32_t longest = 0;
 #pragma unroll
-        for (int o = 0; o < C; o++) {
-            const uint32_t q = (e.i0 + o >= order) ? (emit_fold32(r[o]) >> k) : 0u;
-            mine += (e.i0 + o >= order) ? ((unsigned long long)q + 1 + k) : 0ull;
-            longest = max(longest, q);
-        }
+        for (int o = 0; o < C; o++)
+            longest = max(longest, (e.i0 + o >= order) ? (emit_fold32(r[o]) >> k) : 0u);
         // every codeword of the wave at most 32 bits: one flush test per codeword
         const bool short_codes = !__any(longest + (uint32_t)k + 1u > 32u);
+        const bool tiny_codes = (C % 2 == 0) && !__any(longest + (uint32_t)k + 1u > 16u);
+        unsigned long long mine = part_head ? pbits : 0;
+        if (short_codes) {
+            uint32_t m32 = 0;
+#pragma unroll
+            for (int o = 0; o < C; o++)
+                m32 += (e.i0 + o >= order) ? ((emit_fold32(r[o]) >> k) + 1u + (uint32_t)k) : 0u;
+            mine += m32;
+        } else {
+#pragma unroll
+            for (int o = 0; o < C; o++)
+                mine += (e.i0 + o >= order) ? ((unsigned long long)(emit_fold32(r[o]) >> k) + 1 + k) : 0ull;
+        }
         // in-wave offsets: DPP scan in 32 bits unless some lane of the wave
         // holds an absurdly long run (then the exact 64-bit shuffle scan)
         unsigned long long incl;
@@ -2000,7 +2024,20 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                     };
                     if (part_head) field(pbits, (uint32_t)k);
                     const uint32_t kmask = (1u << k) - 1u;
-                    if (short_codes) {
+                    if (tiny_codes) {
+                        // every codeword of the wave <= 16 bits: two codewords are
+                        // one field of <= 32 bits (half the append/flush work)
+#pragma unroll
+                        for (int o = 0; o < C; o += 2) {
+                            const bool c0 = (e.i0 + o >= order), c1 = (e.i0 + o + 1 >= order);
+                            const uint32_t u0 = emit_fold32(r[o]), u1 = emit_fold32(r[o + 1]);
+                            const int l0 = c0 ? (int)(u0 >> k) + k + 1 : 0;
+                            const int l1 = c1 ? (int)(u1 >> k) + k + 1 : 0;
+                            const uint32_t v0 = c0 ? ((1u << k) | (u0 & kmask)) : 0u;
+                            const uint32_t v1 = c1 ? ((1u << k) | (u1 & kmask)) : 0u;
+                            field(l0 + l1, (v0 << l1) | v1);
+                        }
+                    } else if (short_codes) {
                         // bitio.h:120-141: q zeros, a one, k low bits -- as one field
                         // of q+k+1 <= 32 bits; warm-up samples are zero-length fields
 #pragma unroll

@@ -66,9 +66,22 @@ def build_host(force: bool = False) -> str:
     return out
 
 
+def build_cli(force: bool = False) -> str:
+    """The C command-line harness on the host API (flake/flake.c's block loop)."""
+    out = os.path.join(LIB, "flake_amd_cli")
+    src = os.path.join(PKG, "host/flake_amd_cli.c")
+    if not os.path.exists(src):
+        return ""
+    if force or _stale(out, ["host/flake_amd_cli.c", "../include/flake_amd.h"]):
+        _run(["gcc", "-std=gnu99", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", out,
+              "-L", LIB, "-lflake_amd", "-lflakehip", "-Wl,-rpath,$ORIGIN", "-lm"])
+    return out
+
+
 def build_all(force: bool = False) -> None:
     build_hip(force)
     build_host(force)
+    build_cli(force)
 
 
 if __name__ == "__main__":
@@ -77,3 +90,4 @@ if __name__ == "__main__":
         build_hip(force=True, extra=["-Rpass-analysis=kernel-resource-usage"] if os.environ.get("FHIP_REMARKS") else None)
     if "host" in targets:
         build_host(force=True)
+        build_cli(force=True)

@@ -147,3 +147,41 @@ def test_invalid_parameters_are_rejected_on_the_host():
         flake_amd.HostEncoder(5, variable_block_size=1)          # needs allow_vbs
     with pytest.raises(ValueError):
         flake_amd.HostEncoder(13)
+
+
+def test_cli_wav_to_flac(tmp_path, decoder):
+    """The C command-line harness (flake/flake.c's loop on the host API): WAV in,
+    a complete .flac out -- stream marker, STREAMINFO with the final MD5, frames
+    that decode to the input."""
+    import os
+    import struct
+    import subprocess
+    cli = os.path.join(flake_amd.LIB_DIR, "flake_amd_cli")
+    if not os.path.exists(cli):
+        pytest.skip("flake_amd_cli not built")
+    n_total = 4096 * 5 + 1234
+    pcm = flake_amd.synth_pcm(6, 4096, 2, 16).reshape(-1, 2)[:n_total]
+    raw = pcm.astype("<i2").tobytes()
+    wav = tmp_path / "in.wav"
+    with open(wav, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE" + b"fmt " +
+                struct.pack("<IHHIIHH", 16, 1, 2, 44100, 44100 * 4, 4, 16) + b"data" +
+                struct.pack("<I", len(raw)) + raw)
+    out = tmp_path / "out.flac"
+    r = subprocess.run([cli, "-5", str(wav), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    data = np.fromfile(out, dtype=np.uint8)
+    assert data[:4].tobytes() == b"fLaC"
+    # walk the metadata blocks to the first frame
+    pos, last = 4, 0
+    md5 = None
+    while not last:
+        hdr = data[pos:pos + 4]
+        last, typ = hdr[0] >> 7, hdr[0] & 0x7F
+        ln = (int(hdr[1]) << 16) | (int(hdr[2]) << 8) | int(hdr[3])
+        if typ == 0:
+            md5 = data[pos + 4 + 18: pos + 4 + 34].tobytes()
+        pos += 4 + ln
+    dec, sizes = decoder.decode(data[pos:], 2, 16, n_total)
+    assert (dec == pcm).all() and sizes[-1] == 1234
+    assert md5 == hashlib.md5(raw).digest()

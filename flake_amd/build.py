@@ -66,6 +66,18 @@ def build_host(force: bool = False) -> str:
     return out
 
 
+def build_flake_names(force: bool = False) -> str:
+    """libflake.so: the same host layer exporting libflake's own symbol names
+    (flake_set_defaults ... flake_encode_close), a link-level drop-in."""
+    out = os.path.join(LIB, "libflake.so")
+    srcs = [os.path.join(PKG, s) for s in HOST_SRCS if os.path.exists(os.path.join(PKG, s))]
+    if force or _stale(out, HOST_DEPS):
+        _run(["gcc", "-std=gnu99", "-O2", "-Wall", "-fPIC", "-shared", "-fvisibility=hidden",
+              "-DFLAKE_AMD_EXPORT_FLAKE_NAMES", "-I", os.path.join(ROOT, "include"), *srcs, "-o", out,
+              "-L", LIB, "-lflakehip", "-Wl,-rpath,$ORIGIN", "-lm"])
+    return out
+
+
 def build_cli(force: bool = False) -> str:
     """The C command-line harness on the host API (flake/flake.c's block loop)."""
     out = os.path.join(LIB, "flake_amd_cli")
@@ -81,6 +93,7 @@ def build_cli(force: bool = False) -> str:
 def build_all(force: bool = False) -> None:
     build_hip(force)
     build_host(force)
+    build_flake_names(force)
     build_cli(force)
 
 
@@ -90,4 +103,5 @@ if __name__ == "__main__":
         build_hip(force=True, extra=["-Rpass-analysis=kernel-resource-usage"] if os.environ.get("FHIP_REMARKS") else None)
     if "host" in targets:
         build_host(force=True)
+        build_flake_names(force=True)
         build_cli(force=True)

@@ -742,3 +742,37 @@ FLAKE_AMD_API int flake_amd_encode_frame(FlakeAmdContext *s, const int *samples,
                                           (size_t)c->frame_buffer_size, NULL);
     return (int)w;
 }
+
+
+/* ------------------------------------------------------------------ */
+/* libflake's own symbol names (flake.h:217-295)                       */
+/* ------------------------------------------------------------------ */
+/* Built only into libflake.so (-DFLAKE_AMD_EXPORT_FLAKE_NAMES): a program
+ * written and compiled against the reference's flake.h links against this
+ * library unchanged -- FlakeContext / FlakeEncodeParams / FlakeStreaminfo have
+ * the layouts of the FlakeAmd* structs above. */
+#ifdef FLAKE_AMD_EXPORT_FLAKE_NAMES
+FLAKE_AMD_API int flake_set_defaults(FlakeAmdEncodeParams *p) { return flake_amd_set_defaults(p); }
+FLAKE_AMD_API int flake_validate_params(const FlakeAmdContext *s) { return flake_amd_validate_params(s); }
+FLAKE_AMD_API int flake_encode_init(FlakeAmdContext *s)
+{
+    const int rc = flake_amd_encode_init(s);
+    return rc < 0 ? -1 : rc;                       /* libflake knows only -1 */
+}
+FLAKE_AMD_API void *flake_get_buffer(const FlakeAmdContext *s) { return flake_amd_get_buffer(s); }
+FLAKE_AMD_API int flake_encode_frame(FlakeAmdContext *s, const int *samples, int block_size)
+{
+    const int rc = flake_amd_encode_frame(s, samples, block_size);
+    return rc < 0 ? -1 : rc;
+}
+FLAKE_AMD_API void flake_encode_close(FlakeAmdContext *s) { flake_amd_encode_close(s); }
+FLAKE_AMD_API const char *flake_get_version(void) { return flake_amd_get_version(); }
+FLAKE_AMD_API int flake_get_streaminfo(const FlakeAmdContext *s, FlakeAmdStreaminfo *si)
+{
+    return flake_amd_get_streaminfo(s, si);
+}
+FLAKE_AMD_API void flake_write_streaminfo(const FlakeAmdStreaminfo *si, unsigned char *data)
+{
+    flake_amd_write_streaminfo(si, data);
+}
+#endif

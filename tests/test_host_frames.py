@@ -185,3 +185,29 @@ def test_cli_wav_to_flac(tmp_path, decoder):
     dec, sizes = decoder.decode(data[pos:], 2, 16, n_total)
     assert (dec == pcm).all() and sizes[-1] == 1234
     assert md5 == hashlib.md5(raw).digest()
+
+
+def test_link_level_dropin_client(tmp_path, decoder, oracle):
+    """oracle/_ref/dropin_client is compiled against the REFERENCE's flake.h and linked
+    to our libflake.so (libflake's own symbol names): same call sequence as the
+    reference CLI, one flake_encode_frame() per block."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref",
+                       "dropin_client")
+    if not os.path.exists(exe):
+        pytest.skip("dropin_client not built (needs /root/reference at build time)")
+    out = tmp_path / "d.flac"
+    r = subprocess.run([exe, "5", "7", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    data = np.fromfile(out, dtype=np.uint8)
+    pos, last = 4, 0
+    while not last:
+        last = data[pos] >> 7
+        pos += 4 + ((int(data[pos + 1]) << 16) | (int(data[pos + 2]) << 8) | int(data[pos + 3]))
+    pcm = flake_amd.synth_pcm(7, 4096, 2, 16).reshape(-1, 2)
+    dec, sizes = decoder.decode(data[pos:], 2, 16, 7 * 4096)
+    assert (dec == pcm).all() and len(sizes) == 7
+    p = flake_amd.level_params(5)
+    exp, _ = oracle_stream(oracle, p, pcm, 4096)
+    assert data[pos:].tobytes() == exp.tobytes()

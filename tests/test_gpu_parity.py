@@ -262,3 +262,85 @@ def test_vbs_split_matches_reference_rule(oracle):
             enf, esz = oracle.vbs_split(pcm[b], ch, n)
             assert nf[b] == enf, (ch, bps, b)
             assert (sizes[b, :enf] == esz).all() and (sizes[b, enf:] == 0).all()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE configs[2] and [3] at full size: size-independent properties
+# ---------------------------------------------------------------------------
+
+def _check_properties(p, pcm, n, got, what):
+    """(1) the FLAC decoder recurrence inverts the residual to FlacSubframe.samples,
+    (2) rice_nbits equals the sum of the codeword lengths it stands for,
+    (3) the device-assembled frames decode (CRC-8/16) -- checked by the caller."""
+    info = got["info"]
+    res = got["residual"].reshape(-1, n).astype(np.int64)
+    smp = got["samples"].reshape(-1, n).astype(np.int64)
+    assert (info["type"] == 32).all(), what
+    order = info["order"].astype(np.int64)
+    shift = info["shift"].astype(np.int64)
+    coefs = info["coefs"].astype(np.int64)
+    rec = res.copy()
+    maxo = int(order.max())
+    for i in range(1, n):
+        lo = max(0, i - maxo)
+        # prediction with per-subframe order: taps beyond `order` have zero coefficients
+        hist = rec[:, lo:i][:, ::-1]                       # x[i-1], x[i-2], ...
+        pred = (coefs[:, :hist.shape[1]] * hist).sum(axis=1) >> shift
+        active = i >= order
+        rec[:, i] = np.where(active, rec[:, i] + pred, rec[:, i])
+    assert (rec == smp).all(), what
+    u = (res << 1) ^ (res >> 63)
+    for s in range(0, info.size, max(1, info.size // 64)):
+        po, o = int(info["porder"][s]), int(order[s])
+        psz = n >> po
+        kk = np.repeat(info["rparams"][s][:1 << po].astype(np.int64), psz)[o:]
+        bits = 6 + (4 + int(info["rice_method"][s])) * (1 << po) + int(((u[s, o:] >> kk) + 1 + kk).sum())
+        assert bits == info["rice_nbits"][s], (what, s)
+
+
+def test_config3_full_size_properties(oracle, decoder):
+    """configs[2]: stereo 24-bit 96 kHz, n=4096, order search 1-32 + partition search 0-8,
+    4096 frames on the GPU; the oracle checks a 48-frame slice bit for bit."""
+    p = flake_amd.level_params(5, bits_per_sample=24, sample_rate=96000,
+                               order_method=flake_amd.OM_SEARCH, min_prediction_order=1,
+                               max_prediction_order=32, min_partition_order=0, max_partition_order=8)
+    n, nfr = 4096, 4096
+    pcm = flake_amd.synth_pcm(nfr, n, 2, 24)
+    with flake_amd.Encoder(p, max_frames=nfr) as enc:
+        got = enc.encode_subframes(pcm, n, want_samples=True, want_frames=True)
+    sl = slice(1000, 1048)
+    exp = oracle.encode_subframes_batch(p, pcm[sl], n, slot_bytes=got["slot_bytes"])
+    assert_info_equal(got["info"][2 * sl.start:2 * sl.stop], exp["info"], "config3 slice")
+    assert_residual_equal(got["residual"][sl], exp["residual"], exp["info"], "config3 slice")
+    sub = {k: (v[::16] if k in ("residual", "samples") else v) for k, v in got.items()}
+    sub["info"] = got["info"].reshape(-1, 2)[::16].reshape(-1)
+    _check_properties(p, pcm[::16], n, sub, "config3")
+    stream = np.concatenate([got["frames"][f, :got["frame_bytes"][f]] for f in range(0, nfr, 8)])
+    # frames carry their own numbers, so any subset decodes frame by frame
+    out, _ = decoder.decode(stream, 2, 24, (nfr // 8) * n)
+    assert (out.reshape(-1, n, 2) == pcm[::8]).all()
+
+
+def test_config4_full_size_properties(oracle, decoder):
+    """configs[3]: 8 channels, 24-bit, 192 kHz, n=4096, LPC-12, 1024 frames (8192 subframes)."""
+    p = flake_amd.level_params(5, channels=8, bits_per_sample=24, sample_rate=192000,
+                               order_method=flake_amd.OM_MAX, max_prediction_order=12)
+    n, nfr = 4096, 1024
+    pcm = flake_amd.synth_pcm(nfr, n, 8, 24)
+    with flake_amd.Encoder(p, max_frames=nfr) as enc:
+        got = enc.encode_subframes(pcm, n, want_samples=True, want_frames=True)
+    sl = slice(500, 516)
+    exp = oracle.encode_subframes_batch(p, pcm[sl], n, slot_bytes=got["slot_bytes"])
+    assert_info_equal(got["info"][8 * sl.start:8 * sl.stop], exp["info"], "config4 slice")
+    assert_residual_equal(got["residual"][sl], exp["residual"], exp["info"], "config4 slice")
+    sub = {k: (v[::8] if k in ("residual", "samples") else v) for k, v in got.items()}
+    sub["info"] = got["info"].reshape(-1, 8)[::8].reshape(-1)
+    _check_properties(p, pcm[::8], n, sub, "config4")
+    stream = np.concatenate([got["frames"][f, :got["frame_bytes"][f]] for f in range(0, nfr, 16)])
+    out, _ = decoder.decode(stream, 8, 24, (nfr // 16) * n)
+    assert (out.reshape(-1, n, 8) == pcm[::16]).all()
+    # sharding property: two half batches give the same records as the whole
+    with flake_amd.Encoder(p, max_frames=nfr // 2) as enc:
+        a = enc.encode_subframes(pcm[:nfr // 2], n, want_residual=False, want_bits=False)
+        b = enc.encode_subframes(pcm[nfr // 2:], n, want_residual=False, want_bits=False)
+    assert np.concatenate([a["info"], b["info"]]).tobytes() == got["info"].tobytes()

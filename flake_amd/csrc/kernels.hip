@@ -704,6 +704,199 @@ void k_autocorr(const int32_t *__restrict__ smp, double *__restrict__ autoc,
 }
 
 // ---------------------------------------------------------------------------
+// K1 (small batches)  k_autocorr_ps -- parity-split chains
+// ---------------------------------------------------------------------------
+// A chain walk in k_autocorr is n positions long whatever the batch size, and
+// with few subframes most SIMDs hold one wave or none.  Here each running sum
+// gets its own lane: lane = (subframe g, lag group {l0, l0+2, l0+4}, parity pi)
+// walks only the positions of parity pi, so a walk is n/2 steps of three
+// products.  The operands of the two higher lags are the b of the previous two
+// steps (d[p-2-l0], d[p-4-l0]), carried in registers.  The LDS tile is stored
+// de-interleaved (even positions / odd positions) so that consecutive steps of a
+// lane read consecutive doubles.  The head rule (lpc.c:60-61) sends positions
+// lag..maxlag of every parity to the sum of parity (maxlag+1)&1, in order, before
+// that lane's own walk starts.  autoc = sum(pi=0) + sum(pi=1) (lpc.c:68) joins
+// the two lanes at the end.  launch_autocorr picks this kernel when it needs
+// fewer fp64 issue slots per SIMD than k_autocorr (e.g. LPC-8 at 4096 frames:
+// 1024 waves x 12288 ops instead of 683..1024 x 16384).
+constexpr int PS_HALF = AC_TILE / 2;      // steps per tile and parity
+constexpr int PS_HH = AC_HALO / 2;        // halo entries per parity array
+constexpr int PS_ROW = PS_HH + PS_HALF;   // 80 doubles per parity array
+constexpr int PS_STRIDE = 2 * PS_ROW + 10;   // per subframe (two arrays + bank spread)
+constexpr int PS_GMAX = 8;
+constexpr int PS_CH = 8;                  // steps per software-pipeline stage
+
+__global__ __launch_bounds__(AC_WAVES * WAVE)
+void k_autocorr_ps(const int32_t *__restrict__ smp, double *__restrict__ autoc,
+                   int nsub, int n, int maxlag, int G, int lps, int ge, double c)
+{
+    __shared__ double s_buf[AC_WAVES][PS_GMAX * PS_STRIDE];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    double *buf = s_buf[wv];
+    const int s0 = (blockIdx.x * AC_WAVES + wv) * G;
+    if (s0 >= nsub) return;
+    const int half = n >> 1;
+    const int ntiles = (n + AC_TILE - 1) / AC_TILE;
+
+    const int32_t *rowp[PS_GMAX];
+#pragma unroll
+    for (int q = 0; q < PS_GMAX; q++) rowp[q] = smp + (size_t)min(s0 + q, nsub - 1) * n;
+    int32_t cur[PS_GMAX][AC_PER_LANE];
+
+    // lane -> (subframe, lag group, parity)
+    const int g = lane / lps, ql = lane - g * lps;
+    const int pi = ql & 1, grp = ql >> 1;
+    const int l0 = (grp < ge) ? 6 * grp : 1 + 6 * (grp - ge);
+    const bool chain = (g < G) && (s0 + g < nsub) && (l0 <= maxlag);
+    const bool ok1 = l0 + 2 <= maxlag, ok2 = l0 + 4 <= maxlag;
+    const int pib = pi ^ (l0 & 1);                      // parity array that holds d[p - l0]
+    const int sft = (l0 + pib - pi) / 2;                // index shift inside that array
+    const double *rowA = buf + (chain ? g : 0) * PS_STRIDE + pi * PS_ROW + PS_HH;        // a = rowA[t]
+    const double *rowB = buf + (chain ? g : 0) * PS_STRIDE + pib * PS_ROW + PS_HH - (chain ? sft : 0);
+    const int pih = (maxlag + 1) & 1;                   // parity whose sum owns the head
+    double S0 = 1.0, S1 = 1.0, S2 = 1.0;                // lpc.c:58-59
+    double b1 = 0.0, b2 = 0.0;                          // d[p-2-l0], d[p-4-l0], carried
+
+    auto issue_loads = [&](int tb) {
+#pragma unroll
+        for (int q = 0; q < PS_GMAX; q++)
+#pragma unroll
+            for (int u = 0; u < AC_PER_LANE; u++)
+                cur[q][u] = rowp[q][min(tb + u * WAVE + lane, n - 1)];
+    };
+    // position tb + x sits in parity array (x & 1) at index PS_HH + x/2
+    auto slot = [&](int q, int x) { return q * PS_STRIDE + (x & 1) * PS_ROW + PS_HH + (x >> 1); };
+
+    for (int idx = lane; idx < PS_GMAX * 2 * PS_HH; idx += WAVE) {
+        const int q = idx / (2 * PS_HH), r = idx - q * 2 * PS_HH;
+        buf[q * PS_STRIDE + (r / PS_HH) * PS_ROW + (r % PS_HH)] = 0.0;
+    }
+    issue_loads(0);
+
+    for (int t = 0; t < ntiles; t++) {
+        const int tb = t * AC_TILE;
+        // ---- window the tile into LDS (lpc.c:28-40), de-interleaved by parity ----
+#pragma unroll
+        for (int u = 0; u < AC_PER_LANE; u++) {
+            const int x = u * WAVE + lane;
+            const int p = tb + x;
+            const int ii = (p < half) ? p : (n - 1 - p);
+            const bool valid = (p < n) && (ii < half);
+            const double tt = c - (double)ii;
+            const double w = valid ? (1.0 - (tt * tt)) : 0.0;
+#pragma unroll
+            for (int q = 0; q < PS_GMAX; q++) buf[slot(q, x)] = (double)cur[q][u] * w;
+        }
+        issue_loads(tb + AC_TILE);
+        wave_lds_fence();
+
+        const int kend = min(AC_TILE, n - tb);            // positions in this tile
+        if (t > 0 && kend == AC_TILE) {
+            // steady state: PS_HALF steps, 3 products each, software-pipelined
+            constexpr int NS = PS_HALF / PS_CH;
+            double A[PS_CH], B[PS_CH];
+#pragma unroll
+            for (int u = 0; u < PS_CH; u++) { A[u] = rowA[u]; B[u] = rowB[u]; }
+#pragma unroll
+            for (int st = 0; st < NS; st++) {
+                double An[PS_CH], Bn[PS_CH];
+                if (st + 1 < NS) {
+#pragma unroll
+                    for (int u = 0; u < PS_CH; u++) {
+                        An[u] = rowA[(st + 1) * PS_CH + u];
+                        Bn[u] = rowB[(st + 1) * PS_CH + u];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PS_CH; u++) {
+                    const double p0 = A[u] * B[u], p1 = A[u] * b1, p2 = A[u] * b2;
+                    S0 = S0 + p0;
+                    S1 = S1 + p1;
+                    S2 = S2 + p2;
+                    b2 = b1;
+                    b1 = B[u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 1 < NS) {
+#pragma unroll
+                    for (int u = 0; u < PS_CH; u++) { A[u] = An[u]; B[u] = Bn[u]; }
+                }
+            }
+        } else {
+            if (t == 0 && pi == pih) {
+                // head: positions lag..maxlag of BOTH parities, in order, into this
+                // lane's sums (tile 0 holds them all: maxlag <= 32 < AC_TILE)
+                const int hend = min(maxlag, kend - 1);
+                for (int x = 0; x <= hend; x++) {
+                    const double a = buf[slot(chain ? g : 0, x)];
+                    if (x >= l0) {
+                        const double p0 = a * buf[slot(chain ? g : 0, x - l0)];
+                        S0 = S0 + p0;
+                    }
+                    if (ok1 && x >= l0 + 2) {
+                        const double p1 = a * buf[slot(chain ? g : 0, x - l0 - 2)];
+                        S1 = S1 + p1;
+                    }
+                    if (ok2 && x >= l0 + 4) {
+                        const double p2 = a * buf[slot(chain ? g : 0, x - l0 - 4)];
+                        S2 = S2 + p2;
+                    }
+                }
+            }
+            // own walk through this tile: positions of parity pi above maxlag
+            for (int st = 0; st < PS_HALF; st++) {
+                const int x = 2 * st + pi;
+                const int p = tb + x;
+                if (x >= kend) break;
+                const double a = rowA[st], b0 = rowB[st];
+                if (p > maxlag) {
+                    // operands straight from LDS in this slow path (p - l0 - 4 >= tb - 32)
+                    const double c1 = (x - l0 - 2 >= -AC_HALO) ? buf[slot(chain ? g : 0, x - l0 - 2 + AC_HALO) - PS_HH] : 0.0;
+                    const double c2 = (x - l0 - 4 >= -AC_HALO) ? buf[slot(chain ? g : 0, x - l0 - 4 + AC_HALO) - PS_HH] : 0.0;
+                    const double p0 = a * b0, p1 = a * c1, p2 = a * c2;
+                    S0 = S0 + p0;
+                    S1 = S1 + p1;
+                    S2 = S2 + p2;
+                }
+                b2 = b1;
+                b1 = b0;
+            }
+        }
+        wave_lds_fence();
+        // the last PS_HH entries of both parity arrays become the halo of the next tile
+        {
+            constexpr int NH = (PS_GMAX * 2 * PS_HH) / WAVE;
+            double hv[NH];
+#pragma unroll
+            for (int r = 0; r < NH; r++) {
+                const int idx = lane + r * WAVE;
+                const int q = idx / (2 * PS_HH), rr = idx - q * 2 * PS_HH;
+                hv[r] = buf[q * PS_STRIDE + (rr / PS_HH) * PS_ROW + PS_HALF + (rr % PS_HH)];
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < NH; r++) {
+                const int idx = lane + r * WAVE;
+                const int q = idx / (2 * PS_HH), rr = idx - q * 2 * PS_HH;
+                buf[q * PS_STRIDE + (rr / PS_HH) * PS_ROW + (rr % PS_HH)] = hv[r];
+            }
+        }
+    }
+    // lpc.c:68: autoc = temp + temp2 -- the two parities of a lag group are
+    // neighbouring lanes
+    const double o0 = __shfl_xor(S0, 1, WAVE), o1 = __shfl_xor(S1, 1, WAVE), o2 = __shfl_xor(S2, 1, WAVE);
+    if (chain && pi == 0) {
+        double *dst = autoc + (size_t)(s0 + g) * FHIP_MAX_LAGS;
+        dst[l0] = S0 + o0;
+        if (ok1) dst[l0 + 2] = S1 + o1;
+        if (ok2) dst[l0 + 4] = S2 + o2;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K2  k_lpc
 // ---------------------------------------------------------------------------
 // One lane per subframe; per-lane work arrays live in LDS, laid out
@@ -2676,18 +2869,47 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                            int max_order, double *autoc)
 {
     if (nsub == 0) return hipSuccess;
+    // the window constant is computed on the host exactly as lpc.c:34 does
+    const double c = (2.0 / (n - 1.0)) - 1.0;
+    const int simds = 1024;
+
+    // k_autocorr: lag pairs, both parities in one lane: n positions x 4 fp64 ops
     const int nl2 = (max_order + 2) / 2;          // lag pairs {0,1},{2,3},...
     int G = WAVE / nl2;
     if (G > AC_GMAX) G = AC_GMAX;
     if (G < 1) G = 1;
+    const long waves_cur = (nsub + G - 1) / G;
+    const long cost_cur = ((waves_cur + simds - 1) / simds) * 4L * n;
+
+    // k_autocorr_ps: lag triples, one parity per lane: n/2 steps x 6 fp64 ops
+    const int ne = max_order / 2 + 1, no = (max_order + 1) / 2;
+    const int ge = (ne + 2) / 3, go = (no + 2) / 3;
+    const int lps = 2 * (ge + go);
+    int Gp = WAVE / lps;
+    if (Gp > PS_GMAX) Gp = PS_GMAX;
+    long cost_ps = -1;
+    if (Gp >= 1) {
+        const long waves_ps = (nsub + Gp - 1) / Gp;
+        cost_ps = ((waves_ps + simds - 1) / simds) * 3L * n;
+    }
+    const char *force = getenv("FHIP_AC_KERNEL");         // "cur" / "ps": measurements only
+    bool use_ps = cost_ps > 0 && cost_ps < cost_cur;
+    if (force && force[0] == 'c') use_ps = false;
+    if (force && force[0] == 'p' && cost_ps > 0) use_ps = true;
+
+    if (use_ps) {
+        const int per_block = Gp * AC_WAVES;
+        const int blocks = (nsub + per_block - 1) / per_block;
+        hipLaunchKernelGGL(k_autocorr_ps, dim3(blocks), dim3(AC_WAVES * WAVE), 0, st, smp, autoc,
+                           nsub, n, max_order, Gp, lps, ge, c);
+        return hipGetLastError();
+    }
     // spread over all CUs when the batch is small: fewer subframes per wave
     // cost nothing (a wave's time is its chain length, not its lane count)
     while (G > 1 && (nsub + G * AC_WAVES - 1) / (G * AC_WAVES) < 256) G--;
     if (const char *dbg = getenv("FHIP_AC_G")) { int v = atoi(dbg); if (v >= 1 && v <= AC_GMAX && v * nl2 <= WAVE) G = v; }
     const int per_block = G * AC_WAVES;
     const int blocks = (nsub + per_block - 1) / per_block;
-    // the window constant is computed on the host exactly as lpc.c:34 does
-    const double c = (2.0 / (n - 1.0)) - 1.0;
     hipLaunchKernelGGL(k_autocorr, dim3(blocks), dim3(AC_WAVES * WAVE), 0, st, smp, autoc,
                        nsub, n, max_order, G, nl2, c);
     return hipGetLastError();

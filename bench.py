@@ -11,8 +11,8 @@ batch of synthetic PCM that is already resident in HBM: BASELINE.json
 configs[1] -- stereo 16-bit 44.1 kHz, block size 4096, LPC order 8 (level-5
 parameters with the MAX order method), 4096 frames per GPU.  Frames are
 independent, so with N ranks each rank encodes its own 4096-frame shard of a
-4096*N-frame job (weak scaling); the only collective is the all-reduce of
-{frames, residual bits} (RCCL), issued on a side stream.
+4096*N-frame job (weak scaling); the only collective is the final all-reduce of
+{frames, residual bits} (RCCL), once per job, inside the timed region.
 
 Prints ONE JSON line on rank 0 (see the keys in main()).
 """
@@ -92,13 +92,20 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)          # several ranks may share a GPU in rehearsals
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # "nccl" is RCCL on ROCm; BENCH_DIST_BACKEND=gloo rehearses the N>1 path on one GPU
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     # ---- workload: BASELINE.json configs[1] --------------------------------
     p = flake_amd.level_params(5, channels=2, bits_per_sample=16, sample_rate=44100,
@@ -112,44 +119,41 @@ def main():
                                    first_frame=rank * nframes)
     pcm = torch.from_numpy(pcm_host).to(dev)
     info_bytes = flake_amd.INFO_DTYPE.itemsize
-    nbuf = 2 if world > 1 else 1
-    infos = [torch.zeros(nsub * info_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    bits = [torch.zeros(nsub * slot, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    info = torch.zeros(nsub * info_bytes, dtype=torch.uint8, device=dev)
+    bits = torch.zeros(nsub * slot, dtype=torch.uint8, device=dev)
     resid = torch.zeros((nframes, p.channels, n), dtype=torch.int32, device=dev) \
         if args.with_residual else None
 
-    enc = flake_amd.Encoder(p, max_frames=nframes, device=local_rank)
+    enc = flake_amd.Encoder(p, max_frames=nframes, device=dev_index)
     stream = torch.cuda.current_stream(dev)
     enc.set_stream(stream.cuda_stream)
-    side = torch.cuda.Stream(dev) if world > 1 else None
     stats = torch.zeros(2, dtype=torch.int64, device=dev)
 
-    def step(i):
-        b = i % nbuf
-        enc.encode_subframes_dev(pcm, nframes, n, infos[b], residual=resid,
-                                 rice_bits=bits[b], slot_bytes=slot)
+    def step():
+        enc.encode_subframes_dev(pcm, nframes, n, info, residual=resid, rice_bits=bits,
+                                 slot_bytes=slot)
+
+    def job_stats(steps):
+        """The job's only exchange: {frames, residual bits} summed over ranks."""
+        nb = info.view(torch.int32).view(nsub, info_bytes // 4)[:, 10]
+        stats[0] = nframes * steps
+        stats[1] = nb.clamp(min=0).sum() * steps
         if world > 1:
-            # the job's only exchange: {frames, residual bits}, off the data path
-            ev = torch.cuda.Event()
-            ev.record(stream)
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
-                nb = infos[b].view(torch.int32).view(nsub, info_bytes // 4)[:, 10]
-                stats[0] = nframes
-                stats[1] = nb.clamp(min=0).sum()
-                dist.all_reduce(stats)
+            dist.all_reduce(stats)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        step(i)
+    for _ in range(args.warmup):
+        step()
+    job_stats(0)                 # first use of these torch kernels loads their code objects
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    for _ in range(args.steps):
+        step()
+    job_stats(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -164,7 +168,7 @@ def main():
     roofline = None
     cpu = None
     if rank == 0:
-        info_np = np.frombuffer(infos[0].cpu().numpy().tobytes(), dtype=flake_amd.INFO_DTYPE)
+        info_np = np.frombuffer(info.cpu().numpy().tobytes(), dtype=flake_amd.INFO_DTYPE)
         rice_bytes = int(((info_np["rice_nbits"].clip(min=0) + 31) // 32 * 4).sum())
         alg_bytes = (nframes * n * p.channels * 4          # int32 PCM in
                      + rice_bytes                          # packed residual sections out
@@ -173,8 +177,8 @@ def main():
         enc.set_profiling(True)
         enc.kernel_times(reset=True)
         for i in range(args.profile_steps):
-            enc.encode_subframes_dev(pcm, nframes, n, infos[0], residual=resid,
-                                     rice_bits=bits[0], slot_bytes=slot)
+            enc.encode_subframes_dev(pcm, nframes, n, info, residual=resid,
+                                     rice_bits=bits, slot_bytes=slot)
         enc.sync()
         kt = enc.kernel_times(reset=True)
         enc.set_profiling(False)
@@ -230,9 +234,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-        if world > 1:
-            out["job_frames"] = int(stats[0].item())
-            out["job_residual_bits"] = int(stats[1].item())
+        out["job_frames"] = int(stats[0].item())
+        out["job_residual_bits"] = int(stats[1].item())
         print(json.dumps(out), flush=True)
 
     enc.close()

@@ -2132,6 +2132,8 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     }
     // HIST zeros in front: columns 0 .. COL0-1 of every row
     if (tid < HIST) l.smp[(tid % C) * SmpImg<C, T>::S + tid / C] = 0;
+    // the first emit window is cleared here, under the shadow of the loads above
+    if (bits_out) for (int q = tid; q < ENC_WWORDS; q += T) l.bits[q] = 0;
     if (pre_row && tid < FHIP_MAX_ORDER) {
         l.coef[tid] = fcoef_n;
         l.coefd[tid] = (double)fcoef_n;
@@ -2344,9 +2346,12 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                 const int nwords = (int)((tot + 31) >> 5);
                 for (int wlo = 0; wlo < nwords; wlo += ENC_WWORDS) {
                     const int nw = min(ENC_WWORDS, nwords - wlo);
-                    __syncthreads();
-                    for (int q = tid; q < nw; q += T) l.bits[q] = 0;
-                    __syncthreads();
+                    if (wlo > 0) {
+                        // later windows reuse the buffer (the first was cleared at the top)
+                        __syncthreads();
+                        for (int q = tid; q < nw; q += T) l.bits[q] = 0;
+                        __syncthreads();
+                    }
                     const long long wbit = (long long)wlo * 32;
                     if (tid == 0) {
                         put_bits32(l.bits, nw, 0 - wbit, 2, (uint32_t)method);

@@ -344,3 +344,19 @@ def test_config4_full_size_properties(oracle, decoder):
         a = enc.encode_subframes(pcm[:nfr // 2], n, want_residual=False, want_bits=False)
         b = enc.encode_subframes(pcm[nfr // 2:], n, want_residual=False, want_bits=False)
     assert np.concatenate([a["info"], b["info"]]).tobytes() == got["info"].tobytes()
+
+
+@pytest.mark.parametrize("n", [1024, 2048, 8192, 16384])
+@pytest.mark.parametrize("kw", [
+    dict(order_method=flake_amd.OM_MAX),
+    dict(order_method=flake_amd.OM_LOG, max_prediction_order=12, max_partition_order=8),
+    dict(order_method=flake_amd.OM_SEARCH, max_prediction_order=32, max_partition_order=8),
+    dict(prediction_type=flake_amd.PRED_FIXED, min_prediction_order=0, max_prediction_order=4),
+], ids=["max8", "log12", "search32", "fixed"])
+def test_every_fast_path_geometry(oracle, n, kw):
+    """k_encode_pow2<C,T>: (4,256) (8,256) (16,512) (16,1024) -- the geometries the
+    4096-sample tests do not reach -- for stereo 16-bit and mono 24-bit."""
+    for ch, bps in ((2, 16), (1, 24)):
+        p = flake_amd.level_params(5, channels=ch, bits_per_sample=bps, block_size=n, **kw)
+        pcm = flake_amd.synth_pcm(3, n, ch, bps, first_frame=n // 256)
+        check(oracle, p, pcm, n, f"n{n}")

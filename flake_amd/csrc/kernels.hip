@@ -157,9 +157,9 @@ __device__ __forceinline__ int c_double_to_int(double x)
 // ---------------------------------------------------------------------------
 // K0  k_prepare
 // ---------------------------------------------------------------------------
-// Stereo: one workgroup per frame, both channels resident in LDS.
-// Otherwise: one workgroup per (frame, channel).
-// LDS: int32[(nch==2 ? 2 : 1) * n].
+// Stereo frames that do not qualify for the register path (n > 4096 or n % 4):
+// one workgroup per frame, both channels resident in LDS (int32[2n]).  Other
+// channel counts go to k_prepare_multi.
 __global__ __launch_bounds__(NT)
 void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
                fhip_subframe_info *__restrict__ info, int n, int nch, int bps, int estimate)
@@ -264,30 +264,6 @@ void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
             o->obits = obits[tid];
             o->wasted = wasted[tid];
             o->ch_mode = mode;
-        }
-    } else {
-        const int f = blockIdx.x / nch, ch = blockIdx.x - f * nch;
-        const int32_t *src = pcm + (size_t)f * n * nch + ch;
-        int32_t *S = lds_i32;
-        uint32_t orv = 0;
-        for (int i = tid; i < n; i += NT) {
-            int32_t v = src[(size_t)i * nch];
-            S[i] = v;
-            orv |= (uint32_t)v;
-        }
-        orv = wave_or_u32(orv);
-        if (lane == 0) s_or[wv][0] = orv;
-        __syncthreads();
-        uint32_t o = s_or[0][0] | s_or[1][0] | s_or[2][0] | s_or[3][0];
-        int w = o ? min(__ffs((int)o) - 1, bps - 1) : bps - 1;
-        if (w == bps - 1) w = 0;
-        int32_t *dst = smp + ((size_t)f * nch + ch) * n;
-        for (int i = tid; i < n; i += NT) dst[i] = S[i] >> w;
-        if (tid == 0) {
-            fhip_subframe_info *oi = &info[(size_t)f * nch + ch];
-            oi->obits = bps - w;
-            oi->wasted = w;
-            oi->ch_mode = FHIP_CH_NOT_STEREO;
         }
     }
 }

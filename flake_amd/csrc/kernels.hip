@@ -1719,8 +1719,9 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 // K3 fast path  k_encode_pow2<C, T>
 // ---------------------------------------------------------------------------
 // Same contract as k_encode, for block sizes n = C*T with T (threads) a power
-// of two, C in {4, 8, 16} samples per thread and every partition at least one
-// thread wide ((n >> pmax) >= C).  Then
+// of two >= 64, C in {3, 4, 8, 9, 16} samples per thread and every partition at
+// least one thread wide ((n >> pmax) >= C): all of FLAC's standard block sizes
+// (192, 576, 1152, 2304, 4608 = 3 or 9 times a power of two; 256 .. 16384).  Then
 //   * no lane ever needs a bounds or partition-boundary test per sample: a
 //     thread's run lies inside one partition of every level;
 //   * the FIR runs as exact fp64 FMAs (|coef| < 2^14, |sample| < 2^31, <= 32
@@ -1740,8 +1741,10 @@ constexpr int HIST = 32;                 // zeroed samples in front of the block
 // 33 KB cost the fourth workgroup per CU: measured 108 vs 96 us.)
 template <int C, int T>
 struct SmpImg {
-    static constexpr int COL0 = HIST / C;
-    static constexpr int S = T + COL0 + 2;           // row stride in doubles (even: b128-aligned rows)
+    // columns of zeros in front: the FIR looks back 32 samples in tap blocks
+    // of 16 (C | 16) or 36 in tap blocks of 9 (C = 3, 9)
+    static constexpr int COL0 = (16 % C == 0) ? HIST / C : (36 + C - 1) / C;
+    static constexpr int S = T + COL0 + 2;           // row stride in words
     static constexpr int SIZE = C * S;
     // offset of sample (run start of thread t) + c, relative to &img[t]
     __host__ __device__ static constexpr int off(int c)
@@ -1796,7 +1799,7 @@ __host__ __device__ inline size_t fast_lds_layout(int n, size_t img_doubles, siz
     (void)n;
     size_t o = 0;
     off[0] = o; o += 8 * 512;                                   // sums
-    off[1] = o; o += 8 * 32;                                    // coefd
+    off[1] = o; o += 8 * 48;                                    // coefd (zero-padded past 32)
     off[2] = o; o += 8 * 16;                                    // wtot
     off[3] = o; o += 4 * img_doubles;                           // smp image (ints)
     off[4] = o; o += 4 * 512;                                   // kpar
@@ -1809,6 +1812,8 @@ __host__ __device__ inline size_t fast_lds_layout(int n, size_t img_doubles, siz
     off[10] = o; o += 4 * ENC_WWORDS;                           // bits
     return o;
 }
+
+constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }
 
 template <int C, int T>
 struct FastCtx {
@@ -1826,8 +1831,12 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
     using Img = SmpImg<C, T>;
     const FastLds &l = e.l;
     const double inv = __builtin_ldexp(1.0, -shift);
-    constexpr int OB = (C < 8) ? C : 8;              // outputs per register block
-    const int32_t *mine = l.smp + e.tid;
+    // outputs per register block: a divisor of C
+    constexpr int OB = (C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : 1;
+    // taps per block: a multiple of C (going back C*k samples is going back k
+    // columns of the image, so every block sees the same immediate offsets)
+    constexpr int TB = (16 % C == 0) ? 16 : C * ((8 + C - 1) / C);
+    const int32_t *mine = l.smp + e.tid;             // column of this thread's run
 #pragma unroll
     for (int ob = 0; ob < C; ob += OB) {
         // keep the register blocks apart: interleaving them only costs VGPRs
@@ -1835,36 +1844,28 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
         double acc[OB];
 #pragma unroll
         for (int o = 0; o < OB; o++) acc[o] = 0.0;
-        // taps in blocks of 16 (tb = 0, 16): going back C*k samples is going back
-        // k columns, so the window of block tb is the window of block 0 read
-        // from a base tb/C columns to the left -- all offsets stay immediates.
 #pragma unroll 1
-        for (int tb = 0; tb < order; tb += 16) {
+        for (int tb = 0; tb < order; tb += TB) {
             const int32_t *base = mine - tb / C;
-            // taps tb+1 .. tb+8 : samples c = ob+o-jj-1, jj = 0..7
-            {
-                double W[OB + 7];
 #pragma unroll
-                for (int m = 0; m < OB + 7; m++) W[m] = (double)base[Img::off(ob - 8 + m)];
+            for (int sb = 0; sb < TB; sb += 8) {
+                constexpr int dummy = 0; (void)dummy;
+                if (order > tb + sb) {
+                    // taps tb+sb+1 .. tb+sb+NT_ : samples c = ob+o-(sb+jj+1)
+                    const int NT_ = (TB - sb < 8) ? TB - sb : 8;
+                    double W[OB + 7];
 #pragma unroll
-                for (int jj = 0; jj < 8; jj++) {
-                    const double cd = l.coefd[tb + jj];
+                    for (int m = 0; m < OB + 7; m++)
+                        if (m < OB + NT_ - 1) W[m] = (double)base[Img::off(ob - sb - NT_ + m)];
 #pragma unroll
-                    for (int o = 0; o < OB; o++)
-                        acc[o] = __builtin_fma(cd, W[o + 7 - jj], acc[o]);
-                }
-            }
-            if (order > tb + 8) {
-                // taps tb+9 .. tb+16
-                double W[OB + 7];
+                    for (int jj = 0; jj < 8; jj++) {
+                        if (jj < NT_) {
+                            const double cd = l.coefd[tb + sb + jj];
 #pragma unroll
-                for (int m = 0; m < OB + 7; m++) W[m] = (double)base[Img::off(ob - 16 + m)];
-#pragma unroll
-                for (int jj = 0; jj < 8; jj++) {
-                    const double cd = l.coefd[tb + 8 + jj];
-#pragma unroll
-                    for (int o = 0; o < OB; o++)
-                        acc[o] = __builtin_fma(cd, W[o + 7 - jj], acc[o]);
+                            for (int o = 0; o < OB; o++)
+                                acc[o] = __builtin_fma(cd, W[o + NT_ - 1 - jj], acc[o]);
+                        }
+                    }
                 }
             }
         }
@@ -1913,7 +1914,7 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
                                                      int order, bool lpc, int *porder_out,
                                                      int *method_out)
 {
-    constexpr int LT = (T == 256) ? 8 : (T == 512) ? 9 : 10;     // log2(T): the thread level
+    constexpr int LT = clog2(T);                      // the thread level
     const FastLds &l = e.l;
     const int n = e.n, tid = e.tid, lane = e.lane;
     const int pmin = clamp_porder(e.pmin_req, n, order);
@@ -2069,13 +2070,23 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     // subframe into registers measured slower: the hardware's own dispatch of a
     // fresh workgroup per subframe balances better and costs no VGPRs).
     const int s = blockIdx.x;
-    int4 xn[C / 4];
+    int32_t xn[C];
     int32_t first_n, obits_n, fcoef_n = 0, fshift_n = 0, forder_n = 0;
     {
         const int32_t *srcp = smp_all + (size_t)s * n;
-        const int4 *src4 = reinterpret_cast<const int4 *>(srcp + e.i0);
+        if (C % 4 == 0) {
+            // 16-byte lane accesses of the thread's own run
+            const int4 *src4 = reinterpret_cast<const int4 *>(srcp + e.i0);
 #pragma unroll
-        for (int q = 0; q < C / 4; q++) xn[q] = src4[q];
+            for (int q = 0; q < C / 4; q++) {
+                const int4 t4 = src4[q];
+                xn[4 * q] = t4.x; xn[4 * q + 1] = t4.y; xn[4 * q + 2] = t4.z; xn[4 * q + 3] = t4.w;
+            }
+        } else {
+            // runs of 3 or 9 samples: coalesced dword loads, element tid + T*q
+#pragma unroll
+            for (int q = 0; q < C; q++) xn[q] = srcp[tid + T * q];
+        }
         first_n = srcp[0];
         obits_n = info[s].obits;
         if (pre_row) {
@@ -2094,22 +2105,22 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     // ---- stage this subframe in LDS ------------------------------------------
     int differs = 0;
     {
-        int32_t x[C];
-#pragma unroll
-        for (int q = 0; q < C / 4; q++) {
-            x[4 * q] = xn[q].x; x[4 * q + 1] = xn[q].y; x[4 * q + 2] = xn[q].z; x[4 * q + 3] = xn[q].w;
-        }
         const int32_t first = first_n;
 #pragma unroll
         for (int o = 0; o < C; o++) {
-            l.smp[tid + SmpImg<C, T>::off(o)] = x[o];
-            differs |= (x[o] != first);
+            const int32_t v = xn[o];
+            // own-run mapping: sample i0 + o; coalesced mapping: sample tid + T*o
+            const int idx = (C % 4 == 0) ? tid + SmpImg<C, T>::off(o)
+                                         : ((tid + T * o) % C) * SmpImg<C, T>::S + (tid + T * o) / C + SmpImg<C, T>::COL0;
+            l.smp[idx] = v;
+            differs |= (v != first);
         }
     }
-    // HIST zeros in front: columns 0 .. COL0-1 of every row
-    if (tid < HIST) l.smp[(tid % C) * SmpImg<C, T>::S + tid / C] = 0;
+    // zeros in front: columns 0 .. COL0-1 of every row
+    if (tid < SmpImg<C, T>::COL0 * C) l.smp[(tid % C) * SmpImg<C, T>::S + tid / C] = 0;
     // the first emit window is cleared here, under the shadow of the loads above
     if (bits_out) for (int q = tid; q < ENC_WWORDS; q += T) l.bits[q] = 0;
+    if (tid < 16) l.coefd[32 + tid] = 0.0;
     if (pre_row && tid < FHIP_MAX_ORDER) {
         l.coef[tid] = fcoef_n;
         l.coefd[tid] = (double)fcoef_n;
@@ -2259,16 +2270,22 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
 
     STAMP(9);
     if (res_out) {
-        int4 *dst4 = reinterpret_cast<int4 *>(res_out + (size_t)s * n + e.i0);
+        if (C % 4 == 0) {
+            int4 *dst4 = reinterpret_cast<int4 *>(res_out + (size_t)s * n + e.i0);
 #pragma unroll
-        for (int q = 0; q < C / 4; q++)
-            dst4[q] = make_int4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+            for (int q = 0; q < C / 4; q++)
+                dst4[q] = make_int4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+        } else {
+            int32_t *dst = res_out + (size_t)s * n + e.i0;
+#pragma unroll
+            for (int o = 0; o < C; o++) dst[o] = r[o];
+        }
     }
 
     // ---- encode.c:766-798 output_residual -----------------------------------
     long long total_bits = 0;
     if (has_rice) {
-        constexpr int LT = (T == 256) ? 8 : (T == 512) ? 9 : 10;
+        constexpr int LT = clog2(T);
         const int pbits = 4 + method;
         const int heap0 = (1 << porder) - 1;
         const int tpp = LT - porder;                       // log2(threads per partition)
@@ -2360,7 +2377,9 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                     };
                     if (part_head) field(pbits, (uint32_t)k);
                     const uint32_t kmask = (1u << k) - 1u;
-                    if (tiny_codes) {
+                    bool packed = false;
+                    if constexpr (C % 2 == 0) { if (tiny_codes) {
+                        packed = true;
                         // every codeword of the wave <= 16 bits: two codewords are
                         // one field of <= 32 bits (half the append/flush work)
 #pragma unroll
@@ -2373,6 +2392,8 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                             const uint32_t v1 = c1 ? ((1u << k) | (u1 & kmask)) : 0u;
                             field(l0 + l1, (v0 << l1) | v1);
                         }
+                    } }
+                    if (packed) {
                     } else if (short_codes) {
                         // bitio.h:120-141: q zeros, a one, k low bits -- as one field
                         // of q+k+1 <= 32 bits; warm-up samples are zero-length fields
@@ -2430,11 +2451,11 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     if (tid < FHIP_MAX_ORDER) {
         out->coefs[tid] = (type == FHIP_SUB_LPC && tid < order) ? l.coef[tid] : 0;
         const int nw = (type == FHIP_SUB_CONSTANT) ? 1 : order;
-        out->warmup[tid] = (tid < nw) ? (int32_t)l.smp[(tid % C) * SmpImg<C, T>::S + tid / C + SmpImg<C, T>::COL0] : 0;
+        out->warmup[tid] = (tid < nw) ? l.smp[(tid % C) * SmpImg<C, T>::S + tid / C + SmpImg<C, T>::COL0] : 0;
     }
-    if (tid < FHIP_MAX_PARTS) {
+    {
         const int np = has_rice ? (1 << porder) : 0;
-        out->rparams[tid] = (tid < np) ? l.kpar[np - 1 + tid] : 0;
+        for (int q = tid; q < FHIP_MAX_PARTS; q += T) out->rparams[q] = (q < np) ? l.kpar[np - 1 + q] : 0;
     }
   }
 }
@@ -2921,17 +2942,32 @@ size_t encode_lds_bytes(int n)
     return enc_lds_layout(n, off);
 }
 
-// Fast-path geometry for a block size: C samples per thread, T threads.
+// Fast-path geometry for a block size: C samples per thread, T threads,
+// n = C*T, T a power of two >= 64.
 static bool fast_geometry(const fhip_params &p, int n, int *C, int *T)
 {
-    if (n < 1024 || n > FHIP_MAX_BLOCK || (n & (n - 1))) return false;
-    int c = 16, t = n / 16;
-    if (n == 1024) { c = 4; t = 256; }
-    else if (n == 2048) { c = 8; t = 256; }
-    if (t != 256 && t != 512 && t != 1024) return false;
+    if (n < 192 || n > FHIP_MAX_BLOCK) return false;
+    int odd = n, lg = 0;
+    while ((odd & 1) == 0) { odd >>= 1; lg++; }
+    int c, t;
+    if (odd == 1) {                       // 256 .. 16384
+        if (n >= 4096) { c = 16; t = n / 16; }
+        else if (n >= 2048) { c = 8; t = 256; }
+        else if (n >= 1024) { c = 4; t = 256; }
+        else if (n == 512) { c = 8; t = 64; }
+        else if (n == 256) { c = 4; t = 64; }
+        else return false;
+    } else if (odd == 9) {                // 576, 1152, 2304, 4608, 9216
+        c = 9; t = 1 << lg;
+    } else if (odd == 3) {                // 192, 384, 768, 1536, ...
+        c = 3; t = 1 << lg;
+        if (t > 1024) { c = 0; }
+    } else {
+        return false;
+    }
+    if (c == 0 || t < 64 || t > 1024) return false;
     // every partition at least one thread wide at the finest level that can occur
-    int pmax = p.max_partition_order;
-    if ((n >> pmax) < c) return false;
+    if ((n >> p.max_partition_order) < c && odd == 1) return false;
     *C = c; *T = t;
     return true;
 }
@@ -2945,14 +2981,13 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
 {
     if (nsub == 0) return hipSuccess;
     int fc = 0, ft = 0;
-    if (raw_order < 0 && fast_geometry(p, n, &fc, &ft)) {
+    static const bool force_generic = getenv("FHIP_K3_GENERIC") != nullptr;    // measurements only
+    if (raw_order < 0 && !force_generic && fast_geometry(p, n, &fc, &ft)) {
         size_t off[11];
-        const size_t img = (fc == 4) ? (size_t)SmpImg<4, 256>::SIZE : (fc == 8) ? (size_t)SmpImg<8, 256>::SIZE
-                         : (ft == 256) ? (size_t)SmpImg<16, 256>::SIZE : (ft == 512) ? (size_t)SmpImg<16, 512>::SIZE
-                         : (size_t)SmpImg<16, 1024>::SIZE;
-        const size_t lds = fast_lds_layout(n, img, off);
+        size_t lds = 0;
 #define LAUNCH_FAST(CC, TT)                                                                  \
     do {                                                                                     \
+        lds = fast_lds_layout(n, (size_t)SmpImg<CC, TT>::SIZE, off);                         \
         hipError_t er = hipFuncSetAttribute(                                                 \
             reinterpret_cast<const void *>(&k_encode_pow2<CC, TT>),                          \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
@@ -2961,11 +2996,27 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
                            nsub, smp, coefs, shift, opt_order, fin, info, residual, bits,    \
                            (long long)slot_bytes);                                           \
     } while (0)
-        if (fc == 4) LAUNCH_FAST(4, 256);
-        else if (fc == 8) LAUNCH_FAST(8, 256);
-        else if (ft == 256) LAUNCH_FAST(16, 256);
-        else if (ft == 512) LAUNCH_FAST(16, 512);
-        else LAUNCH_FAST(16, 1024);
+        const int key = fc * 10000 + ft;
+        switch (key) {
+        case 160256: LAUNCH_FAST(16, 256); break;
+        case 160512: LAUNCH_FAST(16, 512); break;
+        case 161024: LAUNCH_FAST(16, 1024); break;
+        case 80256: LAUNCH_FAST(8, 256); break;
+        case 40256: LAUNCH_FAST(4, 256); break;
+        case 80064: LAUNCH_FAST(8, 64); break;
+        case 40064: LAUNCH_FAST(4, 64); break;
+        case 90064: LAUNCH_FAST(9, 64); break;
+        case 90128: LAUNCH_FAST(9, 128); break;
+        case 90256: LAUNCH_FAST(9, 256); break;
+        case 90512: LAUNCH_FAST(9, 512); break;
+        case 91024: LAUNCH_FAST(9, 1024); break;
+        case 30064: LAUNCH_FAST(3, 64); break;
+        case 30128: LAUNCH_FAST(3, 128); break;
+        case 30256: LAUNCH_FAST(3, 256); break;
+        case 30512: LAUNCH_FAST(3, 512); break;
+        case 31024: LAUNCH_FAST(3, 1024); break;
+        default: return hipErrorInvalidValue;
+        }
 #undef LAUNCH_FAST
         return hipGetLastError();
     }

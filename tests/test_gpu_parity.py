@@ -346,7 +346,8 @@ def test_config4_full_size_properties(oracle, decoder):
     assert np.concatenate([a["info"], b["info"]]).tobytes() == got["info"].tobytes()
 
 
-@pytest.mark.parametrize("n", [1024, 2048, 8192, 16384])
+@pytest.mark.parametrize("n", [192, 256, 384, 512, 576, 768, 1024, 1152, 1536, 2048, 2304, 3072,
+                               4608, 6144, 8192, 9216, 12288, 16384])
 @pytest.mark.parametrize("kw", [
     dict(order_method=flake_amd.OM_MAX),
     dict(order_method=flake_amd.OM_LOG, max_prediction_order=12, max_partition_order=8),
@@ -354,9 +355,10 @@ def test_config4_full_size_properties(oracle, decoder):
     dict(prediction_type=flake_amd.PRED_FIXED, min_prediction_order=0, max_prediction_order=4),
 ], ids=["max8", "log12", "search32", "fixed"])
 def test_every_fast_path_geometry(oracle, n, kw):
-    """k_encode_pow2<C,T>: (4,256) (8,256) (16,512) (16,1024) -- the geometries the
-    4096-sample tests do not reach -- for stereo 16-bit and mono 24-bit."""
-    for ch, bps in ((2, 16), (1, 24)):
+    """k_encode_pow2<C,T>: every (C,T) the launcher can pick -- C = 4, 8, 16 for
+    powers of two, C = 9 and 3 for FLAC's 576/1152/2304/4608 and 192/384/... -- for
+    stereo 16-bit, mono 24-bit and (wide residuals, long codewords) mono 32-bit."""
+    for ch, bps in ((2, 16), (1, 24), (1, 32)):
         p = flake_amd.level_params(5, channels=ch, bits_per_sample=bps, block_size=n, **kw)
         pcm = flake_amd.synth_pcm(3, n, ch, bps, first_frame=n // 256)
         check(oracle, p, pcm, n, f"n{n}")

@@ -32,6 +32,8 @@ if __name__ == "__main__":
     run("c2 bits", c2)
     run("c2 nobits", c2, bits=False)
     run("c2 bits+resid", c2, resid=True)
+    for bs in (1152, 4608, 576, 256):
+        run(f"lvl5 n={bs}", P(5, block_size=bs, order_method=flake_amd.OM_MAX), nframes=4096 * 4096 // bs)
     run("c2 fixed", P(2, block_size=4096))
     run("c2 est", P(5))
     run("lvl8 log12", P(8), nframes=1024)

@@ -1922,8 +1922,8 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
 
     // thread-level sum; partition 0 of every level starts at `order` (rice.c:85-94)
     unsigned long long v;
-    if (e.obits <= 27) {
-        // C <= 16 folded values below 2^28 each: the thread's sum fits 32 bits
+    if (e.obits <= 31 - clog2(C)) {
+        // C folded values below 2^(32 - log2 C) each: the thread's sum fits 32 bits
         uint32_t v32 = 0;
 #pragma unroll
         for (int o = 0; o < C; o++) v32 += (e.i0 + o >= order) ? zigzag32(r[o]) : 0u;
@@ -2031,6 +2031,8 @@ template <int C, int T>
 // 4 waves per SIMD (<= 128 VGPRs): four 256-thread workgroups per CU.  The
 // kernel is latency-bound (a dozen dependent phases), so the fourth workgroup
 // is worth 12 %; a fifth needs <= 96 VGPRs and spills (measured 125 us vs 96).
+// Geometry for n = 4096, measured: (C,T) = (16,256) 94 us, (8,512) 137, (4,1024)
+// 256, (32,128) 115 (206 VGPRs): cross-wave phases grow with T, serial ones with C.
 __global__ __launch_bounds__(T, 4)   // VGPR cap per waves/SIMD: 2 -> 256, 3 -> 168, 4 -> 128
 void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ smp_all,
                    const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,

@@ -30,6 +30,8 @@ if __name__ == "__main__":
     P = flake_amd.level_params
     c2 = P(5, order_method=flake_amd.OM_MAX)
     run("c2 bits", c2)
+    if "--quick" in sys.argv:
+        sys.exit(0)
     run("c2 nobits", c2, bits=False)
     run("c2 bits+resid", c2, resid=True)
     for bs in (1152, 4608, 576, 256):

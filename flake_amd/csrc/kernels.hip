@@ -1871,48 +1871,60 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
         }
 #pragma unroll
         for (int o = 0; o < OB; o++) {
-            // pred >> shift == floor(pred * 2^-shift); (int32)(x - that) = low 32 bits
-            const double xd = (double)mine[Img::off(ob + o)];
-            const double q = __builtin_floor(acc[o] * inv);
-            const double d = xd - q;
-            const double hi = __builtin_floor(d * (1.0 / 4294967296.0));
-            const double lo = __builtin_fma(-hi, 4294967296.0, d);
-            const int32_t v = (int32_t)(uint32_t)lo;
-            r[ob + o] = (e.i0 + ob + o < order) ? (int32_t)xd : v;
+            // pred >> shift == floor(pred * 2^-shift).  The kernel runs with the
+            // fp64 rounding mode "toward -inf" (set_round_down): acc * 2^-shift is
+            // exact, |.| < 2^51, so the one rounding of fma(acc, 2^-shift, 1.5 * 2^52)
+            // is that floor, and the low mantissa word is the floor's low 32 bits in
+            // two's complement.  (int32)(x - (pred >> shift)) only needs those.
+            const double z = __builtin_fma(acc[o], inv, 6755399441055744.0);
+            const uint32_t qlo = (uint32_t)__double2loint(z);
+            r[ob + o] = (int32_t)((uint32_t)mine[Img::off(ob + o)] - qlo);
         }
+    }
+    // warm-up samples pass through (optimize.c:84-86): only the first threads
+    if (e.i0 < order) {
+#pragma unroll
+        for (int o = 0; o < C; o++)
+            if (e.i0 + o < order) r[o] = mine[Img::off(o)];
     }
 }
 
-// optimize.c:34-68 encode_residual_fixed on the thread's run
+// optimize.c:34-68 encode_residual_fixed on the thread's run.  The reference
+// computes in long long and stores to int32: the low 32 bits, which wrapping
+// 32-bit arithmetic yields directly.
 template <int C, int T>
 __device__ __forceinline__ void fir_fixed(const FastCtx<C, T> &e, int32_t (&r)[C], int order)
 {
     using Img = SmpImg<C, T>;
     const FastLds &l = e.l;
     const int32_t *mine = l.smp + e.tid;
-    long long h[4];
+    uint32_t h[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) h[k] = (long long)mine[Img::off(-1 - k)];
+    for (int k = 0; k < 4; k++) h[k] = (uint32_t)mine[Img::off(-1 - k)];
 #pragma unroll
     for (int o = 0; o < C; o++) {
-        const int32_t xo = (int32_t)mine[Img::off(o)];
-        const long long x0 = xo;
-        long long acc;
+        const uint32_t x0 = (uint32_t)mine[Img::off(o)];
+        uint32_t acc;
         if (order == 0) acc = x0;
         else if (order == 1) acc = x0 - h[0];
-        else if (order == 2) acc = x0 - 2 * h[0] + h[1];
-        else if (order == 3) acc = x0 - 3 * h[0] + 3 * h[1] - h[2];
-        else acc = x0 - 4 * h[0] + 6 * h[1] - 4 * h[2] + h[3];
-        r[o] = (e.i0 + o < order) ? xo : (int32_t)acc;
+        else if (order == 2) acc = x0 - 2u * h[0] + h[1];
+        else if (order == 3) acc = x0 - 3u * h[0] + 3u * h[1] - h[2];
+        else acc = x0 - 4u * h[0] + 6u * h[1] - 4u * h[2] + h[3];
+        r[o] = (int32_t)acc;
         h[3] = h[2]; h[2] = h[1]; h[1] = h[0]; h[0] = x0;
+    }
+    if (e.i0 < order) {
+#pragma unroll
+        for (int o = 0; o < C; o++)
+            if (e.i0 + o < order) r[o] = mine[Img::off(o)];
     }
 }
 
 // rice.c:105-187 on the residuals in r[]; all threads call it.
 template <int C, int T>
 __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, const int32_t (&r)[C],
-                                                     int order, bool lpc, int *porder_out,
-                                                     int *method_out)
+                                                     uint32_t (&u)[C], int order, bool lpc,
+                                                     int *porder_out, int *method_out)
 {
     constexpr int LT = clog2(T);                      // the thread level
     const FastLds &l = e.l;
@@ -1920,18 +1932,28 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
     const int pmin = clamp_porder(e.pmin_req, n, order);
     const int pmax = clamp_porder(e.pmax_req, n, order);
 
-    // thread-level sum; partition 0 of every level starts at `order` (rice.c:85-94)
+    // rice.c:122 folded residuals.  They stay in registers for the emit; the
+    // warm-up samples (partition 0 of every level starts at `order`, rice.c:85-94)
+    // are zeroed, which only the first threads have to do.
+#pragma unroll
+    for (int o = 0; o < C; o++) u[o] = zigzag32(r[o]);
+    if (e.i0 < order) {
+#pragma unroll
+        for (int o = 0; o < C; o++)
+            if (e.i0 + o < order) u[o] = 0u;
+    }
+    // thread-level sum
     unsigned long long v;
     if (e.obits <= 31 - clog2(C)) {
         // C folded values below 2^(32 - log2 C) each: the thread's sum fits 32 bits
         uint32_t v32 = 0;
 #pragma unroll
-        for (int o = 0; o < C; o++) v32 += (e.i0 + o >= order) ? zigzag32(r[o]) : 0u;
+        for (int o = 0; o < C; o++) v32 += u[o];
         v = v32;
     } else {
         v = 0;
 #pragma unroll
-        for (int o = 0; o < C; o++) v += (e.i0 + o >= order) ? zigzag32(r[o]) : 0u;
+        for (int o = 0; o < C; o++) v += u[o];
     }
 
     // (callers guarantee a barrier between the previous search's reads of
@@ -2057,6 +2079,12 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     e.l.bits = reinterpret_cast<uint32_t *>(lds_raw + off[10]);
     const FastLds &l = e.l;
 
+    // fp64 rounding toward -inf for the whole kernel (MODE[3:2] = 2): every fp64
+    // operation in here is exact except the one fma in fir_lpc that wants a floor.
+    // As inline asm: after the builtin the compiler re-asserts the default mode in
+    // front of the next fp64 instruction.
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2" ::: "memory");
+
     const int tid = threadIdx.x;
     e.n = n; e.tid = tid; e.lane = tid & 63; e.wv = tid >> 6;
     e.i0 = tid * C;
@@ -2130,7 +2158,8 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     const bool constant = (__syncthreads_or(differs) == 0);
     STAMP(1);
 
-    int32_t r[C];
+    int32_t r[C];                        // residuals of the current candidate
+    uint32_t u[C];                       // ... folded (rice.c:122), warm-up zeroed: what the emit reads
     int type, type_code, order = 0, shift = 0;
     uint32_t est_bits = 0;
     bool has_rice = false;
@@ -2172,7 +2201,6 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     if (tree == T_CONST || tree == T_VERB) {
         type = type_code = (tree == T_CONST) ? FHIP_SUB_CONSTANT : FHIP_SUB_VERBATIM;
         est_bits = (uint32_t)(tree == T_CONST ? e.obits : e.obits * n);
-        fir_fixed<C, T>(e, r, 0);
     } else {
         for (;;) {
             int cand = -1;
@@ -2213,7 +2241,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
             if (tree == T_FIXED) {
                 fir_fixed<C, T>(e, r, cand);
                 __syncthreads();                      // previous search fully read
-                b = rice_search_fast<C, T>(e, r, cand, false, &porder, &method);
+                b = rice_search_fast<C, T>(e, r, u, cand, false, &porder, &method);
             } else {
                 const int ord = cand + 1;
                 int cshift;
@@ -2232,7 +2260,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                 STAMP(2);
                 fir_lpc<C, T>(e, r, ord, cshift);
                 STAMP(3);
-                b = rice_search_fast<C, T>(e, r, ord, true, &porder, &method);
+                b = rice_search_fast<C, T>(e, r, u, ord, true, &porder, &method);
                 STAMP(8);
             }
             if (final_pass) { est_bits = b; break; }
@@ -2272,6 +2300,14 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
 
     STAMP(9);
     if (res_out) {
+        // FlacSubframe.residual: the samples themselves for CONSTANT / VERBATIM and
+        // for warm-up positions, else the fold undone (a bijection on 32 bits)
+        const int32_t *mine_s = l.smp + tid;
+#pragma unroll
+        for (int o = 0; o < C; o++) {
+            const int32_t back = (int32_t)((u[o] >> 1) ^ (0u - (u[o] & 1u)));
+            r[o] = (!has_rice || e.i0 + o < order) ? mine_s[SmpImg<C, T>::off(o)] : back;
+        }
         if (C % 4 == 0) {
             int4 *dst4 = reinterpret_cast<int4 *>(res_out + (size_t)s * n + e.i0);
 #pragma unroll
@@ -2293,26 +2329,34 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
         const int tpp = LT - porder;                       // log2(threads per partition)
         const int part = tid >> tpp;
         const int k = l.kpar[heap0 + part];
+        const int k1 = k + 1;
         const bool part_head = (part > 0) && ((tid & ((1 << tpp) - 1)) == 0);
-        // codeword lengths of the run; in 32 bits unless a quotient is huge
-        uint32_t longest = 0;
+        // warm-up samples at the front of this thread's run (first threads only)
+        const int nwarm = min(max(order - e.i0, 0), C);
+        // the emit-side fold (bitio.h:128) differs from rice.c's for |x| >= 2^30
+        if (e.obits > 30) {
 #pragma unroll
-        for (int o = 0; o < C; o++)
-            longest = max(longest, (e.i0 + o >= order) ? (emit_fold32(r[o]) >> k) : 0u);
+            for (int o = 0; o < C; o++)
+                u[o] = emit_fold32((int32_t)((u[o] >> 1) ^ (0u - (u[o] & 1u)))) & ((e.i0 + o < order) ? 0u : ~0u);
+        }
+        // codeword lengths of the run; in 32 bits unless a quotient is huge.
+        // A zeroed warm-up entry counts k+1 bits here, taken off again below.
+        uint32_t umax = 0;
+#pragma unroll
+        for (int o = 0; o < C; o++) umax = max(umax, u[o]);
+        const uint32_t longest = umax >> k;
         // every codeword of the wave at most 32 bits: one flush test per codeword
-        const bool short_codes = !__any(longest + (uint32_t)k + 1u > 32u);
-        const bool tiny_codes = (C % 2 == 0) && !__any(longest + (uint32_t)k + 1u > 16u);
-        unsigned long long mine = part_head ? pbits : 0;
+        const bool short_codes = !__any(longest + (uint32_t)k1 > 32u);
+        const bool tiny_codes = (C % 2 == 0) && !__any(longest + (uint32_t)k1 > 16u);
+        unsigned long long mine = (part_head ? pbits : 0) + (unsigned long long)((C - nwarm) * k1);
         if (short_codes) {
             uint32_t m32 = 0;
 #pragma unroll
-            for (int o = 0; o < C; o++)
-                m32 += (e.i0 + o >= order) ? ((emit_fold32(r[o]) >> k) + 1u + (uint32_t)k) : 0u;
+            for (int o = 0; o < C; o++) m32 += u[o] >> k;
             mine += m32;
         } else {
 #pragma unroll
-            for (int o = 0; o < C; o++)
-                mine += (e.i0 + o >= order) ? ((unsigned long long)(emit_fold32(r[o]) >> k) + 1 + k) : 0ull;
+            for (int o = 0; o < C; o++) mine += (unsigned long long)(u[o] >> k);
         }
         // in-wave offsets: DPP scan in 32 bits unless some lane of the wave
         // holds an absurdly long run (then the exact 64-bit shuffle scan)
@@ -2339,6 +2383,14 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
             } else {
                 uint32_t *dst32 = reinterpret_cast<uint32_t *>(bits_out + (size_t)s * slot_bytes);
                 const int nwords = (int)((tot + 31) >> 5);
+                // Every thread writes all C codewords, unconditionally.  A zeroed
+                // warm-up entry is the k+1-bit code of 0; the run of a thread that
+                // has some starts that many bits early, so those land in front of
+                // the thread's first real codeword -- i.e. in bits [.., 6+pbits) of
+                // the section (only threads at the start of partition 0 have warm-up
+                // samples), which thread 0 overwrites with the section header after
+                // the barrier.
+                const long long start = (long long)my_off - (long long)(nwarm * k1);
                 for (int wlo = 0; wlo < nwords; wlo += ENC_WWORDS) {
                     const int nw = min(ENC_WWORDS, nwords - wlo);
                     if (wlo > 0) {
@@ -2347,38 +2399,32 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                         for (int q = tid; q < nw; q += T) l.bits[q] = 0;
                         __syncthreads();
                     }
-                    const long long wbit = (long long)wlo * 32;
-                    if (tid == 0) {
-                        put_bits32(l.bits, nw, 0 - wbit, 2, (uint32_t)method);
-                        put_bits32(l.bits, nw, 2 - wbit, 4, (uint32_t)porder);
-                        put_bits32(l.bits, nw, 6 - wbit, pbits, (uint32_t)l.kpar[heap0]);
-                    }
+                    const long long rel = start - (long long)wlo * 32;
                     // The thread's codewords form one contiguous bit run.  It is
                     // assembled MSB-first in a 32-bit register and leaves a word at
                     // a time by LDS OR (the run's first and last word are shared
                     // with the neighbours; OR-ing the interior ones too costs the
                     // same LDS issue slot as a store and needs no bookkeeping).
                     uint32_t hi = 0;
-                    int nacc = (int)(my_off & 31);
-                    int w = (int)((long long)(my_off >> 5) - wlo);
-                    // append a field of len <= 32 bits (val < 2^len); at most one word leaves
+                    int nacc = (int)(rel & 31);
+                    int w = (int)(rel >> 5);
+                    // append a field of len <= 32 bits (val < 2^len; len 0 => val 0);
+                    // at most one word leaves
                     auto field = [&](int len, uint32_t val) {
+                        const uint32_t a = val << ((32 - len) & 31);        // left-aligned
+                        const uint32_t head = a >> nacc;
+                        // a << (32 - nacc), and 0 for nacc == 0
+                        const uint32_t tail = __builtin_amdgcn_alignbit(a, 0u, (uint32_t)nacc);
                         const int t = nacc + len;
-                        const int spill = t - 32;                       // > 0: the field straddles
-                        const uint32_t head = (spill > 0) ? (val >> spill) : (val << ((32 - t) & 31));
-                        const uint32_t word = hi | ((t == 32 || spill > 0 || t < 32) ? head : 0u);
-                        if (t >= 32) {
-                            if ((unsigned)w < (unsigned)nw) atomicOr(&l.bits[w], word);
-                            hi = (spill > 0) ? (val << (32 - spill)) : 0u;
-                            nacc = spill;
-                            w++;
-                        } else {
-                            hi = word;
-                            nacc = t;
-                        }
+                        const uint32_t word = hi | head;
+                        const bool full = t >= 32;
+                        if (full && (unsigned)w < (unsigned)nw) atomicOr(&l.bits[w], word);
+                        hi = full ? tail : word;
+                        w += full ? 1 : 0;
+                        nacc = t & 31;
                     };
                     if (part_head) field(pbits, (uint32_t)k);
-                    const uint32_t kmask = (1u << k) - 1u;
+                    const uint32_t kmask = (1u << k) - 1u, kbit = 1u << k;
                     bool packed = false;
                     if constexpr (C % 2 == 0) { if (tiny_codes) {
                         packed = true;
@@ -2386,50 +2432,46 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                         // one field of <= 32 bits (half the append/flush work)
 #pragma unroll
                         for (int o = 0; o < C; o += 2) {
-                            const bool c0 = (e.i0 + o >= order), c1 = (e.i0 + o + 1 >= order);
-                            const uint32_t u0 = emit_fold32(r[o]), u1 = emit_fold32(r[o + 1]);
-                            const int l0 = c0 ? (int)(u0 >> k) + k + 1 : 0;
-                            const int l1 = c1 ? (int)(u1 >> k) + k + 1 : 0;
-                            const uint32_t v0 = c0 ? ((1u << k) | (u0 & kmask)) : 0u;
-                            const uint32_t v1 = c1 ? ((1u << k) | (u1 & kmask)) : 0u;
-                            field(l0 + l1, (v0 << l1) | v1);
+                            const int l1 = (int)(u[o + 1] >> k) + k1;
+                            const uint32_t v0 = (u[o] & kmask) | kbit, v1 = (u[o + 1] & kmask) | kbit;
+                            field((int)(u[o] >> k) + k1 + l1, (v0 << l1) | v1);
                         }
                     } }
                     if (packed) {
                     } else if (short_codes) {
                         // bitio.h:120-141: q zeros, a one, k low bits -- as one field
-                        // of q+k+1 <= 32 bits; warm-up samples are zero-length fields
+                        // of q+k+1 <= 32 bits
 #pragma unroll
-                        for (int o = 0; o < C; o++) {
-                            const bool coded = (e.i0 + o >= order);
-                            const uint32_t u = emit_fold32(r[o]);
-                            const int len = coded ? (int)(u >> k) + k + 1 : 0;
-                            const uint32_t val = coded ? ((1u << k) | (u & kmask)) : 0u;
-                            field(len, val);
-                        }
+                        for (int o = 0; o < C; o++)
+                            field((int)(u[o] >> k) + k1, (u[o] & kmask) | kbit);
                     } else {
 #pragma unroll 2
                         for (int o = 0; o < C; o++) {
-                            if (e.i0 + o >= order) {
-                                const uint32_t u = emit_fold32(r[o]);
-                                uint32_t q = u >> k;
-                                if (q >= 32u) {
-                                    // long unary run: the pending word leaves, whole zero
-                                    // words are skipped (the window is zero-filled)
-                                    const long long adv = (long long)nacc + q;
-                                    if (hi && (unsigned)w < (unsigned)nw) atomicOr(&l.bits[w], hi);
-                                    hi = 0;
-                                    w += (int)(adv >> 5);
-                                    nacc = (int)(adv & 31);
-                                } else {
-                                    field((int)q, 0u);
-                                }
-                                field(k + 1, (1u << k) | (u & kmask));
+                            const uint32_t q = u[o] >> k;
+                            if (q >= 32u) {
+                                // long unary run: the pending word leaves, whole zero
+                                // words are skipped (the window is zero-filled)
+                                const long long adv = (long long)nacc + q;
+                                if (hi && (unsigned)w < (unsigned)nw) atomicOr(&l.bits[w], hi);
+                                hi = 0;
+                                w += (int)(adv >> 5);
+                                nacc = (int)(adv & 31);
+                            } else {
+                                field((int)q, 0u);
                             }
+                            field(k1, (u[o] & kmask) | kbit);
                         }
                     }
                     if (nacc > 0 && hi && (unsigned)w < (unsigned)nw) atomicOr(&l.bits[w], hi);
                     __syncthreads();
+                    if (tid == 0 && wlo == 0) {
+                        // section header (encode.c:771-776): method, partition order,
+                        // first parameter; replaces whatever warm-up filler landed there
+                        const int hb = 6 + pbits;
+                        const uint32_t hdr = ((uint32_t)method << (4 + pbits)) | ((uint32_t)porder << pbits) |
+                                             (uint32_t)l.kpar[heap0];
+                        l.bits[0] = (l.bits[0] & (0xFFFFFFFFu >> hb)) | (hdr << (32 - hb));
+                    }
                     STAMP(11);
                     for (int q = tid; q < nw; q += T)
                         dst32[wlo + q] = __builtin_bswap32(l.bits[q]);

@@ -16,6 +16,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 #ifdef FHIP_STAMPS
 // Diagnostic build only (tools/stamps.py): phase time stamps of workgroup 0.
@@ -860,6 +861,231 @@ void k_autocorr_ps(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                 buf[q * PS_STRIDE + (rr / PS_HH) * PS_ROW + (rr % PS_HH)] = hv[r];
             }
         }
+    }
+    // lpc.c:68: autoc = temp + temp2 -- the two parities of a lag group are
+    // neighbouring lanes
+    const double o0 = __shfl_xor(S0, 1, WAVE), o1 = __shfl_xor(S1, 1, WAVE), o2 = __shfl_xor(S2, 1, WAVE);
+    if (chain && pi == 0) {
+        double *dst = autoc + (size_t)(s0 + g) * FHIP_MAX_LAGS;
+        dst[l0] = S0 + o0;
+        if (ok1) dst[l0 + 2] = S1 + o1;
+        if (ok2) dst[l0 + 4] = S2 + o2;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1 (producer/consumer)  k_autocorr_pc
+// ---------------------------------------------------------------------------
+// k_autocorr_ps with the two halves of its loop body on different waves.  PMC
+// showed the one-wave-per-SIMD walk spending 40 % of its cycles parked (global
+// loads, LDS round trips of the staging) and 25 % of its vector instructions
+// outside the chains.  Here a workgroup is four wave pairs: the consumer of a
+// pair (waves 0-3, one per SIMD) only walks -- LDS operand reads and the ordered
+// mul/add chains -- while its producer (waves 4-7, again one per SIMD) loads the
+// samples two tiles ahead, windows them and writes the fp64 tile.  Tiles live in
+// a ring of three LDS buffers per pair: while the consumer walks buffer t%3 (and
+// its halo), the producer fills buffer (t+1)%3 and the halo of buffer (t+2)%3
+// with the same values (the last 32 positions of a tile are the next tile's
+// halo).  One workgroup barrier per tile hands a tile over; the arithmetic, its
+// order and the lane mapping are those of k_autocorr_ps.
+constexpr int PC_PAIRS = 4;
+constexpr int PC_NBUF = 3;
+constexpr int PC_BUF = PS_GMAX * PS_STRIDE;          // doubles per tile buffer
+
+template <int DBG>
+__global__ __launch_bounds__(2 * PC_PAIRS * WAVE)
+void k_autocorr_pc(const int32_t *__restrict__ smp, double *__restrict__ autoc,
+                   int nsub, int n, int maxlag, int G, int lps, int ge, double c)
+{
+    extern __shared__ __attribute__((aligned(16))) double pc_lds[];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const bool producer = wv >= PC_PAIRS;
+    const int pair = wv & (PC_PAIRS - 1);
+    double *ring = pc_lds + (size_t)pair * PC_NBUF * PC_BUF;
+    const int s0 = (blockIdx.x * PC_PAIRS + pair) * G;   // >= nsub: the pair idles through the barriers
+    const int half = n >> 1;
+    const int ntiles = (n + AC_TILE - 1) / AC_TILE;
+    const int ntiles_pad = ((ntiles + 2) / 3) * 3;      // the producer's unroll; both roles run this many barriers
+    // position tb + x sits in parity array (x & 1) at index PS_HH + x/2
+    auto slot = [&](int q, int x) { return q * PS_STRIDE + (x & 1) * PS_ROW + PS_HH + (x >> 1); };
+
+    if (producer) {
+        // lane = position inside the tile (two per lane), so a window weight is
+        // computed once per lane and tile and serves all subframes of the pair.
+        // PC_AHEAD tiles of loads are in flight per wave (48 dwords per lane); the
+        // loop is unrolled by that depth so every tile has its own registers, and
+        // it has no branches, so the waits stay counted (vmcnt(N), never 0).
+        constexpr int PC_AHEAD = 3;
+        const int32_t *rowp[PS_GMAX];
+#pragma unroll
+        for (int q = 0; q < PS_GMAX; q++) rowp[q] = smp + (size_t)min(s0 + q, nsub - 1) * n;
+        int32_t pre[PC_AHEAD][PS_GMAX][AC_PER_LANE];
+        auto issue_loads = [&](int32_t (&dst)[PS_GMAX][AC_PER_LANE], int tb) {
+#pragma unroll
+            for (int q = 0; q < PS_GMAX; q++)
+#pragma unroll
+                for (int u = 0; u < AC_PER_LANE; u++)
+                    dst[q][u] = (DBG == 5) ? rowp[0][min((tb / AC_TILE) * (PS_GMAX * AC_TILE) + (q * AC_PER_LANE + u) * WAVE + lane, PS_GMAX * n - 1)]   // timing probe: one contiguous 4 KB per tile
+                                           : rowp[q][min(tb + u * WAVE + lane, n - 1)];
+        };
+#pragma unroll
+        for (int a = 0; a < PC_AHEAD; a++) issue_loads(pre[a], a * AC_TILE);
+        // the halo of the first tile is zeros (positions -32 .. -1)
+        for (int idx = lane; idx < PS_GMAX * 2 * PS_HH; idx += WAVE) {
+            const int qq = idx / (2 * PS_HH), r = idx - qq * 2 * PS_HH;
+            ring[qq * PS_STRIDE + (r / PS_HH) * PS_ROW + (r % PS_HH)] = 0.0;
+        }
+        int bi = 0;                                        // t % 3
+        for (int t0 = 0; t0 < ntiles_pad; t0 += PC_AHEAD) {
+#pragma unroll
+            for (int a = 0; a < PC_AHEAD; a++) {
+                const int tb = (t0 + a) * AC_TILE;
+                double *bw = ring + bi * PC_BUF;
+                const int bnx = (bi == PC_NBUF - 1) ? 0 : bi + 1;
+                double *bn = ring + bnx * PC_BUF;
+                // ---- window the tile (lpc.c:28-40), de-interleaved by parity ----
+#pragma unroll
+                for (int u = 0; u < AC_PER_LANE; u++) {
+                    const int x = u * WAVE + lane;
+                    const int p = tb + x;
+                    const int ii = (p < half) ? p : (n - 1 - p);
+                    const bool valid = (p < n) && (ii < half);
+                    const double tt = c - (double)ii;
+                    const double w = valid ? (1.0 - (tt * tt)) : 0.0;
+                    const bool tail = x >= AC_TILE - AC_HALO;
+#pragma unroll
+                    for (int q = 0; q < PS_GMAX; q++) {
+                        const double v = (double)pre[a][q][u] * w;
+                        bw[slot(q, x)] = v;
+                        if (tail) bn[slot(q, x) - PS_HALF] = v;      // = position x - AC_TILE of the next tile
+                    }
+                }
+                if (DBG != 6) issue_loads(pre[a], tb + PC_AHEAD * AC_TILE);   // 6: timing probe without loads
+                __syncthreads();                               // tile handed over
+                // keep the next tile's conversions below this point: hoisted, they
+                // would wait for loads that still have two tiles of time
+                __builtin_amdgcn_sched_barrier(0);
+                bi = bnx;
+            }
+        }
+        return;
+    }
+
+    // ---- consumer: lane -> (subframe, lag group, parity) ----
+    const int g = lane / lps, ql = lane - g * lps;
+    const int pi = ql & 1, grp = ql >> 1;
+    const int l0 = (grp < ge) ? 6 * grp : 1 + 6 * (grp - ge);
+    const bool chain = (g < G) && (s0 + g < nsub) && (l0 <= maxlag);
+    const bool ok1 = l0 + 2 <= maxlag, ok2 = l0 + 4 <= maxlag;
+    const int pib = pi ^ (l0 & 1);                      // parity array that holds d[p - l0]
+    const int sft = (l0 + pib - pi) / 2;                // index shift inside that array
+    const int gq = chain ? g : 0;
+    const int offA = gq * PS_STRIDE + pi * PS_ROW + PS_HH;                         // a = buf[offA + t]
+    const int offB = gq * PS_STRIDE + pib * PS_ROW + PS_HH - (chain ? sft : 0);
+    const int pih = (maxlag + 1) & 1;                   // parity whose sum owns the head
+    double S0 = 1.0, S1 = 1.0, S2 = 1.0;                // lpc.c:58-59
+    double b1 = 0.0, b2 = 0.0;                          // d[p-2-l0], d[p-4-l0], carried
+
+    // One full tile: PS_HALF steps of 3 products, software-pipelined.  FIRST is the
+    // tile that starts the block: the products of positions <= maxlag belong to
+    // the head (below), so their `a` is replaced by 0 -- a (+-0) product leaves a
+    // running sum, which is never -0, bit for bit as it was.
+    auto walk_tile = [&](const double *rowA, const double *rowB, auto first) {
+        constexpr bool FIRST = decltype(first)::value;
+        constexpr int NS = PS_HALF / PS_CH;
+        double A[PS_CH], B[PS_CH];
+#pragma unroll
+        for (int u = 0; u < PS_CH; u++) { A[u] = rowA[u]; B[u] = rowB[u]; }
+#pragma unroll
+        for (int st = 0; st < NS; st++) {
+            double An[PS_CH], Bn[PS_CH];
+            if (DBG == 1 || DBG >= 3) {
+#pragma unroll
+                for (int u = 0; u < PS_CH; u++) { An[u] = A[u] ; Bn[u] = B[u]; }
+            } else
+            if (st + 1 < NS) {
+#pragma unroll
+                for (int u = 0; u < PS_CH; u++) {
+                    An[u] = rowA[(st + 1) * PS_CH + u];
+                    Bn[u] = rowB[(st + 1) * PS_CH + u];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < PS_CH; u++) {
+                if (DBG >= 2) { if (u == 0 && (DBG == 2 || st == 0)) S0 = S0 + A[0] * B[7]; continue; }
+                double a = A[u];
+                if (FIRST && 2 * (st * PS_CH + u) <= FHIP_MAX_ORDER)            // steps that can hold p <= maxlag
+                    a = (2 * (st * PS_CH + u) + pi > maxlag) ? a : 0.0;
+                const double p0 = a * B[u], p1 = a * b1, p2 = a * b2;
+                S0 = S0 + p0;
+                S1 = S1 + p1;
+                S2 = S2 + p2;
+                b2 = b1;
+                b1 = B[u];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 1 < NS) {
+#pragma unroll
+                for (int u = 0; u < PS_CH; u++) { A[u] = An[u]; B[u] = Bn[u]; }
+            }
+        }
+    };
+
+    int bi = 0;
+    for (int t = 0; t < ntiles_pad; t++) {
+        const int tb = t * AC_TILE;
+        __syncthreads();                                   // tile t is in buffer bi
+        if (t >= ntiles) continue;                         // padding of the producer's unroll
+        const double *buf = ring + bi * PC_BUF;
+        const double *rowA = buf + offA, *rowB = buf + offB;
+        const int kend = min(AC_TILE, n - tb);            // positions in this tile
+        if (t == 0 && pi == pih) {
+            // head (lpc.c:60-61): positions lag..maxlag of BOTH parities, in order,
+            // into this lane's sums (tile 0 holds them all: maxlag <= 32 < AC_TILE)
+            const int hend = min(maxlag, kend - 1);
+            for (int x = 0; x <= hend; x++) {
+                const double a = buf[slot(gq, x)];
+                if (x >= l0) {
+                    const double p0 = a * buf[slot(gq, x - l0)];
+                    S0 = S0 + p0;
+                }
+                if (ok1 && x >= l0 + 2) {
+                    const double p1 = a * buf[slot(gq, x - l0 - 2)];
+                    S1 = S1 + p1;
+                }
+                if (ok2 && x >= l0 + 4) {
+                    const double p2 = a * buf[slot(gq, x - l0 - 4)];
+                    S2 = S2 + p2;
+                }
+            }
+        }
+        if (kend == AC_TILE) {
+            if (t == 0) walk_tile(rowA, rowB, std::true_type{});
+            else walk_tile(rowA, rowB, std::false_type{});
+        } else {
+            // ragged last tile: positions of parity pi above maxlag, one at a time
+            for (int st = 0; st < PS_HALF; st++) {
+                const int x = 2 * st + pi;
+                const int p = tb + x;
+                if (x >= kend) break;
+                const double a = rowA[st], b0 = rowB[st];
+                if (p > maxlag) {
+                    // operands straight from LDS in this slow path (p - l0 - 4 >= tb - 32)
+                    const double c1 = (x - l0 - 2 >= -AC_HALO) ? buf[slot(gq, x - l0 - 2 + AC_HALO) - PS_HH] : 0.0;
+                    const double c2 = (x - l0 - 4 >= -AC_HALO) ? buf[slot(gq, x - l0 - 4 + AC_HALO) - PS_HH] : 0.0;
+                    const double p0 = a * b0, p1 = a * c1, p2 = a * c2;
+                    S0 = S0 + p0;
+                    S1 = S1 + p1;
+                    S2 = S2 + p2;
+                }
+                b2 = b1;
+                b1 = b0;
+            }
+        }
+        bi = (bi == PC_NBUF - 1) ? 0 : bi + 1;
     }
     // lpc.c:68: autoc = temp + temp2 -- the two parities of a lag group are
     // neighbouring lanes
@@ -2946,8 +3172,23 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
     if (use_ps) {
         const int per_block = Gp * AC_WAVES;
         const int blocks = (nsub + per_block - 1) / per_block;
-        hipLaunchKernelGGL(k_autocorr_ps, dim3(blocks), dim3(AC_WAVES * WAVE), 0, st, smp, autoc,
-                           nsub, n, max_order, Gp, lps, ge, c);
+        if ((force && force[0] == 'p' && force[1] == 's') || (n % 4) != 0 || n < 4) {   // the single-wave variant
+            hipLaunchKernelGGL(k_autocorr_ps, dim3(blocks), dim3(AC_WAVES * WAVE), 0, st, smp, autoc,
+                               nsub, n, max_order, Gp, lps, ge, c);
+            return hipGetLastError();
+        }
+        const size_t lds = sizeof(double) * (size_t)PC_PAIRS * PC_NBUF * PC_BUF;
+        static const int dbg = getenv("FHIP_PC_DBG") ? atoi(getenv("FHIP_PC_DBG")) : 0;
+#define LAUNCH_PC(D)                                                                         \
+    do {                                                                                     \
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_autocorr_pc<D>), \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (er != hipSuccess) return er;                                                     \
+        hipLaunchKernelGGL(k_autocorr_pc<D>, dim3(blocks), dim3(2 * PC_PAIRS * WAVE), lds, st, smp, \
+                           autoc, nsub, n, max_order, Gp, lps, ge, c);                       \
+    } while (0)
+        if (dbg == 1) LAUNCH_PC(1); else if (dbg == 2) LAUNCH_PC(2); else if (dbg == 3) LAUNCH_PC(3); else if (dbg == 5) LAUNCH_PC(5); else if (dbg == 6) LAUNCH_PC(6); else LAUNCH_PC(0);
+#undef LAUNCH_PC
         return hipGetLastError();
     }
     // spread over all CUs when the batch is small: fewer subframes per wave

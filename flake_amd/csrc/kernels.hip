@@ -35,8 +35,28 @@ extern "C" __attribute__((visibility("default"))) int fhip_debug_read_stamps(lon
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fhip_stamps), sizeof(long long) * 64);
 }
+// accumulating timers (tools/stamps_k1.py): TICK reads the clock, ACCUM adds an
+// interval to slot i for the first wave pair of workgroup 0
+#define TICK(v_)                                                                       \
+    unsigned long long v_;                                                             \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v_)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    } while (0)
+#define ACCUM(i, a_, b_)                                                               \
+    do {                                                                               \
+        if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) g_fhip_stamps[i] += (long long)((b_) - (a_)); \
+    } while (0)
+#define ACC_RESET(lo, hi)                                                              \
+    do {                                                                               \
+        if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) for (int z_ = lo; z_ < hi; z_++) g_fhip_stamps[z_] = 0; \
+    } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define TICK(v_) do { } while (0)
+#define ACCUM(i, a_, b_) do { } while (0)
+#define ACC_RESET(lo, hi) do { } while (0)
 #endif
 
 namespace fhip {
@@ -874,227 +894,245 @@ void k_autocorr_ps(const int32_t *__restrict__ smp, double *__restrict__ autoc,
 }
 
 // ---------------------------------------------------------------------------
-// K1 (producer/consumer)  k_autocorr_pc
+// K1 (main)  k_autocorr_wt<NCH> -- wave-typed producer / consumer
 // ---------------------------------------------------------------------------
-// k_autocorr_ps with the two halves of its loop body on different waves.  PMC
-// showed the one-wave-per-SIMD walk spending 40 % of its cycles parked (global
-// loads, LDS round trips of the staging) and 25 % of its vector instructions
-// outside the chains.  Here a workgroup is four wave pairs: the consumer of a
-// pair (waves 0-3, one per SIMD) only walks -- LDS operand reads and the ordered
-// mul/add chains -- while its producer (waves 4-7, again one per SIMD) loads the
-// samples two tiles ahead, windows them and writes the fp64 tile.  Tiles live in
-// a ring of three LDS buffers per pair: while the consumer walks buffer t%3 (and
-// its halo), the producer fills buffer (t+1)%3 and the halo of buffer (t+2)%3
-// with the same values (the last 32 positions of a tile are the next tile's
-// halo).  One workgroup barrier per tile hands a tile over; the arithmetic, its
-// order and the lane mapping are those of k_autocorr_ps.
-constexpr int PC_PAIRS = 4;
-constexpr int PC_NBUF = 3;
-constexpr int PC_BUF = PS_GMAX * PS_STRIDE;          // doubles per tile buffer
+// PMC and in-kernel stamps on k_autocorr_ps showed the chain walk bound by the LDS
+// (two 8-byte operand reads per lane and step, bank conflicts between the lag
+// groups of a subframe, and one wave per SIMD that stalls on its own staging),
+// not by the fp64 chains.  This kernel keeps the arithmetic and its order and
+// changes who does what:
+//  * a workgroup owns 32 subframes and has four consumer waves (one per SIMD) and
+//    four producer waves (again one per SIMD);
+//  * consumer wave w owns one lag group {l0, l0+2, .., l0+2(nch-1)} (same-parity
+//    lags) for all 32 subframes: lane = (parity pi, subframe).  The lag shift is
+//    wave-uniform, 32 lanes of one parity read 32 consecutive-stride addresses
+//    (stride odd: conflict-free ds_read_b64), the group with l0 = 0 needs no
+//    second operand stream at all (d[p - 0] is `a`), and the operands of the
+//    higher lags of a group are the previous steps' values, carried in registers;
+//  * producer wave p loads rows 8p..8p+7 three tiles ahead (counted waits),
+//    windows them (lpc.c:28-40; two weights per lane and tile serve all rows)
+//    and writes fp64 tiles, de-interleaved by parity, into a ring of three LDS
+//    buffers: while the consumers walk buffer t%3 and its halo, the producers
+//    fill buffer (t+1)%3 and the halo of buffer (t+2)%3 (the last 32 positions
+//    of a tile are the next tile's halo).  One barrier per tile.
+// Per step a consumer issues 2*NCH fp64 operations and one or two LDS reads, so
+// the walk is bound by fp64 issue: n/2 steps x 2*NCH x ~4.6 cycles.
+// Requires n % AC_TILE == 0 (launch_autocorr falls back otherwise).
+constexpr int WT_SUB = 32;                           // subframes per workgroup
+constexpr int WT_ROWS0 = 2;                          // rows staged by the producer next to consumer 0
+constexpr int WT_ROWS1 = (WT_SUB - WT_ROWS0) / 3;    // ... by each of the other three
+static_assert(WT_ROWS0 + 3 * WT_ROWS1 == WT_SUB, "producer row split");
+constexpr int WT_ROW = PS_HH + PS_HALF + 1;          // doubles per parity array (81)
+constexpr int WT_STRIDE = 2 * WT_ROW + 1;            // per subframe: odd, so 32 subframes hit 32 bank pairs
+constexpr int WT_BUF = WT_SUB * WT_STRIDE;           // doubles per tile buffer
+constexpr int WT_NBUF = 3;
+constexpr int WT_AHEAD = 3;                          // tiles of loads in flight per producer
 
-template <int DBG>
-__global__ __launch_bounds__(2 * PC_PAIRS * WAVE)
-void k_autocorr_pc(const int32_t *__restrict__ smp, double *__restrict__ autoc,
-                   int nsub, int n, int maxlag, int G, int lps, int ge, double c)
+struct wt_groups { int l0[4]; int nch[4]; };
+
+template <int NCH>
+__global__ __launch_bounds__(8 * WAVE)
+void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
+                   int nsub, int n, int maxlag, wt_groups grp, double c)
 {
-    extern __shared__ __attribute__((aligned(16))) double pc_lds[];
+    extern __shared__ __attribute__((aligned(16))) double wt_lds[];
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const bool producer = wv >= PC_PAIRS;
-    const int pair = wv & (PC_PAIRS - 1);
-    double *ring = pc_lds + (size_t)pair * PC_NBUF * PC_BUF;
-    const int s0 = (blockIdx.x * PC_PAIRS + pair) * G;   // >= nsub: the pair idles through the barriers
+    const int sub0 = blockIdx.x * WT_SUB;
     const int half = n >> 1;
-    const int ntiles = (n + AC_TILE - 1) / AC_TILE;
-    const int ntiles_pad = ((ntiles + 2) / 3) * 3;      // the producer's unroll; both roles run this many barriers
-    // position tb + x sits in parity array (x & 1) at index PS_HH + x/2
-    auto slot = [&](int q, int x) { return q * PS_STRIDE + (x & 1) * PS_ROW + PS_HH + (x >> 1); };
+    const int ntiles = n / AC_TILE;
+    const int ntiles_pad = ((ntiles + WT_AHEAD - 1) / WT_AHEAD) * WT_AHEAD;   // the producers' unroll
 
-    if (producer) {
-        // lane = position inside the tile (two per lane), so a window weight is
-        // computed once per lane and tile and serves all subframes of the pair.
-        // PC_AHEAD tiles of loads are in flight per wave (48 dwords per lane); the
-        // loop is unrolled by that depth so every tile has its own registers, and
-        // it has no branches, so the waits stay counted (vmcnt(N), never 0).
-        constexpr int PC_AHEAD = 3;
-        const int32_t *rowp[PS_GMAX];
+    if (wv >= 4) {
+        // ------------------------------ producer ------------------------------
+        // lane = positions 2*lane, 2*lane+1 of the tile: one 8-byte load per row,
+        // 512 contiguous bytes per row and instruction.  The loop is unrolled by
+        // the prefetch depth so every tile has its own registers, and it has no
+        // branches, so the waits stay counted (vmcnt(N), never 0).
+        // A producer shares its SIMD with consumer wv-4.  Consumer 0 owns the
+        // largest lag group (its chains take 2 fp64 issue slots per step more than
+        // the others'), so its producer stages WT_ROWS0 rows and the other three
+        // WT_ROWS1 each: the four SIMDs finish a tile at about the same time.
+        auto produce = [&](auto nrows_c, int q0) {
+            constexpr int NR = decltype(nrows_c)::value;
+            // row bases are wave-uniform: SGPR base + lane offset addressing
+            unsigned long long rowb[NR];
 #pragma unroll
-        for (int q = 0; q < PS_GMAX; q++) rowp[q] = smp + (size_t)min(s0 + q, nsub - 1) * n;
-        int32_t pre[PC_AHEAD][PS_GMAX][AC_PER_LANE];
-        auto issue_loads = [&](int32_t (&dst)[PS_GMAX][AC_PER_LANE], int tb) {
-#pragma unroll
-            for (int q = 0; q < PS_GMAX; q++)
-#pragma unroll
-                for (int u = 0; u < AC_PER_LANE; u++)
-                    dst[q][u] = (DBG == 5) ? rowp[0][min((tb / AC_TILE) * (PS_GMAX * AC_TILE) + (q * AC_PER_LANE + u) * WAVE + lane, PS_GMAX * n - 1)]   // timing probe: one contiguous 4 KB per tile
-                                           : rowp[q][min(tb + u * WAVE + lane, n - 1)];
-        };
-#pragma unroll
-        for (int a = 0; a < PC_AHEAD; a++) issue_loads(pre[a], a * AC_TILE);
-        // the halo of the first tile is zeros (positions -32 .. -1)
-        for (int idx = lane; idx < PS_GMAX * 2 * PS_HH; idx += WAVE) {
-            const int qq = idx / (2 * PS_HH), r = idx - qq * 2 * PS_HH;
-            ring[qq * PS_STRIDE + (r / PS_HH) * PS_ROW + (r % PS_HH)] = 0.0;
-        }
-        int bi = 0;                                        // t % 3
-        for (int t0 = 0; t0 < ntiles_pad; t0 += PC_AHEAD) {
-#pragma unroll
-            for (int a = 0; a < PC_AHEAD; a++) {
-                const int tb = (t0 + a) * AC_TILE;
-                double *bw = ring + bi * PC_BUF;
-                const int bnx = (bi == PC_NBUF - 1) ? 0 : bi + 1;
-                double *bn = ring + bnx * PC_BUF;
-                // ---- window the tile (lpc.c:28-40), de-interleaved by parity ----
-#pragma unroll
-                for (int u = 0; u < AC_PER_LANE; u++) {
-                    const int x = u * WAVE + lane;
-                    const int p = tb + x;
-                    const int ii = (p < half) ? p : (n - 1 - p);
-                    const bool valid = (p < n) && (ii < half);
-                    const double tt = c - (double)ii;
-                    const double w = valid ? (1.0 - (tt * tt)) : 0.0;
-                    const bool tail = x >= AC_TILE - AC_HALO;
-#pragma unroll
-                    for (int q = 0; q < PS_GMAX; q++) {
-                        const double v = (double)pre[a][q][u] * w;
-                        bw[slot(q, x)] = v;
-                        if (tail) bn[slot(q, x) - PS_HALF] = v;      // = position x - AC_TILE of the next tile
-                    }
-                }
-                if (DBG != 6) issue_loads(pre[a], tb + PC_AHEAD * AC_TILE);   // 6: timing probe without loads
-                __syncthreads();                               // tile handed over
-                // keep the next tile's conversions below this point: hoisted, they
-                // would wait for loads that still have two tiles of time
-                __builtin_amdgcn_sched_barrier(0);
-                bi = bnx;
+            for (int r = 0; r < NR; r++) {
+                const unsigned long long pa = (unsigned long long)(smp + (size_t)min(sub0 + q0 + r, nsub - 1) * n);
+                rowb[r] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) |
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)pa);
             }
-        }
+            int2 pre[WT_AHEAD][NR];
+            auto issue_loads = [&](int2 (&dst)[NR], int tb) {
+                const int p = min(tb + 2 * lane, n - 2);       // past the block: clamped, weight 0
+#pragma unroll
+                for (int r = 0; r < NR; r++) dst[r] = *reinterpret_cast<const int2 *>(reinterpret_cast<const int32_t *>(rowb[r]) + p);
+            };
+#pragma unroll
+            for (int a = 0; a < WT_AHEAD; a++) issue_loads(pre[a], a * AC_TILE);
+            // the halo of the first tile is zeros (positions -32 .. -1)
+            for (int idx = lane; idx < NR * 2 * PS_HH; idx += WAVE) {
+                const int r = idx / (2 * PS_HH), k = idx - r * 2 * PS_HH;
+                wt_lds[(q0 + r) * WT_STRIDE + (k / PS_HH) * WT_ROW + (k % PS_HH)] = 0.0;
+            }
+            // lpc.c:34-39, 0 beyond the block
+            auto weight = [&](int p) {
+                const int ii = (p < half) ? p : (n - 1 - p);
+                const bool valid = (p < n) && (ii < half);
+                const double tt = c - (double)ii;
+                return valid ? (1.0 - (tt * tt)) : 0.0;
+            };
+            int bi = 0;                                        // t % 3
+            ACC_RESET(44, 48);
+            for (int t0 = 0; t0 < ntiles_pad; t0 += WT_AHEAD) {
+#pragma unroll
+                for (int a = 0; a < WT_AHEAD; a++) {
+                    TICK(tp0);
+                    const int tb = (t0 + a) * AC_TILE;
+                    const int bnx = (bi == WT_NBUF - 1) ? 0 : bi + 1;
+                    double *bw = wt_lds + bi * WT_BUF + q0 * WT_STRIDE + PS_HH + lane;
+                    double *bn = wt_lds + bnx * WT_BUF + q0 * WT_STRIDE + PS_HH + lane - PS_HALF;
+                    const double w0 = weight(tb + 2 * lane), w1 = weight(tb + 2 * lane + 1);
+                    const bool tail = lane >= PS_HALF - PS_HH;        // positions 96..127
+#pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        const double v0 = (double)pre[a][r].x * w0;
+                        const double v1 = (double)pre[a][r].y * w1;
+                        bw[r * WT_STRIDE] = v0;
+                        bw[r * WT_STRIDE + WT_ROW] = v1;
+                        if (tail) {                                   // = positions -32..-1 of the next tile
+                            bn[r * WT_STRIDE] = v0;
+                            bn[r * WT_STRIDE + WT_ROW] = v1;
+                        }
+                    }
+                    TICK(tp1);
+                    issue_loads(pre[a], tb + WT_AHEAD * AC_TILE);
+                    TICK(tp2);
+                    __syncthreads();                               // tile handed over
+                    TICK(tp3);
+                    ACCUM(44, tp0, tp1); ACCUM(45, tp1, tp2); ACCUM(46, tp2, tp3);
+                    // keep the next tile's conversions below this point: hoisted, they
+                    // would wait for loads that still have two tiles of time
+                    __builtin_amdgcn_sched_barrier(0);
+                    bi = bnx;
+                }
+            }
+        };
+        if (wv == 4) produce(std::integral_constant<int, WT_ROWS0>{}, 0);
+        else produce(std::integral_constant<int, WT_ROWS1>{}, WT_ROWS0 + (wv - 5) * WT_ROWS1);
         return;
     }
 
-    // ---- consumer: lane -> (subframe, lag group, parity) ----
-    const int g = lane / lps, ql = lane - g * lps;
-    const int pi = ql & 1, grp = ql >> 1;
-    const int l0 = (grp < ge) ? 6 * grp : 1 + 6 * (grp - ge);
-    const bool chain = (g < G) && (s0 + g < nsub) && (l0 <= maxlag);
-    const bool ok1 = l0 + 2 <= maxlag, ok2 = l0 + 4 <= maxlag;
+    // -------------------------------- consumer --------------------------------
+    const int pi = lane >> 5, sl = lane & 31;
+    const int l0 = grp.l0[wv], nch = grp.nch[wv];       // wave-uniform
+    const bool live = (sub0 + sl < nsub) && nch > 0;
     const int pib = pi ^ (l0 & 1);                      // parity array that holds d[p - l0]
     const int sft = (l0 + pib - pi) / 2;                // index shift inside that array
-    const int gq = chain ? g : 0;
-    const int offA = gq * PS_STRIDE + pi * PS_ROW + PS_HH;                         // a = buf[offA + t]
-    const int offB = gq * PS_STRIDE + pib * PS_ROW + PS_HH - (chain ? sft : 0);
+    const int offA = sl * WT_STRIDE + pi * WT_ROW + PS_HH;             // a  = buf[offA + step]
+    const int offB = sl * WT_STRIDE + pib * WT_ROW + PS_HH - sft;      // b0 = buf[offB + step]
     const int pih = (maxlag + 1) & 1;                   // parity whose sum owns the head
-    double S0 = 1.0, S1 = 1.0, S2 = 1.0;                // lpc.c:58-59
-    double b1 = 0.0, b2 = 0.0;                          // d[p-2-l0], d[p-4-l0], carried
-
-    // One full tile: PS_HALF steps of 3 products, software-pipelined.  FIRST is the
-    // tile that starts the block: the products of positions <= maxlag belong to
-    // the head (below), so their `a` is replaced by 0 -- a (+-0) product leaves a
-    // running sum, which is never -0, bit for bit as it was.
-    auto walk_tile = [&](const double *rowA, const double *rowB, auto first) {
-        constexpr bool FIRST = decltype(first)::value;
-        constexpr int NS = PS_HALF / PS_CH;
-        double A[PS_CH], B[PS_CH];
+    auto slotc = [&](int x) { return sl * WT_STRIDE + (x & 1) * WT_ROW + PS_HH + (x >> 1); };
+    double S[NCH], cy[NCH];                             // running sums (lpc.c:58-59); cy[j] = d[p - l0 - 2j] carried
 #pragma unroll
-        for (int u = 0; u < PS_CH; u++) { A[u] = rowA[u]; B[u] = rowB[u]; }
+    for (int j = 0; j < NCH; j++) { S[j] = 1.0; cy[j] = 0.0; }
+
+    // One tile: PS_HALF steps of NCH products, operands read two stages ahead.
+    // FIRST is the tile that starts the block: products of positions <= maxlag
+    // belong to the head (below), so their `a` is replaced by 0 -- a (+-0) product
+    // leaves a running sum, which is never -0, bit for bit as it was.  SAME: the
+    // group starts at lag 0, so b0 is a.
+    auto walk_tile = [&](const double *rowA_, const double *rowB_, auto first, auto same) {
+        constexpr bool FIRST = decltype(first)::value;
+        constexpr bool SAME = decltype(same)::value;
+        constexpr int NS = PS_HALF / PS_CH;
+        // stages of operands in flight ahead of their use: two while a stage is short
+        constexpr int DEPTH = (NCH <= 3) ? 2 : 1;
+        constexpr int NSET = DEPTH + 1;
+        // volatile: keeps the reads single ds_read_b64 (256 B/clk, 64 banks); merged
+        // into ds_read2_b64 they run at half that rate with 32-bank banking
+        typedef const volatile double __attribute__((address_space(3))) lds_cvd;
+        lds_cvd *rowA = (lds_cvd *)rowA_, *rowB = (lds_cvd *)rowB_;
+        double A[NSET][PS_CH], B[NSET][PS_CH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++)
+#pragma unroll
+            for (int u = 0; u < PS_CH; u++) {
+                A[k][u] = rowA[k * PS_CH + u];
+                if (!SAME) B[k][u] = rowB[k * PS_CH + u];
+            }
 #pragma unroll
         for (int st = 0; st < NS; st++) {
-            double An[PS_CH], Bn[PS_CH];
-            if (DBG == 1 || DBG >= 3) {
-#pragma unroll
-                for (int u = 0; u < PS_CH; u++) { An[u] = A[u] ; Bn[u] = B[u]; }
-            } else
-            if (st + 1 < NS) {
+            if (st + DEPTH < NS) {
 #pragma unroll
                 for (int u = 0; u < PS_CH; u++) {
-                    An[u] = rowA[(st + 1) * PS_CH + u];
-                    Bn[u] = rowB[(st + 1) * PS_CH + u];
+                    A[(st + DEPTH) % NSET][u] = rowA[(st + DEPTH) * PS_CH + u];
+                    if (!SAME) B[(st + DEPTH) % NSET][u] = rowB[(st + DEPTH) * PS_CH + u];
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < PS_CH; u++) {
-                if (DBG >= 2) { if (u == 0 && (DBG == 2 || st == 0)) S0 = S0 + A[0] * B[7]; continue; }
-                double a = A[u];
+                const double x = SAME ? A[st % NSET][u] : B[st % NSET][u];
+                double a = A[st % NSET][u];
                 if (FIRST && 2 * (st * PS_CH + u) <= FHIP_MAX_ORDER)            // steps that can hold p <= maxlag
                     a = (2 * (st * PS_CH + u) + pi > maxlag) ? a : 0.0;
-                const double p0 = a * B[u], p1 = a * b1, p2 = a * b2;
-                S0 = S0 + p0;
-                S1 = S1 + p1;
-                S2 = S2 + p2;
-                b2 = b1;
-                b1 = B[u];
+                double pr[NCH];
+                pr[0] = a * x;
+#pragma unroll
+                for (int j = 1; j < NCH; j++) pr[j] = a * cy[j];
+#pragma unroll
+                for (int j = 0; j < NCH; j++) S[j] = S[j] + pr[j];
+#pragma unroll
+                for (int j = NCH - 1; j >= 2; j--) cy[j] = cy[j - 1];
+                if (NCH > 1) cy[1] = x;
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (st + 1 < NS) {
-#pragma unroll
-                for (int u = 0; u < PS_CH; u++) { A[u] = An[u]; B[u] = Bn[u]; }
-            }
         }
     };
 
     int bi = 0;
+    ACC_RESET(40, 44);
     for (int t = 0; t < ntiles_pad; t++) {
-        const int tb = t * AC_TILE;
+        TICK(tc0);
         __syncthreads();                                   // tile t is in buffer bi
-        if (t >= ntiles) continue;                         // padding of the producer's unroll
-        const double *buf = ring + bi * PC_BUF;
-        const double *rowA = buf + offA, *rowB = buf + offB;
-        const int kend = min(AC_TILE, n - tb);            // positions in this tile
+        TICK(tc1);
+        ACCUM(40, tc0, tc1);
+        if (t >= ntiles) continue;                         // padding of the producers' unroll
+        const double *buf = wt_lds + bi * WT_BUF;
         if (t == 0 && pi == pih) {
             // head (lpc.c:60-61): positions lag..maxlag of BOTH parities, in order,
             // into this lane's sums (tile 0 holds them all: maxlag <= 32 < AC_TILE)
-            const int hend = min(maxlag, kend - 1);
-            for (int x = 0; x <= hend; x++) {
-                const double a = buf[slot(gq, x)];
-                if (x >= l0) {
-                    const double p0 = a * buf[slot(gq, x - l0)];
-                    S0 = S0 + p0;
-                }
-                if (ok1 && x >= l0 + 2) {
-                    const double p1 = a * buf[slot(gq, x - l0 - 2)];
-                    S1 = S1 + p1;
-                }
-                if (ok2 && x >= l0 + 4) {
-                    const double p2 = a * buf[slot(gq, x - l0 - 4)];
-                    S2 = S2 + p2;
+            for (int x = 0; x <= maxlag; x++) {
+                const double a = buf[slotc(x)];
+#pragma unroll
+                for (int j = 0; j < NCH; j++) {
+                    const int lag = l0 + 2 * j;
+                    if (j < nch && x >= lag) {
+                        const double pr = a * buf[slotc(x - lag)];
+                        S[j] = S[j] + pr;
+                    }
                 }
             }
         }
-        if (kend == AC_TILE) {
-            if (t == 0) walk_tile(rowA, rowB, std::true_type{});
-            else walk_tile(rowA, rowB, std::false_type{});
+        if (l0 == 0) {
+            if (t == 0) walk_tile(buf + offA, buf + offB, std::true_type{}, std::true_type{});
+            else walk_tile(buf + offA, buf + offB, std::false_type{}, std::true_type{});
         } else {
-            // ragged last tile: positions of parity pi above maxlag, one at a time
-            for (int st = 0; st < PS_HALF; st++) {
-                const int x = 2 * st + pi;
-                const int p = tb + x;
-                if (x >= kend) break;
-                const double a = rowA[st], b0 = rowB[st];
-                if (p > maxlag) {
-                    // operands straight from LDS in this slow path (p - l0 - 4 >= tb - 32)
-                    const double c1 = (x - l0 - 2 >= -AC_HALO) ? buf[slot(gq, x - l0 - 2 + AC_HALO) - PS_HH] : 0.0;
-                    const double c2 = (x - l0 - 4 >= -AC_HALO) ? buf[slot(gq, x - l0 - 4 + AC_HALO) - PS_HH] : 0.0;
-                    const double p0 = a * b0, p1 = a * c1, p2 = a * c2;
-                    S0 = S0 + p0;
-                    S1 = S1 + p1;
-                    S2 = S2 + p2;
-                }
-                b2 = b1;
-                b1 = b0;
-            }
+            if (t == 0) walk_tile(buf + offA, buf + offB, std::true_type{}, std::false_type{});
+            else walk_tile(buf + offA, buf + offB, std::false_type{}, std::false_type{});
         }
-        bi = (bi == PC_NBUF - 1) ? 0 : bi + 1;
+        bi = (bi == WT_NBUF - 1) ? 0 : bi + 1;
+        TICK(tc2);
+        ACCUM(t == 0 ? 42 : 41, tc1, tc2);
     }
-    // lpc.c:68: autoc = temp + temp2 -- the two parities of a lag group are
-    // neighbouring lanes
-    const double o0 = __shfl_xor(S0, 1, WAVE), o1 = __shfl_xor(S1, 1, WAVE), o2 = __shfl_xor(S2, 1, WAVE);
-    if (chain && pi == 0) {
-        double *dst = autoc + (size_t)(s0 + g) * FHIP_MAX_LAGS;
-        dst[l0] = S0 + o0;
-        if (ok1) dst[l0 + 2] = S1 + o1;
-        if (ok2) dst[l0 + 4] = S2 + o2;
+    // lpc.c:68: autoc = temp + temp2 -- the two parities of a lag are lanes l, l+32
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+        const double o = __shfl_xor(S[j], 32, WAVE);
+        if (live && pi == 0 && j < nch) autoc[(size_t)(sub0 + sl) * FHIP_MAX_LAGS + l0 + 2 * j] = S[j] + o;
     }
 }
 
@@ -3169,26 +3207,53 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
     if (force && force[0] == 'c') use_ps = false;
     if (force && force[0] == 'p' && cost_ps > 0) use_ps = true;
 
+    // k_autocorr_wt: whole tiles only.  Which kernel: a measured time model in ns
+    // (MI355X; rounds = workgroup waves over the chip, step = one walk step):
+    //   wt : rounds x (n/2 x max(30, 6.2 NCH) + 3200)      32 subframes per workgroup
+    //   ps : rounds x (n/2 x 39 + 1000)                      Gp subframes per wave
+    //   cur: rounds x (n x 20 + 1000)                        G subframes per wave
+    const int e0 = (ne + 1) / 2, e1 = ne - e0, o0 = (no + 1) / 2, o1 = no - o0;
+    bool use_wt = false;
+    if ((n % AC_TILE) == 0) {
+        const double per_step = (6.2 * e0 > 30.0) ? 6.2 * e0 : 30.0;
+        const double t_wt = (double)(((nsub + WT_SUB - 1) / WT_SUB + 255) / 256) * (0.5 * n * per_step + 3200.0);
+        const double t_ps = (cost_ps > 0) ? (double)(((nsub + Gp - 1) / Gp + simds - 1) / simds) * (0.5 * n * 39.0 + 1000.0) : 1e30;
+        const double t_cur = (double)((waves_cur + simds - 1) / simds) * (n * 20.0 + 1000.0);
+        use_wt = t_wt <= t_ps && t_wt <= t_cur;
+        if (!use_wt) use_ps = t_ps < t_cur;
+        if (force) use_wt = (force[0] == 'w');
+    }
+    if (use_wt) {
+        wt_groups gr;
+        gr.l0[0] = 0;          gr.nch[0] = e0;
+        gr.l0[1] = 2 * e0;     gr.nch[1] = e1;
+        gr.l0[2] = 1;          gr.nch[2] = o0;
+        gr.l0[3] = 1 + 2 * o0; gr.nch[3] = o1;
+        const int nch = e0;                                    // e0 >= e1, o0, o1
+        const int blocks = (nsub + WT_SUB - 1) / WT_SUB;
+        const size_t lds = sizeof(double) * (size_t)WT_NBUF * WT_BUF;
+#define LAUNCH_WT(N_)                                                                        \
+    case N_: {                                                                               \
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_autocorr_wt<N_>), \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (er != hipSuccess) return er;                                                     \
+        hipLaunchKernelGGL(k_autocorr_wt<N_>, dim3(blocks), dim3(8 * WAVE), lds, st, smp, autoc, \
+                           nsub, n, max_order, gr, c);                                       \
+        break;                                                                               \
+    }
+        switch (nch) {
+            LAUNCH_WT(1) LAUNCH_WT(2) LAUNCH_WT(3) LAUNCH_WT(4) LAUNCH_WT(5)
+            LAUNCH_WT(6) LAUNCH_WT(7) LAUNCH_WT(8) LAUNCH_WT(9)
+        default: return hipErrorInvalidValue;
+        }
+#undef LAUNCH_WT
+        return hipGetLastError();
+    }
     if (use_ps) {
         const int per_block = Gp * AC_WAVES;
         const int blocks = (nsub + per_block - 1) / per_block;
-        if ((force && force[0] == 'p' && force[1] == 's') || (n % 4) != 0 || n < 4) {   // the single-wave variant
-            hipLaunchKernelGGL(k_autocorr_ps, dim3(blocks), dim3(AC_WAVES * WAVE), 0, st, smp, autoc,
-                               nsub, n, max_order, Gp, lps, ge, c);
-            return hipGetLastError();
-        }
-        const size_t lds = sizeof(double) * (size_t)PC_PAIRS * PC_NBUF * PC_BUF;
-        static const int dbg = getenv("FHIP_PC_DBG") ? atoi(getenv("FHIP_PC_DBG")) : 0;
-#define LAUNCH_PC(D)                                                                         \
-    do {                                                                                     \
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_autocorr_pc<D>), \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (er != hipSuccess) return er;                                                     \
-        hipLaunchKernelGGL(k_autocorr_pc<D>, dim3(blocks), dim3(2 * PC_PAIRS * WAVE), lds, st, smp, \
-                           autoc, nsub, n, max_order, Gp, lps, ge, c);                       \
-    } while (0)
-        if (dbg == 1) LAUNCH_PC(1); else if (dbg == 2) LAUNCH_PC(2); else if (dbg == 3) LAUNCH_PC(3); else if (dbg == 5) LAUNCH_PC(5); else if (dbg == 6) LAUNCH_PC(6); else LAUNCH_PC(0);
-#undef LAUNCH_PC
+        hipLaunchKernelGGL(k_autocorr_ps, dim3(blocks), dim3(AC_WAVES * WAVE), 0, st, smp, autoc,
+                           nsub, n, max_order, Gp, lps, ge, c);
         return hipGetLastError();
     }
     // spread over all CUs when the batch is small: fewer subframes per wave

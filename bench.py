@@ -183,23 +183,24 @@ def main():
         kt = enc.kernel_times(reset=True)
         enc.set_profiling(False)
         per = {k: (ms / max(c, 1)) for k, (ms, c) in kt.items() if c}
-        dom = max(per, key=per.get)
-        achieved = alg_bytes / (per[dom] * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {
-            "bound": "hbm", "kernel": dom,
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "kernel_ms": {k: round(v, 4) for k, v in per.items()},
-            "pipeline_achieved": round(alg_bytes / (sum(per.values()) * 1e-3) / 1e9, 1),
-        }
+        if per:                          # empty with --profile-steps 0 (the PMC passes)
+            dom = max(per, key=per.get)
+            achieved = alg_bytes / (per[dom] * 1e-3) / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get(dom, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {
+                "bound": "hbm", "kernel": dom,
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms": {k: round(v, 4) for k, v in per.items()},
+                "pipeline_achieved": round(alg_bytes / (sum(per.values()) * 1e-3) / 1e9, 1),
+            }
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(p, n, args.cpu_seconds)
 

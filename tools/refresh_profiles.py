@@ -13,7 +13,7 @@ shutil.copy(one(stats, '*kernel_stats.csv'), f'{R}/profiles/{tag}_kernel_stats.c
 shutil.copy(os.path.join(R, 'gpurun_out', bench), f'{R}/profiles/{tag}_bench.json')
 f = avg(one(fetch, '*counter_collection.csv'), 'FETCH_SIZE')
 w = avg(one(write, '*counter_collection.csv'), 'WRITE_SIZE')
-names = {'k_prepare': 'k_prepare_stereo', 'k_autocorr': 'k_autocorr', 'k_lpc': 'k_lpc', 'k_encode': 'k_encode_pow2'}
+names = {'k_prepare': 'k_prepare_stereo', 'k_autocorr': 'k_autocorr_wt', 'k_lpc': 'k_lpc', 'k_encode': 'k_encode_pow2'}
 old = json.load(open(f'{R}/profiles/pmc_traffic.json'))
 out = {"_note": old["_note"], "_calibration": old["_calibration"], "_tag": tag}
 for short, sym in names.items():

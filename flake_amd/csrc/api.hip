@@ -172,14 +172,18 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
         MaybeProf(fhip_ctx *cc, bool o, int i) : c(cc), on(o), p(o ? new Prof(cc, i) : nullptr) {}
         ~MaybeProf() { delete p; }
     };
+    // stereo batches in whole tiles: K0 only decides (ch_mode, wasted bits), the K1
+    // producers apply that to the PCM they stream anyway and write smp
+    const bool fused = lpc_path && fhip::autocorr_fuses_prepare(p, nsub, n);
     {
         MaybeProf pr(c, prof, 0);
-        HIP_TRY(c, fhip::launch_prepare(st, p, pcm, nframes, n, smp, info));
+        HIP_TRY(c, fhip::launch_prepare(st, p, pcm, nframes, n, smp, info, fused));
     }
     if (lpc_path) {
         {
             MaybeProf pr(c, prof, 1);
-            HIP_TRY(c, fhip::launch_autocorr(st, smp, nsub, n, p.max_prediction_order, autoc));
+            HIP_TRY(c, fhip::launch_autocorr(st, smp, nsub, n, p.max_prediction_order, autoc,
+                                             fused ? pcm : nullptr, fused ? smp : nullptr, info));
         }
         {
             MaybeProf pr(c, prof, 2);

@@ -18,13 +18,22 @@ struct EncodeArgs {
 
 // K0: copy_samples + channel_decorrelation + remove_wasted_bits
 // (encode.c:541-694).  pcm [nframes][n][ch] -> smp [nframes][ch][n].
+// decide_only: write obits / wasted / ch_mode to info[] and leave smp to the fused K1.
 hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *pcm,
-                          int nframes, int n, int32_t *smp, fhip_subframe_info *info);
+                          int nframes, int n, int32_t *smp, fhip_subframe_info *info,
+                          bool decide_only = false);
+
+// True when K1 will also do K0's apply stage for such a batch (stereo, whole
+// tiles, the wave-typed kernel): launch_prepare(decide_only) + launch_autocorr(pcm).
+bool autocorr_fuses_prepare(const fhip_params &p, int nsub, int n);
 
 // K1: apply_welch_window + compute_autocorr (lpc.c:28-71).
 // smp [nsub][n] -> autoc [nsub][FHIP_MAX_LAGS].
+// With pcm_fused (stereo PCM) the producers read it instead of smp, apply info[]'s
+// channel mode / wasted bits and write smp_out.
 hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
-                           int max_order, double *autoc);
+                           int max_order, double *autoc, const int32_t *pcm_fused = nullptr,
+                           int32_t *smp_out = nullptr, const fhip_subframe_info *info = nullptr);
 
 // K2: compute_lpc_coefs / _est + quantize_lpc_coefs (lpc.c:77-257).
 // coefs [nsub][32][32], shift [nsub][32], opt_order [nsub].

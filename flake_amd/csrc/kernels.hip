@@ -367,7 +367,10 @@ void k_prepare_multi(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
 // shift, and leave as one 16-byte store per channel and quad.  The two
 // sample-frames in front of a quad (for the 2nd-order residual) are one more
 // 16-byte load that hits L1/L2.
-template <int M>
+// APPLY = false is the decision pass of the fused pipeline: it writes only
+// obits / wasted / ch_mode; the K1 producers then apply them to the PCM they
+// load anyway and write smp (k_autocorr_wt<NCH, true>).
+template <int M, bool APPLY>
 __global__ __launch_bounds__(NT)
 void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
                       fhip_subframe_info *__restrict__ info, int n, int bps, int estimate)
@@ -483,7 +486,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
 #pragma unroll
     for (int m = 0; m < M; m++) {
         const int g = tid + NT * m;
-        if (g < nquads) {
+        if (APPLY && g < nquads) {
             dl[g] = make_int4(L[m][0] >> wasted[0], L[m][1] >> wasted[0], L[m][2] >> wasted[0], L[m][3] >> wasted[0]);
             dr[g] = make_int4(R[m][0] >> wasted[1], R[m][1] >> wasted[1], R[m][2] >> wasted[1], R[m][3] >> wasted[1]);
         }
@@ -919,21 +922,41 @@ void k_autocorr_ps(const int32_t *__restrict__ smp, double *__restrict__ autoc,
 // the walk is bound by fp64 issue: n/2 steps x 2*NCH x ~4.6 cycles.
 // Requires n % AC_TILE == 0 (launch_autocorr falls back otherwise).
 constexpr int WT_SUB = 32;                           // subframes per workgroup
-constexpr int WT_ROWS0 = 2;                          // rows staged by the producer next to consumer 0
+#ifndef FHIP_WT_ROWS0
+#define FHIP_WT_ROWS0 8
+#endif
+constexpr int WT_ROWS0 = FHIP_WT_ROWS0;              // rows staged by the producer next to consumer 0
 constexpr int WT_ROWS1 = (WT_SUB - WT_ROWS0) / 3;    // ... by each of the other three
 static_assert(WT_ROWS0 + 3 * WT_ROWS1 == WT_SUB, "producer row split");
-constexpr int WT_ROW = PS_HH + PS_HALF + 1;          // doubles per parity array (81)
-constexpr int WT_STRIDE = 2 * WT_ROW + 1;            // per subframe: odd, so 32 subframes hit 32 bank pairs
+// LDS geometry: the `a` stream is read 16 bytes (two steps) at a time, so arrays
+// start on even doubles; ds_read_b128 serves 16 lanes per LDS cycle and is
+// conflict-free when their 16-byte slots differ mod 16: stride/2 odd (83).  The
+// shifted `b0` stream stays on single 8-byte reads (its alignment depends on the
+// lag); with this stride they are 2-way conflicted, which the walk -- bound by
+// instruction issue, not by the LDS -- does not feel.
+constexpr int WT_ROW = PS_HH + PS_HALF + 2;          // doubles per parity array (82)
+constexpr int WT_STRIDE = 2 * WT_ROW + 2;            // per subframe (166)
+static_assert(WT_ROW % 2 == 0 && WT_STRIDE % 4 == 2, "16-byte aligned arrays, odd slot stride");
 constexpr int WT_BUF = WT_SUB * WT_STRIDE;           // doubles per tile buffer
 constexpr int WT_NBUF = 3;
 constexpr int WT_AHEAD = 3;                          // tiles of loads in flight per producer
 
 struct wt_groups { int l0[4]; int nch[4]; };
 
-template <int NCH>
+// FUSED: the producers read the interleaved stereo PCM instead of smp, apply the
+// channel mode and wasted-bits shift that the decision pass of K0 left in info[]
+// (encode.c:668-693, :586-590), write smp for K3 and window the same values.
+#ifdef FHIP_PROBE_NOHALO
+constexpr bool wt_probe_nohalo = true;      // timing probe only: results are wrong
+#else
+constexpr bool wt_probe_nohalo = false;
+#endif
+template <int NCH, bool FUSED>
 __global__ __launch_bounds__(8 * WAVE)
 void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
-                   int nsub, int n, int maxlag, wt_groups grp, double c)
+                   int nsub, int n, int maxlag, wt_groups grp, double c,
+                   const int32_t *__restrict__ pcm, int32_t *__restrict__ smp_out,
+                   const fhip_subframe_info *__restrict__ info)
 {
     extern __shared__ __attribute__((aligned(16))) double wt_lds[];
 
@@ -950,25 +973,42 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
         // 512 contiguous bytes per row and instruction.  The loop is unrolled by
         // the prefetch depth so every tile has its own registers, and it has no
         // branches, so the waits stay counted (vmcnt(N), never 0).
-        // A producer shares its SIMD with consumer wv-4.  Consumer 0 owns the
-        // largest lag group (its chains take 2 fp64 issue slots per step more than
-        // the others'), so its producer stages WT_ROWS0 rows and the other three
-        // WT_ROWS1 each: the four SIMDs finish a tile at about the same time.
+        // A producer shares its SIMD with consumer wv-4.  The split of the 32 rows
+        // between the producer next to consumer 0 (largest lag group) and the other
+        // three is a build constant; measured 2/10/10/10: 60.3 us, 5/9/9/9 and
+        // 8/8/8/8: 58.2 -- the walk of consumer 0, not the staging, sets the time.
         auto produce = [&](auto nrows_c, int q0) {
             constexpr int NR = decltype(nrows_c)::value;
+            constexpr int NL = FUSED ? (NR + 1) / 2 : NR;      // loads per tile: one per frame when fused
+            // (FUSED needs even row counts: rows come in channel pairs; the launcher checks)
+            auto uni64 = [](unsigned long long v) {            // wave-uniform value -> SGPR pair
+                return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                       (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+            };
             // row bases are wave-uniform: SGPR base + lane offset addressing
-            unsigned long long rowb[NR];
+            unsigned long long rowb[NL], outb[NR];
+            int mode[NL], w0s[NL], w1s[NL];
 #pragma unroll
-            for (int r = 0; r < NR; r++) {
-                const unsigned long long pa = (unsigned long long)(smp + (size_t)min(sub0 + q0 + r, nsub - 1) * n);
-                rowb[r] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) |
-                          (unsigned)__builtin_amdgcn_readfirstlane((int)pa);
+            for (int r = 0; r < NL; r++) {
+                if (FUSED) {
+                    const int sub = min(sub0 + q0 + 2 * r, nsub - 2);      // even: channel 0 of a frame
+                    rowb[r] = uni64((unsigned long long)(pcm + (size_t)sub * n));     // frame sub/2: [n][2]
+                    outb[2 * r] = uni64((unsigned long long)(smp_out + (size_t)sub * n));
+                    outb[2 * r + 1] = uni64((unsigned long long)(smp_out + (size_t)(sub + 1) * n));
+                    mode[r] = __builtin_amdgcn_readfirstlane(info[sub].ch_mode);
+                    w0s[r] = __builtin_amdgcn_readfirstlane(info[sub].wasted);
+                    w1s[r] = __builtin_amdgcn_readfirstlane(info[sub + 1].wasted);
+                } else {
+                    rowb[r] = uni64((unsigned long long)(smp + (size_t)min(sub0 + q0 + r, nsub - 1) * n));
+                }
             }
-            int2 pre[WT_AHEAD][NR];
-            auto issue_loads = [&](int2 (&dst)[NR], int tb) {
+            typedef typename std::conditional<FUSED, int4, int2>::type ld_t;
+            ld_t pre[WT_AHEAD][NL];
+            auto issue_loads = [&](ld_t (&dst)[NL], int tb) {
                 const int p = min(tb + 2 * lane, n - 2);       // past the block: clamped, weight 0
 #pragma unroll
-                for (int r = 0; r < NR; r++) dst[r] = *reinterpret_cast<const int2 *>(reinterpret_cast<const int32_t *>(rowb[r]) + p);
+                for (int r = 0; r < NL; r++)
+                    dst[r] = *reinterpret_cast<const ld_t *>(reinterpret_cast<const int32_t *>(rowb[r]) + (FUSED ? 2 * p : p));
             };
 #pragma unroll
             for (int a = 0; a < WT_AHEAD; a++) issue_loads(pre[a], a * AC_TILE);
@@ -996,13 +1036,37 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                     double *bn = wt_lds + bnx * WT_BUF + q0 * WT_STRIDE + PS_HH + lane - PS_HALF;
                     const double w0 = weight(tb + 2 * lane), w1 = weight(tb + 2 * lane + 1);
                     const bool tail = lane >= PS_HALF - PS_HH;        // positions 96..127
+                    const int pst = min(tb + 2 * lane, n - 2);        // padding tiles rewrite the last pair
 #pragma unroll
                     for (int r = 0; r < NR; r++) {
-                        const double v0 = (double)pre[a][r].x * w0;
-                        const double v1 = (double)pre[a][r].y * w1;
+                        int32_t x0, x1;                               // samples 2*lane, 2*lane+1 of row r
+                        if (FUSED) {
+                            const int4 v = *reinterpret_cast<const int4 *>(&pre[a][r / 2]);   // l0 r0 l1 r1
+                            const int md = mode[r / 2];
+                            // encode.c:668-693: channel 0 is mid / left / side(RS), channel 1 side / right
+                            const int32_t s0 = (int32_t)((uint32_t)v.x - (uint32_t)v.y);
+                            const int32_t s1 = (int32_t)((uint32_t)v.z - (uint32_t)v.w);
+                            if ((r & 1) == 0) {
+                                const int32_t m0 = (int32_t)((uint32_t)v.x + (uint32_t)v.y) >> 1;
+                                const int32_t m1 = (int32_t)((uint32_t)v.z + (uint32_t)v.w) >> 1;
+                                x0 = (md == FHIP_CH_MID_SIDE) ? m0 : (md == FHIP_CH_RIGHT_SIDE) ? s0 : v.x;
+                                x1 = (md == FHIP_CH_MID_SIDE) ? m1 : (md == FHIP_CH_RIGHT_SIDE) ? s1 : v.z;
+                                x0 >>= w0s[r / 2]; x1 >>= w0s[r / 2];
+                            } else {
+                                x0 = (md == FHIP_CH_MID_SIDE || md == FHIP_CH_LEFT_SIDE) ? s0 : v.y;
+                                x1 = (md == FHIP_CH_MID_SIDE || md == FHIP_CH_LEFT_SIDE) ? s1 : v.w;
+                                x0 >>= w1s[r / 2]; x1 >>= w1s[r / 2];
+                            }
+                            *reinterpret_cast<int2 *>(reinterpret_cast<int32_t *>(outb[r]) + pst) = make_int2(x0, x1);
+                        } else {
+                            const int2 v = *reinterpret_cast<const int2 *>(&pre[a][r]);
+                            x0 = v.x; x1 = v.y;
+                        }
+                        const double v0 = (double)x0 * w0;
+                        const double v1 = (double)x1 * w1;
                         bw[r * WT_STRIDE] = v0;
                         bw[r * WT_STRIDE + WT_ROW] = v1;
-                        if (tail) {                                   // = positions -32..-1 of the next tile
+                        if (tail && !wt_probe_nohalo) {                // = positions -32..-1 of the next tile
                             bn[r * WT_STRIDE] = v0;
                             bn[r * WT_STRIDE + WT_ROW] = v1;
                         }
@@ -1044,33 +1108,52 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
     // belong to the head (below), so their `a` is replaced by 0 -- a (+-0) product
     // leaves a running sum, which is never -0, bit for bit as it was.  SAME: the
     // group starts at lag 0, so b0 is a.
-    auto walk_tile = [&](const double *rowA_, const double *rowB_, auto first, auto same) {
+    // K = chains of this wave's group (NCH or NCH-1: the groups differ by at most one).
+    auto walk_tile = [&](const double *rowA_, const double *rowB_, auto first, auto same, auto kc) {
         constexpr bool FIRST = decltype(first)::value;
         constexpr bool SAME = decltype(same)::value;
+        constexpr int K = decltype(kc)::value;
         constexpr int NS = PS_HALF / PS_CH;
         // stages of operands in flight ahead of their use: two while a stage is short
-        constexpr int DEPTH = (NCH <= 3) ? 2 : 1;
+        constexpr int DEPTH = (K <= 3) ? 2 : 1;
         constexpr int NSET = DEPTH + 1;
-        // volatile: keeps the reads single ds_read_b64 (256 B/clk, 64 banks); merged
-        // into ds_read2_b64 they run at half that rate with 32-bank banking
+        // volatile: keeps the reads as written -- ds_read_b128 for `a`, single
+        // ds_read_b64 for b0 (merged into ds_read2_b64 they run at half rate)
         typedef const volatile double __attribute__((address_space(3))) lds_cvd;
-        lds_cvd *rowA = (lds_cvd *)rowA_, *rowB = (lds_cvd *)rowB_;
+        typedef double dbl2 __attribute__((ext_vector_type(2)));
+        typedef const volatile dbl2 __attribute__((address_space(3))) lds_cvd2;
+        lds_cvd2 *rowA = (lds_cvd2 *)rowA_;
+        lds_cvd *rowB = (lds_cvd *)rowB_;
         double A[NSET][PS_CH], B[NSET][PS_CH];
+        auto fetch = [&](int set, int stage) {
 #pragma unroll
-        for (int k = 0; k < DEPTH; k++)
-#pragma unroll
-            for (int u = 0; u < PS_CH; u++) {
-                A[k][u] = rowA[k * PS_CH + u];
-                if (!SAME) B[k][u] = rowB[k * PS_CH + u];
+            for (int u = 0; u < PS_CH; u += 2) {
+                const dbl2 v = rowA[(stage * PS_CH + u) / 2];
+                A[set][u] = v.x; A[set][u + 1] = v.y;
             }
+            if (!SAME) {
+#pragma unroll
+                for (int u = 0; u < PS_CH; u++) B[set][u] = rowB[stage * PS_CH + u];
+            }
+        };
+        constexpr int PER_STAGE = PS_CH / 2 + (SAME ? 0 : PS_CH);     // LDS reads per stage
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) fetch(k, k);
 #pragma unroll
         for (int st = 0; st < NS; st++) {
-            if (st + DEPTH < NS) {
-#pragma unroll
-                for (int u = 0; u < PS_CH; u++) {
-                    A[(st + DEPTH) % NSET][u] = rowA[(st + DEPTH) * PS_CH + u];
-                    if (!SAME) B[(st + DEPTH) % NSET][u] = rowB[(st + DEPTH) * PS_CH + u];
-                }
+            if (st + DEPTH < NS) fetch((st + DEPTH) % NSET, st + DEPTH);
+            // one wait per stage: everything but the reads just issued (and, two
+            // stages deep, the stage before them) has arrived
+            {
+                constexpr int w1 = PER_STAGE > 15 ? 15 : PER_STAGE;              // one newer stage in flight
+                constexpr int w2 = 2 * PER_STAGE > 15 ? 15 : 2 * PER_STAGE;      // two
+                constexpr int enc1 = (3 << 14) | (w1 << 8) | (7 << 4) | 0xF;
+                constexpr int enc2 = (3 << 14) | (w2 << 8) | (7 << 4) | 0xF;
+                constexpr int enc0 = (3 << 14) | (0 << 8) | (7 << 4) | 0xF;
+                const int newer = (st + DEPTH < NS ? 1 : 0) + ((DEPTH == 2 && st + 1 < NS) ? 1 : 0);
+                if (newer == 2) __builtin_amdgcn_s_waitcnt(enc2);
+                else if (newer == 1) __builtin_amdgcn_s_waitcnt(enc1);
+                else __builtin_amdgcn_s_waitcnt(enc0);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1079,15 +1162,15 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                 double a = A[st % NSET][u];
                 if (FIRST && 2 * (st * PS_CH + u) <= FHIP_MAX_ORDER)            // steps that can hold p <= maxlag
                     a = (2 * (st * PS_CH + u) + pi > maxlag) ? a : 0.0;
-                double pr[NCH];
+                double pr[K];
                 pr[0] = a * x;
 #pragma unroll
-                for (int j = 1; j < NCH; j++) pr[j] = a * cy[j];
+                for (int j = 1; j < K; j++) pr[j] = a * cy[j];
 #pragma unroll
-                for (int j = 0; j < NCH; j++) S[j] = S[j] + pr[j];
+                for (int j = 0; j < K; j++) S[j] = S[j] + pr[j];
 #pragma unroll
-                for (int j = NCH - 1; j >= 2; j--) cy[j] = cy[j - 1];
-                if (NCH > 1) cy[1] = x;
+                for (int j = K - 1; j >= 2; j--) cy[j] = cy[j - 1];
+                if (K > 1) cy[1] = x;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1117,12 +1200,17 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                 }
             }
         }
-        if (l0 == 0) {
-            if (t == 0) walk_tile(buf + offA, buf + offB, std::true_type{}, std::true_type{});
-            else walk_tile(buf + offA, buf + offB, std::false_type{}, std::true_type{});
-        } else {
-            if (t == 0) walk_tile(buf + offA, buf + offB, std::true_type{}, std::false_type{});
-            else walk_tile(buf + offA, buf + offB, std::false_type{}, std::false_type{});
+        using KF = std::integral_constant<int, NCH>;
+        using KL = std::integral_constant<int, (NCH > 1) ? NCH - 1 : 1>;
+        if (l0 == 0) {                                     // group 0 always has NCH chains
+            if (t == 0) walk_tile(buf + offA, buf + offB, std::true_type{}, std::true_type{}, KF{});
+            else walk_tile(buf + offA, buf + offB, std::false_type{}, std::true_type{}, KF{});
+        } else if (nch == NCH) {
+            if (t == 0) walk_tile(buf + offA, buf + offB, std::true_type{}, std::false_type{}, KF{});
+            else walk_tile(buf + offA, buf + offB, std::false_type{}, std::false_type{}, KF{});
+        } else if (nch > 0) {
+            if (t == 0) walk_tile(buf + offA, buf + offB, std::true_type{}, std::false_type{}, KL{});
+            else walk_tile(buf + offA, buf + offB, std::false_type{}, std::false_type{}, KL{});
         }
         bi = (bi == WT_NBUF - 1) ? 0 : bi + 1;
         TICK(tc2);
@@ -3143,21 +3231,23 @@ void k_vbs_split(const int32_t *__restrict__ pcm, int nblocks, int block_size, i
 // ---------------------------------------------------------------------------
 
 hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *pcm,
-                          int nframes, int n, int32_t *smp, fhip_subframe_info *info)
+                          int nframes, int n, int32_t *smp, fhip_subframe_info *info, bool decide_only)
 {
     const int nch = p.channels;
     if (nframes == 0) return hipSuccess;
     if (nch == 2 && (n & 3) == 0 && n <= 4096) {
         const int est = p.stereo_method == 1 ? 1 : 0;
         const int quads = n >> 2;
-        if (quads <= NT)
-            hipLaunchKernelGGL(k_prepare_stereo<1>, dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est);
-        else if (quads <= 2 * NT)
-            hipLaunchKernelGGL(k_prepare_stereo<2>, dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est);
-        else
-            hipLaunchKernelGGL(k_prepare_stereo<4>, dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est);
+#define LAUNCH_PS(M_, A_) hipLaunchKernelGGL((k_prepare_stereo<M_, A_>), dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est)
+        if (decide_only) {
+            if (quads <= NT) LAUNCH_PS(1, false); else if (quads <= 2 * NT) LAUNCH_PS(2, false); else LAUNCH_PS(4, false);
+        } else {
+            if (quads <= NT) LAUNCH_PS(1, true); else if (quads <= 2 * NT) LAUNCH_PS(2, true); else LAUNCH_PS(4, true);
+        }
+#undef LAUNCH_PS
         return hipGetLastError();
     }
+    if (decide_only) return hipErrorInvalidValue;
     if (nch != 2) {
         hipLaunchKernelGGL(k_prepare_multi, dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, nch,
                            p.bits_per_sample);
@@ -3175,54 +3265,71 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
     return hipGetLastError();
 }
 
+namespace {
+// Which K1 kernel serves a batch: a measured time model in ns (MI355X; rounds =
+// workgroup waves over the chip, step = one walk step):
+//   wt : rounds x (n/2 x max(30, 6.2 NCH) + 3200)      32 subframes per workgroup, whole tiles only
+//   ps : rounds x (n/2 x 39 + 1000)                      Gp subframes per wave
+//   cur: rounds x (n x 20 + 1000)                        G subframes per wave
+struct ac_choice { int kernel; int G, nl2, Gp, lps, ge, ne, no; };   // kernel: 0 cur, 1 ps, 2 wt
+ac_choice pick_autocorr(int nsub, int n, int max_order)
+{
+    ac_choice ch{};
+    const int simds = 1024;
+    // k_autocorr: lag pairs, both parities in one lane: n positions x 4 fp64 ops
+    ch.nl2 = (max_order + 2) / 2;                 // lag pairs {0,1},{2,3},...
+    ch.G = WAVE / ch.nl2;
+    if (ch.G > AC_GMAX) ch.G = AC_GMAX;
+    if (ch.G < 1) ch.G = 1;
+    const long waves_cur = (nsub + ch.G - 1) / ch.G;
+    // k_autocorr_ps: lag triples, one parity per lane: n/2 steps x 6 fp64 ops
+    ch.ne = max_order / 2 + 1; ch.no = (max_order + 1) / 2;
+    ch.ge = (ch.ne + 2) / 3;
+    const int go = (ch.no + 2) / 3;
+    ch.lps = 2 * (ch.ge + go);
+    ch.Gp = WAVE / ch.lps;
+    if (ch.Gp > PS_GMAX) ch.Gp = PS_GMAX;
+    const double t_cur = (double)((waves_cur + simds - 1) / simds) * (n * 20.0 + 1000.0);
+    const double t_ps = (ch.Gp >= 1) ? (double)(((nsub + ch.Gp - 1) / ch.Gp + simds - 1) / simds) * (0.5 * n * 39.0 + 1000.0) : 1e30;
+    double t_wt = 1e30;
+    if ((n % AC_TILE) == 0) {
+        const int e0 = (ch.ne + 1) / 2;
+        const double per_step = (6.2 * e0 > 30.0) ? 6.2 * e0 : 30.0;
+        t_wt = (double)(((nsub + WT_SUB - 1) / WT_SUB + 255) / 256) * (0.5 * n * per_step + 3200.0);
+    }
+    ch.kernel = (t_wt <= t_ps && t_wt <= t_cur) ? 2 : (t_ps < t_cur) ? 1 : 0;
+    if (const char *force = getenv("FHIP_AC_KERNEL")) {       // "cur" / "ps" / "wt": measurements only
+        if (force[0] == 'c') ch.kernel = 0;
+        if (force[0] == 'p' && ch.Gp >= 1) ch.kernel = 1;
+        if (force[0] == 'w' && (n % AC_TILE) == 0) ch.kernel = 2;
+    }
+    return ch;
+}
+}  // namespace
+
+bool autocorr_fuses_prepare(const fhip_params &p, int nsub, int n)
+{
+    // Off by default: measured on configs[1] the decision-only K0 saves 18 us and 134 MB
+    // of HBM writes, but the producers' extra work costs K1 11 us on the SIMDs that
+    // are its bottleneck, and the step ends up 2 % slower (0.2106 vs 0.2057 ms).
+    static const bool on = getenv("FHIP_FUSE") != nullptr && (WT_ROWS0 % 2) == 0 && (WT_ROWS1 % 2) == 0;
+    if (!on || p.channels != 2 || (n & 3) != 0 || n > 4096 || (nsub & 1)) return false;
+    return pick_autocorr(nsub, n, p.max_prediction_order).kernel == 2;
+}
+
 hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
-                           int max_order, double *autoc)
+                           int max_order, double *autoc, const int32_t *pcm_fused,
+                           int32_t *smp_out, const fhip_subframe_info *info)
 {
     if (nsub == 0) return hipSuccess;
     // the window constant is computed on the host exactly as lpc.c:34 does
     const double c = (2.0 / (n - 1.0)) - 1.0;
-    const int simds = 1024;
-
-    // k_autocorr: lag pairs, both parities in one lane: n positions x 4 fp64 ops
-    const int nl2 = (max_order + 2) / 2;          // lag pairs {0,1},{2,3},...
-    int G = WAVE / nl2;
-    if (G > AC_GMAX) G = AC_GMAX;
-    if (G < 1) G = 1;
-    const long waves_cur = (nsub + G - 1) / G;
-    const long cost_cur = ((waves_cur + simds - 1) / simds) * 4L * n;
-
-    // k_autocorr_ps: lag triples, one parity per lane: n/2 steps x 6 fp64 ops
-    const int ne = max_order / 2 + 1, no = (max_order + 1) / 2;
-    const int ge = (ne + 2) / 3, go = (no + 2) / 3;
-    const int lps = 2 * (ge + go);
-    int Gp = WAVE / lps;
-    if (Gp > PS_GMAX) Gp = PS_GMAX;
-    long cost_ps = -1;
-    if (Gp >= 1) {
-        const long waves_ps = (nsub + Gp - 1) / Gp;
-        cost_ps = ((waves_ps + simds - 1) / simds) * 3L * n;
-    }
-    const char *force = getenv("FHIP_AC_KERNEL");         // "cur" / "ps": measurements only
-    bool use_ps = cost_ps > 0 && cost_ps < cost_cur;
-    if (force && force[0] == 'c') use_ps = false;
-    if (force && force[0] == 'p' && cost_ps > 0) use_ps = true;
-
-    // k_autocorr_wt: whole tiles only.  Which kernel: a measured time model in ns
-    // (MI355X; rounds = workgroup waves over the chip, step = one walk step):
-    //   wt : rounds x (n/2 x max(30, 6.2 NCH) + 3200)      32 subframes per workgroup
-    //   ps : rounds x (n/2 x 39 + 1000)                      Gp subframes per wave
-    //   cur: rounds x (n x 20 + 1000)                        G subframes per wave
+    const ac_choice ch = pick_autocorr(nsub, n, max_order);
+    const int ne = ch.ne, no = ch.no, Gp = ch.Gp, lps = ch.lps, ge = ch.ge, nl2 = ch.nl2;
+    int G = ch.G;
+    const bool use_wt = ch.kernel == 2, use_ps = ch.kernel == 1;
+    if (pcm_fused && !use_wt) return hipErrorInvalidValue;
     const int e0 = (ne + 1) / 2, e1 = ne - e0, o0 = (no + 1) / 2, o1 = no - o0;
-    bool use_wt = false;
-    if ((n % AC_TILE) == 0) {
-        const double per_step = (6.2 * e0 > 30.0) ? 6.2 * e0 : 30.0;
-        const double t_wt = (double)(((nsub + WT_SUB - 1) / WT_SUB + 255) / 256) * (0.5 * n * per_step + 3200.0);
-        const double t_ps = (cost_ps > 0) ? (double)(((nsub + Gp - 1) / Gp + simds - 1) / simds) * (0.5 * n * 39.0 + 1000.0) : 1e30;
-        const double t_cur = (double)((waves_cur + simds - 1) / simds) * (n * 20.0 + 1000.0);
-        use_wt = t_wt <= t_ps && t_wt <= t_cur;
-        if (!use_wt) use_ps = t_ps < t_cur;
-        if (force) use_wt = (force[0] == 'w');
-    }
     if (use_wt) {
         wt_groups gr;
         gr.l0[0] = 0;          gr.nch[0] = e0;
@@ -3232,21 +3339,25 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
         const int nch = e0;                                    // e0 >= e1, o0, o1
         const int blocks = (nsub + WT_SUB - 1) / WT_SUB;
         const size_t lds = sizeof(double) * (size_t)WT_NBUF * WT_BUF;
-#define LAUNCH_WT(N_)                                                                        \
-    case N_: {                                                                               \
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_autocorr_wt<N_>), \
+#define LAUNCH_WT2(N_, F_)                                                                   \
+    do {                                                                                     \
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_autocorr_wt<N_, F_>), \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (er != hipSuccess) return er;                                                     \
-        hipLaunchKernelGGL(k_autocorr_wt<N_>, dim3(blocks), dim3(8 * WAVE), lds, st, smp, autoc, \
-                           nsub, n, max_order, gr, c);                                       \
-        break;                                                                               \
-    }
+        hipLaunchKernelGGL((k_autocorr_wt<N_, F_>), dim3(blocks), dim3(8 * WAVE), lds, st, smp, \
+                           autoc, nsub, n, max_order, gr, c, pcm_fused, smp_out, info);      \
+    } while (0)
+#define LAUNCH_WT(N_)                                                                        \
+    case N_:                                                                                 \
+        if (pcm_fused) LAUNCH_WT2(N_, true); else LAUNCH_WT2(N_, false);                     \
+        break;
         switch (nch) {
             LAUNCH_WT(1) LAUNCH_WT(2) LAUNCH_WT(3) LAUNCH_WT(4) LAUNCH_WT(5)
             LAUNCH_WT(6) LAUNCH_WT(7) LAUNCH_WT(8) LAUNCH_WT(9)
         default: return hipErrorInvalidValue;
         }
 #undef LAUNCH_WT
+#undef LAUNCH_WT2
         return hipGetLastError();
     }
     if (use_ps) {

@@ -362,3 +362,34 @@ def test_every_fast_path_geometry(oracle, n, kw):
         p = flake_amd.level_params(5, channels=ch, bits_per_sample=bps, block_size=n, **kw)
         pcm = flake_amd.synth_pcm(3, n, ch, bps, first_frame=n // 256)
         check(oracle, p, pcm, n, f"n{n}")
+
+
+def test_fused_prepare_path_subprocess():
+    """FHIP_FUSE=1: K0 only decides, the K1 producers apply channel mode / wasted
+    bits and write the samples.  The switch is read once per process, so the
+    comparison with the oracle runs in a child."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import flake_amd
+        from oraclelib import Oracle
+        from cases import stereo_frames
+        from parity import assert_info_equal, assert_residual_equal, assert_bits_equal
+        o = Oracle()
+        fr = stereo_frames(4096, 16)
+        pcm = np.concatenate([np.stack([fr[k] for k in sorted(fr)]), flake_amd.synth_pcm(40, 4096, 2, 16)])
+        for kw in (dict(order_method=flake_amd.OM_MAX), dict()):
+            p = flake_amd.level_params(5, **kw)
+            with flake_amd.Encoder(p, max_frames=pcm.shape[0]) as enc:
+                got = enc.encode_subframes(pcm, 4096)
+            exp = o.encode_subframes_batch(p, pcm, 4096, slot_bytes=got["slot_bytes"])
+            assert_info_equal(got["info"], exp["info"], "fused")
+            assert_residual_equal(got["residual"], exp["residual"], exp["info"], "fused")
+            assert_bits_equal(got["rice_bits"], exp["rice_bits"], exp["info"], "fused")
+        print("fused ok")
+    """ % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, FHIP_FUSE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fused ok" in r.stdout, r.stdout + r.stderr

@@ -62,7 +62,7 @@ def build_host(force: bool = False) -> str:
         os.makedirs(LIB, exist_ok=True)
         _run(["gcc", "-std=gnu99", "-O2", "-Wall", "-fPIC", "-shared", "-fvisibility=hidden",
               "-I", os.path.join(ROOT, "include"), *srcs, "-o", out,
-              "-L", LIB, "-lflakehip", "-Wl,-rpath,$ORIGIN", "-lm"])
+              "-L", LIB, "-lflakehip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"])
     return out
 
 
@@ -74,7 +74,7 @@ def build_flake_names(force: bool = False) -> str:
     if force or _stale(out, HOST_DEPS):
         _run(["gcc", "-std=gnu99", "-O2", "-Wall", "-fPIC", "-shared", "-fvisibility=hidden",
               "-DFLAKE_AMD_EXPORT_FLAKE_NAMES", "-I", os.path.join(ROOT, "include"), *srcs, "-o", out,
-              "-L", LIB, "-lflakehip", "-Wl,-rpath,$ORIGIN", "-lm"])
+              "-L", LIB, "-lflakehip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"])
     return out
 
 
@@ -86,7 +86,7 @@ def build_cli(force: bool = False) -> str:
         return ""
     if force or _stale(out, ["host/flake_amd_cli.c", "../include/flake_amd.h"]):
         _run(["gcc", "-std=gnu99", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", out,
-              "-L", LIB, "-lflake_amd", "-lflakehip", "-Wl,-rpath,$ORIGIN", "-lm"])
+              "-L", LIB, "-lflake_amd", "-lflakehip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"])
     return out
 
 

@@ -246,19 +246,21 @@ int run_pipeline(fhip_ctx *c, const int32_t *pcm, int nframes, int n,
     return FHIP_OK;
 }
 
-int check_batch(fhip_ctx *c, const fhip_batch *b)
+int check_batch(fhip_ctx *c, const fhip_batch *b, bool host = false)
 {
-    if (!c || !b || !b->pcm || !b->info) return fail(c, FHIP_E_INVALID, "null batch argument");
+    // host entry: frames alone are a complete result, info / rice_bits optional then
+    const bool lean = host && b && b->frames;
+    if (!c || !b || !b->pcm || (!b->info && !lean)) return fail(c, FHIP_E_INVALID, "null batch argument");
     if (b->nframes < 0 || b->nframes > c->max_frames)
         return fail(c, FHIP_E_INVALID, "nframes exceeds the handle's max_frames");
     if (b->block_size < 1 || b->block_size > c->p.block_size)
         return fail(c, FHIP_E_INVALID, "block_size out of range (encode.c:987)");
     if (b->block_size > FHIP_MAX_BLOCK)
         return fail(c, FHIP_E_UNSUPPORTED, "block_size above FHIP_MAX_BLOCK");
-    if (b->rice_bits && (b->rice_slot_bytes < 4 || (b->rice_slot_bytes & 3)))
+    if ((b->rice_bits || lean) && (b->rice_slot_bytes < 4 || (b->rice_slot_bytes & 3)))
         return fail(c, FHIP_E_INVALID, "rice_slot_bytes must be a positive multiple of 4");
     if (b->frames) {
-        if (!b->rice_bits || !b->frame_bytes)
+        if ((!b->rice_bits && !lean) || !b->frame_bytes)
             return fail(c, FHIP_E_INVALID, "frames need rice_bits and frame_bytes");
         if ((b->frame_stride & 3) || b->frame_stride < fhip_frame_stride(&c->p, b->block_size))
             return fail(c, FHIP_E_INVALID, "frame_stride too small or not a multiple of 4");
@@ -445,12 +447,13 @@ static int ensure_staging(fhip_ctx *c, size_t bits_bytes)
 
 int fhip_encode_subframes(fhip_ctx *c, const fhip_batch *b)
 {
-    int rc = check_batch(c, b);
+    int rc = check_batch(c, b, true);
     if (rc != FHIP_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t nch = (size_t)c->p.channels, n = (size_t)b->block_size;
     const size_t nsub = (size_t)b->nframes * nch;
-    const size_t bits_bytes = b->rice_bits ? nsub * (size_t)b->rice_slot_bytes : 0;
+    const bool want_bits = b->rice_bits || b->frames;      // K4 reads the sections on the device
+    const size_t bits_bytes = want_bits ? nsub * (size_t)b->rice_slot_bytes : 0;
     rc = ensure_staging(c, bits_bytes);
     if (rc != FHIP_OK) return rc;
     if (nsub == 0) return FHIP_OK;
@@ -458,7 +461,6 @@ int fhip_encode_subframes(fhip_ctx *c, const fhip_batch *b)
     double *d_autoc_out = b->autoc ? c->d_autoc : nullptr;
     HIP_TRY(c, hipMemcpyAsync(c->d_pcm, b->pcm, nsub * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_info, 0, nsub * sizeof(fhip_subframe_info), c->stream));
-    if (bits_bytes) HIP_TRY(c, hipMemsetAsync(c->d_bits, 0, bits_bytes, c->stream));
     FrameOut fo{nullptr, 0, nullptr, 0};
     if (b->frames) {
         const size_t fb = (size_t)b->nframes * (size_t)b->frame_stride;
@@ -477,10 +479,11 @@ int fhip_encode_subframes(fhip_ctx *c, const fhip_batch *b)
         }
     }
     rc = run_pipeline(c, c->d_pcm, b->nframes, b->block_size, c->d_info,
-                      b->residual ? c->d_res : nullptr, b->rice_bits ? c->d_bits : nullptr,
+                      b->residual ? c->d_res : nullptr, want_bits ? c->d_bits : nullptr,
                       b->rice_slot_bytes, nullptr, d_autoc_out, fo);
     if (rc != FHIP_OK) return rc;
-    HIP_TRY(c, hipMemcpyAsync(b->info, c->d_info, nsub * sizeof(fhip_subframe_info), hipMemcpyDeviceToHost, c->stream));
+    if (b->info)
+        HIP_TRY(c, hipMemcpyAsync(b->info, c->d_info, nsub * sizeof(fhip_subframe_info), hipMemcpyDeviceToHost, c->stream));
     if (b->residual)
         HIP_TRY(c, hipMemcpyAsync(b->residual, c->d_res, nsub * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     if (b->rice_bits)
@@ -564,7 +567,6 @@ int fhip_encode_residual(fhip_ctx *c, const int32_t *samples, int nsub, int n,
     const fhip_params &p = c->p;
     HIP_TRY(c, hipMemcpyAsync(c->d_smp, samples, ns * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_info, info, ns * sizeof(fhip_subframe_info), hipMemcpyHostToDevice, c->stream));
-    if (bits_bytes) HIP_TRY(c, hipMemsetAsync(c->d_bits, 0, bits_bytes, c->stream));
     if (p.prediction_type == 2 && n > p.max_prediction_order && n >= 5) {
         HIP_TRY(c, fhip::launch_autocorr(c->stream, c->d_smp, nsub, n, p.max_prediction_order, c->d_autoc));
         HIP_TRY(c, fhip::launch_lpc(c->stream, c->d_autoc, nsub, p.max_prediction_order,
@@ -629,7 +631,6 @@ int fhip_calc_rice_params(fhip_ctx *c, const int32_t *residual, int nsub, int n,
     for (auto &s : seed) s.obits = bps;
     HIP_TRY(c, hipMemcpyAsync(c->d_smp, residual, ns * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_info, seed.data(), ns * sizeof(fhip_subframe_info), hipMemcpyHostToDevice, c->stream));
-    if (bits_bytes) HIP_TRY(c, hipMemsetAsync(c->d_bits, 0, bits_bytes, c->stream));
     HIP_TRY(c, fhip::launch_encode(c->stream, p, c->d_smp, nsub, n, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
                                    c->d_info, nullptr, rice_bits ? c->d_bits : nullptr,
                                    rice_slot_bytes, pred_order, lpc ? 1 : 0));

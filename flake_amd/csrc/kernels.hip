@@ -1170,7 +1170,7 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                 for (int j = 0; j < K; j++) S[j] = S[j] + pr[j];
 #pragma unroll
                 for (int j = K - 1; j >= 2; j--) cy[j] = cy[j - 1];
-                if (K > 1) cy[1] = x;
+                if constexpr (K > 1) cy[1] = x;
             }
             __builtin_amdgcn_sched_barrier(0);
         }

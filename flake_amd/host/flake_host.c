@@ -17,6 +17,7 @@
  * side information and already-packed bits.  Written from the behaviour of
  * the reference; citations are relative to the reference tree.
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -39,6 +40,7 @@ typedef struct host_ctx {
     int last_frame;
     int host_assembly;                    /* FLAKE_AMD_HOST_ASSEMBLY=1: build frames on the CPU */
     int host_vbs;                         /* FLAKE_AMD_HOST_VBS=1: split blocks on the CPU */
+    int md5_off;                          /* FLAKE_AMD_MD5=0: STREAMINFO carries the all-zero "not computed" MD5 */
     fa_md5 md5;
     /* single-frame buffer of flake_amd_encode_frame */
     uint8_t *frame_buffer;
@@ -236,7 +238,8 @@ FLAKE_AMD_API int flake_amd_get_streaminfo(const FlakeAmdContext *s, FlakeAmdStr
     si->channels = (unsigned)s->channels;
     si->bits_per_sample = (unsigned)s->bits_per_sample;
     si->samples = s->samples;
-    fa_md5_final(&c->md5, si->md5sum);
+    if (c->md5_off) memset(si->md5sum, 0, 16);
+    else fa_md5_final(&c->md5, si->md5sum);
     return 0;
 }
 
@@ -340,6 +343,7 @@ FLAKE_AMD_API int flake_amd_encode_init(FlakeAmdContext *s)
     const char *eh = getenv("FLAKE_AMD_HOST_ASSEMBLY");
     c->host_assembly = eh && eh[0] == '1';
     { const char *ev = getenv("FLAKE_AMD_HOST_VBS"); c->host_vbs = ev && ev[0] == '1'; }
+    { const char *ev = getenv("FLAKE_AMD_MD5"); c->md5_off = ev && ev[0] == '0'; }
     c->max_batch = eb ? atoi(eb) : 1024;
     if (c->max_batch < 1) c->max_batch = 1;
     /* a VBS block may turn into up to 8 frames of the smallest size */
@@ -547,8 +551,11 @@ static int run_gpu(host_ctx *c, const int32_t *pcm, int nframes, int n, size_t f
     fhip_batch b;
     memset(&b, 0, sizeof b);
     b.pcm = pcm; b.nframes = nframes; b.block_size = n;
-    b.info = c->info + first_sub;
-    b.rice_bits = c->bits + first_sub * (size_t)c->slot;
+    if (c->host_assembly) {
+        /* the CPU builds the frames from side information + residual sections */
+        b.info = c->info + first_sub;
+        b.rice_bits = c->bits + first_sub * (size_t)c->slot;
+    }
     b.rice_slot_bytes = c->slot;
     /* whole frames come back assembled (K4); numbers were filled by the caller */
     b.frames = c->frames + first_frame * (size_t)c->fstride;
@@ -562,6 +569,17 @@ static int run_gpu(host_ctx *c, const int32_t *pcm, int nframes, int n, size_t f
     return rc;
 }
 
+/* encode.c:1006 md5_accumulate over the batch's input, on a helper thread: the
+ * hash is sequential over the whole stream (~0.5 GB/s) and would otherwise sit
+ * behind every GPU batch. */
+typedef struct { fa_md5 *m; const int32_t *pcm; size_t nvalues; int bps; } md5_job;
+static void *md5_worker(void *arg)
+{
+    md5_job *j = (md5_job *)arg;
+    fa_md5_pcm(j->m, j->pcm, j->nvalues, j->bps);
+    return NULL;
+}
+
 /* Encode `count` blocks starting at pcm (each block_size samples/channel). */
 static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pcm, int count,
                               int block_size, uint8_t *out, size_t cap, int *frame_sizes)
@@ -573,6 +591,12 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
     piece *pieces = (piece *)malloc(sizeof(piece) * (size_t)count * VBS_PARTS);
     int32_t *scratch = (int32_t *)malloc(sizeof(int32_t) * (size_t)block_size);
     if (!pieces || !scratch) { free(pieces); free(scratch); return -1; }
+    /* hash a copy of the state; it is committed only if the batch succeeds */
+    fa_md5 md5_next = c->md5;
+    md5_job job = { &md5_next, pcm, (size_t)count * bstride, c->hp.bits_per_sample };
+    pthread_t md5_thread;
+    int md5_running = 0, md5_done = 0;
+    if (!c->md5_off) md5_running = pthread_create(&md5_thread, NULL, md5_worker, &job) == 0;
     int np = 0;
     int32_t *dev_nf = NULL, *dev_sizes = NULL;
     if (vbs && !c->host_vbs) {
@@ -582,6 +606,7 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
         if (!dev_nf || !dev_sizes ||
             fhip_vbs_split(c->hip, pcm, count, block_size, dev_nf, dev_sizes) != FHIP_OK) {
             snprintf(c->err, sizeof c->err, "fhip_vbs_split failed");
+            if (md5_running) pthread_join(md5_thread, NULL);
             free(dev_nf); free(dev_sizes); free(pieces); free(scratch);
             return -1;
         }
@@ -688,8 +713,14 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
         }
         total = (long long)pos;
     }
-    fa_md5_pcm(&c->md5, pcm, (size_t)count * bstride, c->hp.bits_per_sample);   /* encode.c:1006 */
+    if (!c->md5_off) {
+        if (md5_running) { pthread_join(md5_thread, NULL); md5_running = 0; }
+        else md5_worker(&job);                         /* no thread: hash here */
+        md5_done = 1;
+    }
 out:
+    if (md5_running) pthread_join(md5_thread, NULL);
+    if (md5_done && total >= 0) c->md5 = md5_next;
     free(dev_nf); free(dev_sizes);
     free(pieces); free(scratch); free(slot_of); free(done); free(num_of);
     return total;

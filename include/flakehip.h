@@ -174,7 +174,10 @@ FHIP_API int64_t fhip_frame_stride(const fhip_params *p, int block_size);
 
 FHIP_API int fhip_encode_subframes_dev(fhip_ctx *ctx, const fhip_batch *b);
 
-/* Same with HOST pointers: copies in, runs, copies out, synchronises. */
+/* Same with HOST pointers: copies in, runs, copies out, synchronises.  When
+ * `frames` is requested, `info` and `rice_bits` may be NULL (the frames are
+ * complete; the sections then live only in a device workspace of
+ * rice_slot_bytes per subframe, which must still be given). */
 FHIP_API int fhip_encode_subframes(fhip_ctx *ctx, const fhip_batch *b_host);
 
 /* ---- stage entry points (HOST pointers, synchronous) ---------------- */

@@ -41,6 +41,12 @@ typedef struct host_ctx {
     int host_assembly;                    /* FLAKE_AMD_HOST_ASSEMBLY=1: build frames on the CPU */
     int host_vbs;                         /* FLAKE_AMD_HOST_VBS=1: split blocks on the CPU */
     int md5_off;                          /* FLAKE_AMD_MD5=0: STREAMINFO carries the all-zero "not computed" MD5 */
+    /* FLAKE_AMD_LOOKAHEAD=N: flake_encode_frame() queues up to N whole blocks and
+     * encodes them as one GPU batch (see flake_amd_encode_frame) */
+    int lookahead;
+    int32_t *q_pcm;
+    int q_count;
+    unsigned long long q_seen;            /* samples per channel handed in so far */
     fa_md5 md5;
     /* single-frame buffer of flake_amd_encode_frame */
     uint8_t *frame_buffer;
@@ -336,6 +342,20 @@ FLAKE_AMD_API int flake_amd_encode_init(FlakeAmdContext *s)
     c->ch_code = s->channels - 1;
     c->max_frame_size = frame_verbatim_size(c, s->params.block_size);   /* encode.c:446-450 */
     c->frame_buffer_size = c->max_frame_size * 3 / 2;
+    {
+        /* the look-ahead queue needs the stream length (to know the last block) */
+        const char *el = getenv("FLAKE_AMD_LOOKAHEAD");
+        c->lookahead = (el && s->samples > 0) ? atoi(el) : 0;
+        if (c->lookahead < 2) c->lookahead = 0;
+        if (c->lookahead > 4096) c->lookahead = 4096;
+        if (c->lookahead) {
+            const long long one = (long long)c->frame_buffer_size + 8 * 32;    /* a VBS block: up to 8 frames */
+            if (one * c->lookahead > 0x7FFFFFFFLL) c->lookahead = (int)(0x7FFFFFFFLL / one);
+            c->frame_buffer_size = (int)(one * c->lookahead);
+            c->q_pcm = (int32_t *)malloc(sizeof(int32_t) * (size_t)(c->lookahead + 1) *
+                                         (size_t)s->params.block_size * (size_t)s->channels);
+        }
+    }
     c->frame_buffer = (uint8_t *)calloc((size_t)c->frame_buffer_size, 1);
     fa_md5_init(&c->md5);
 
@@ -346,6 +366,7 @@ FLAKE_AMD_API int flake_amd_encode_init(FlakeAmdContext *s)
     { const char *ev = getenv("FLAKE_AMD_MD5"); c->md5_off = ev && ev[0] == '0'; }
     c->max_batch = eb ? atoi(eb) : 1024;
     if (c->max_batch < 1) c->max_batch = 1;
+    if (c->lookahead > c->max_batch) c->max_batch = c->lookahead;
     /* a VBS block may turn into up to 8 frames of the smallest size */
     const int max_frames = c->max_batch * (s->params.variable_block_size ? VBS_PARTS : 1);
     int rc = fhip_create(&c->hip, ed ? atoi(ed) : 0, hp, max_frames);
@@ -384,7 +405,7 @@ FLAKE_AMD_API void flake_amd_encode_close(FlakeAmdContext *s)
     host_ctx *c = (host_ctx *)s->private_ctx;
     if (c) {
         if (c->hip) fhip_destroy(c->hip);
-        free(c->frame_buffer); free(c->info); free(c->bits); free(c->gather);
+        free(c->frame_buffer); free(c->info); free(c->bits); free(c->gather); free(c->q_pcm);
         free(c->frames); free(c->fbytes); free(c->fnum);
         free(c);
     }
@@ -762,12 +783,40 @@ FLAKE_AMD_API long long flake_amd_encode_frames(FlakeAmdContext *s, const int *s
     return total;
 }
 
+/* flake_encode_frame(), flake.h:229 / encode.c:979-1008.
+ *
+ * With FLAKE_AMD_LOOKAHEAD=N (and FlakeContext.samples known) an unmodified
+ * caller loop (flake/flake.c:624-663: read block, flake_encode_frame, write fs
+ * bytes from flake_get_buffer() if fs > 0) gets GPU batching: whole blocks are
+ * copied into a queue and the call returns 0 -- which libflake's callers already
+ * treat as "nothing to write" -- until N blocks are queued, the stream's last
+ * sample has been handed in, or a short block arrives; that call encodes the
+ * queue as one batch and returns all its frames back to back in the buffer,
+ * exactly as a VBS call returns several frames (vbs.c:104-116).  The stream is
+ * byte-identical to the unqueued one.  A caller that stops before `samples` are
+ * in loses the queued blocks, so the switch is opt-in. */
 FLAKE_AMD_API int flake_amd_encode_frame(FlakeAmdContext *s, const int *samples, int block_size)
 {
     if (!s || !samples || !s->private_ctx) return -1;
     host_ctx *c = (host_ctx *)s->private_ctx;
     if (block_size < 1 || block_size > s->params.block_size) return -1;
     const int short_block = block_size != s->params.block_size;
+    if (c->lookahead && c->q_pcm && !c->last_frame) {
+        const size_t bstride = (size_t)s->params.block_size * (size_t)s->channels;
+        memcpy(c->q_pcm + (size_t)c->q_count * bstride, samples,
+               sizeof(int32_t) * (size_t)block_size * (size_t)s->channels);
+        c->q_seen += (unsigned long long)block_size;
+        if (!short_block) c->q_count++;
+        const int flush = short_block || c->q_count >= c->lookahead || c->q_seen >= s->samples;
+        if (!flush) return 0;
+        const int cnt = c->q_count;
+        c->q_count = 0;
+        if (c->q_seen >= s->samples) c->lookahead = 0;          /* past the announced end: block by block */
+        const long long w = flake_amd_encode_frames(s, c->q_pcm, cnt, s->params.block_size,
+                                                    short_block ? block_size : 0, c->frame_buffer,
+                                                    (size_t)c->frame_buffer_size, NULL);
+        return (w < 0 || w > 0x7FFFFFFFLL) ? -1 : (int)w;
+    }
     long long w = flake_amd_encode_frames(s, samples, short_block ? 0 : 1, short_block ? s->params.block_size : block_size,
                                           short_block ? block_size : 0, c->frame_buffer,
                                           (size_t)c->frame_buffer_size, NULL);

@@ -71,6 +71,9 @@ FLAKE_AMD_API int flake_amd_validate_params(const FlakeAmdContext *s);
 /* flake_encode_init(), encode.c:378-472: returns the header length (bytes in
  * s->header) or a negative code.  The HIP device is FLAKE_AMD_DEVICE (default
  * 0); up to FLAKE_AMD_BATCH (default 1024) blocks are encoded per GPU batch.
+ * FLAKE_AMD_LOOKAHEAD=N (with FlakeContext.samples set) makes the one-block
+ * flake_amd_encode_frame() queue N blocks per GPU batch: it returns 0 while it
+ * queues and all queued frames at once when it flushes (see flake_host.c).
  * FLAKE_AMD_MD5=0 skips the stream MD5 (STREAMINFO then carries the all-zero
  * "not computed" signature); FLAKE_AMD_HOST_ASSEMBLY=1 / FLAKE_AMD_HOST_VBS=1 move
  * frame assembly / block splitting back to the CPU (for comparison). */

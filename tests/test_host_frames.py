@@ -211,3 +211,25 @@ def test_link_level_dropin_client(tmp_path, decoder, oracle):
     p = flake_amd.level_params(5)
     exp, _ = oracle_stream(oracle, p, pcm, 4096)
     assert data[pos:].tobytes() == exp.tobytes()
+
+
+@pytest.mark.parametrize("level,nblocks,look", [(5, 50, 16), (8, 33, 64), (10, 21, 8)])
+def test_lookahead_queue_is_transparent(tmp_path, level, nblocks, look):
+    """FLAKE_AMD_LOOKAHEAD=N: the unmodified one-block-per-call client gets GPU batches;
+    the stream it writes is byte-identical to the unqueued one (frame numbers, MD5,
+    STREAMINFO frame sizes included).  nblocks is not a multiple of N, so the last
+    flush comes from the announced stream length; level 10 is variable block size."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref",
+                       "dropin_client")
+    if not os.path.exists(exe):
+        pytest.skip("dropin_client not built (needs /root/reference at build time)")
+    outs = []
+    for tag, env in (("plain", {}), ("queued", {"FLAKE_AMD_LOOKAHEAD": str(look)})):
+        out = tmp_path / f"{tag}.flac"
+        r = subprocess.run([exe, str(level), str(nblocks), str(out)], capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr + r.stdout
+        outs.append(np.fromfile(out, dtype=np.uint8))
+    assert outs[0].size > 1000 and outs[0].tobytes() == outs[1].tobytes()

@@ -2485,9 +2485,12 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
 
     STAMP(0);
     // ---- stage this subframe in LDS ------------------------------------------
+    // "all samples equal the first" (CONSTANT, optimize.c:143-151) is max == min
+    // == first: running max / min cost one three-input instruction per two samples
     int differs = 0;
     {
         const int32_t first = first_n;
+        int32_t mx = first, mn = first;
 #pragma unroll
         for (int o = 0; o < C; o++) {
             const int32_t v = xn[o];
@@ -2495,8 +2498,10 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
             const int idx = (C % 4 == 0) ? tid + SmpImg<C, T>::off(o)
                                          : ((tid + T * o) % C) * SmpImg<C, T>::S + (tid + T * o) / C + SmpImg<C, T>::COL0;
             l.smp[idx] = v;
-            differs |= (v != first);
+            mx = max(mx, v);
+            mn = min(mn, v);
         }
+        differs = (mx != mn);
     }
     // zeros in front: columns 0 .. COL0-1 of every row
     if (tid < SmpImg<C, T>::COL0 * C) l.smp[(tid % C) * SmpImg<C, T>::S + tid / C] = 0;

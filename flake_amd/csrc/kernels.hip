@@ -2272,6 +2272,22 @@ __device__ __forceinline__ void fir_fixed(const FastCtx<C, T> &e, int32_t (&r)[C
     }
 }
 
+// rice.c:122 folded residuals.  They stay in registers for the emit; the warm-up
+// samples (partition 0 of every level starts at `order`, rice.c:85-94) are
+// zeroed, which only the first threads have to do.
+template <int C, int T>
+__device__ __forceinline__ void fold_residuals(const FastCtx<C, T> &e, const int32_t (&r)[C],
+                                               uint32_t (&u)[C], int order)
+{
+#pragma unroll
+    for (int o = 0; o < C; o++) u[o] = zigzag32(r[o]);
+    if (e.i0 < order) {
+#pragma unroll
+        for (int o = 0; o < C; o++)
+            if (e.i0 + o < order) u[o] = 0u;
+    }
+}
+
 // rice.c:105-187 on the residuals in r[]; all threads call it.
 template <int C, int T>
 __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, const int32_t (&r)[C],
@@ -2284,16 +2300,7 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
     const int pmin = clamp_porder(e.pmin_req, n, order);
     const int pmax = clamp_porder(e.pmax_req, n, order);
 
-    // rice.c:122 folded residuals.  They stay in registers for the emit; the
-    // warm-up samples (partition 0 of every level starts at `order`, rice.c:85-94)
-    // are zeroed, which only the first threads have to do.
-#pragma unroll
-    for (int o = 0; o < C; o++) u[o] = zigzag32(r[o]);
-    if (e.i0 < order) {
-#pragma unroll
-        for (int o = 0; o < C; o++)
-            if (e.i0 + o < order) u[o] = 0u;
-    }
+    fold_residuals<C, T>(e, r, u, order);
     // thread-level sum
     unsigned long long v;
     if (e.obits <= 31 - clog2(C)) {
@@ -2401,7 +2408,10 @@ __device__ __forceinline__ void put_bits32(uint32_t *win, int nw, long long pos,
     }
 }
 
-template <int C, int T>
+// MULTI = false: the MAX / EST order methods (one quantised row, known before the
+// kernel starts) -- the lean instance the headline workload runs; MULTI = true:
+// FIXED / NONE prediction and the order-search methods.
+template <int C, int T, bool MULTI>
 // 4 waves per SIMD (<= 128 VGPRs): four 256-thread workgroups per CU.  The
 // kernel is latency-bound (a dozen dependent phases), so the fourth workgroup
 // is worth 12 %; a fifth needs <= 96 VGPRs and spills (measured 125 us vs 96).
@@ -2415,7 +2425,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                    int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    size_t off[11];
+    size_t off[12];
     fast_lds_layout(n, SmpImg<C, T>::SIZE, off);
     FastCtx<C, T> e;
     e.l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
@@ -2446,7 +2456,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
 
     // MAX / EST: the one row the reference quantises is known before the
     // search starts and comes compact from K2
-    const bool pre_row = (P.prediction_type == 2) && (n > P.max_prediction_order) && (P.order_method <= 1);
+    constexpr bool pre_row = !MULTI;     // launcher: prediction_type == 2, n > max order, order method <= 1
 
     // One workgroup per subframe (a persistent variant that prefetched the next
     // subframe into registers measured slower: the hardware's own dispatch of a
@@ -2527,11 +2537,12 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     // loop as k_encode, every variable workgroup-uniform
     enum { T_CONST, T_VERB, T_FIXED, T_LPC } tree;
     if (constant) tree = T_CONST;
+    else if (!MULTI) tree = T_LPC;
     else if (n < 5 || P.prediction_type == 0) tree = T_VERB;
     else if (P.prediction_type == 1 || n <= P.max_prediction_order) tree = T_FIXED;
     else tree = T_LPC;
 
-    const int omethod = P.order_method;
+    const int omethod = MULTI ? P.order_method : 0;
     const int min_order = P.min_prediction_order;
     const int max_order = (tree == T_FIXED) ? min(P.max_prediction_order, 4) : P.max_prediction_order;
 
@@ -2539,8 +2550,11 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     uint32_t best_bits = 0, last_bits = 0;
     bool have_best = false;
     int lg_step = 16, lg_last = 0, lg_pos = 3;
-    bool final_pass = false;
+    bool final_pass = false;             // MAX / EST: the one row is the result
     int porder = 0, method = 0;          // of the most recent Rice search
+    // (Keeping the winner's Rice result instead of searching it again after the
+    // order search -- optimize.c:183-187, :265-274 -- was measured: the extra live
+    // state costs a wave of occupancy and the kernel ends up 15 % slower.)
 
     if (tree == T_FIXED) { it = min_order; best = min_order; }
     if (tree == T_LPC) {
@@ -2639,6 +2653,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                 if (b < l.trial[best]) best = cand;
             }
             have_best = true;
+
         }
         if (tree == T_FIXED) {
             order = best;
@@ -3449,18 +3464,24 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
     int fc = 0, ft = 0;
     static const bool force_generic = getenv("FHIP_K3_GENERIC") != nullptr;    // measurements only
     if (raw_order < 0 && !force_generic && fast_geometry(p, n, &fc, &ft)) {
-        size_t off[11];
+        size_t off[12];
         size_t lds = 0;
-#define LAUNCH_FAST(CC, TT)                                                                  \
+#define LAUNCH_FAST2(CC, TT, MM)                                                             \
     do {                                                                                     \
         lds = fast_lds_layout(n, (size_t)SmpImg<CC, TT>::SIZE, off);                         \
         hipError_t er = hipFuncSetAttribute(                                                 \
-            reinterpret_cast<const void *>(&k_encode_pow2<CC, TT>),                          \
+            reinterpret_cast<const void *>(&k_encode_pow2<CC, TT, MM>),                      \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         if (er != hipSuccess) return er;                                                     \
-        hipLaunchKernelGGL((k_encode_pow2<CC, TT>), dim3(nsub), dim3(TT), lds, st, p, n,    \
+        hipLaunchKernelGGL((k_encode_pow2<CC, TT, MM>), dim3(nsub), dim3(TT), lds, st, p, n, \
                            nsub, smp, coefs, shift, opt_order, fin, info, residual, bits,    \
                            (long long)slot_bytes);                                           \
+    } while (0)
+        // one quantised row known up front (MAX / EST): the lean instance
+        const bool single_row = (p.prediction_type == 2) && (n > p.max_prediction_order) && (p.order_method <= 1);
+#define LAUNCH_FAST(CC, TT)                                                                  \
+    do {                                                                                     \
+        if (single_row) LAUNCH_FAST2(CC, TT, false); else LAUNCH_FAST2(CC, TT, true);        \
     } while (0)
         const int key = fc * 10000 + ft;
         switch (key) {
@@ -3484,6 +3505,7 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
         default: return hipErrorInvalidValue;
         }
 #undef LAUNCH_FAST
+#undef LAUNCH_FAST2
         return hipGetLastError();
     }
     const size_t lds = encode_lds_bytes(n);

@@ -2408,10 +2408,11 @@ __device__ __forceinline__ void put_bits32(uint32_t *win, int nw, long long pos,
     }
 }
 
-// MULTI = false: the MAX / EST order methods (one quantised row, known before the
-// kernel starts) -- the lean instance the headline workload runs; MULTI = true:
+// MODE 0: the MAX / EST order methods (one quantised row, known before the kernel
+// starts) -- the lean instance the headline workload runs; MODE 1: fixed predictors
+// only (prediction_type FIXED: no LPC code, no fp64); MODE 2: everything --
 // FIXED / NONE prediction and the order-search methods.
-template <int C, int T, bool MULTI>
+template <int C, int T, int MODE>
 // 4 waves per SIMD (<= 128 VGPRs): four 256-thread workgroups per CU.  The
 // kernel is latency-bound (a dozen dependent phases), so the fourth workgroup
 // is worth 12 %; a fifth needs <= 96 VGPRs and spills (measured 125 us vs 96).
@@ -2456,6 +2457,8 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
 
     // MAX / EST: the one row the reference quantises is known before the
     // search starts and comes compact from K2
+    constexpr bool MULTI = MODE != 0;
+    constexpr bool HAS_LPC = MODE != 1;
     constexpr bool pre_row = !MULTI;     // launcher: prediction_type == 2, n > max order, order method <= 1
 
     // One workgroup per subframe (a persistent variant that prefetched the next
@@ -2538,6 +2541,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     enum { T_CONST, T_VERB, T_FIXED, T_LPC } tree;
     if (constant) tree = T_CONST;
     else if (!MULTI) tree = T_LPC;
+    else if (MODE == 1) tree = T_FIXED;                     // launcher: prediction_type == 1, n >= 5
     else if (n < 5 || P.prediction_type == 0) tree = T_VERB;
     else if (P.prediction_type == 1 || n <= P.max_prediction_order) tree = T_FIXED;
     else tree = T_LPC;
@@ -2557,7 +2561,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     // state costs a wave of occupancy and the kernel ends up 15 % slower.)
 
     if (tree == T_FIXED) { it = min_order; best = min_order; }
-    if (tree == T_LPC) {
+    if (HAS_LPC && tree == T_LPC) {
         if (omethod <= 1) { best = forder - 1; final_pass = true; }     // MAX: max_order, EST: est
         else if (omethod <= 4) { it = (1 << (omethod - 1)) - 1; best = max_order - 1; }
         else if (omethod == 5) { it = 0; best = 0; }
@@ -2608,12 +2612,12 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
             }
             if (final_pass) cand = best;
 
-            uint32_t b;
-            if (tree == T_FIXED) {
+            uint32_t b = 0;
+            if (MULTI && (!HAS_LPC || tree == T_FIXED)) {
                 fir_fixed<C, T>(e, r, cand);
                 __syncthreads();                      // previous search fully read
                 b = rice_search_fast<C, T>(e, r, u, cand, false, &porder, &method);
-            } else {
+            } else if constexpr (HAS_LPC) {
                 const int ord = cand + 1;
                 int cshift;
                 if (pre_row) {
@@ -3479,9 +3483,12 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
     } while (0)
         // one quantised row known up front (MAX / EST): the lean instance
         const bool single_row = (p.prediction_type == 2) && (n > p.max_prediction_order) && (p.order_method <= 1);
+        const bool fixed_only = (p.prediction_type == 1) && n >= 5;
 #define LAUNCH_FAST(CC, TT)                                                                  \
     do {                                                                                     \
-        if (single_row) LAUNCH_FAST2(CC, TT, false); else LAUNCH_FAST2(CC, TT, true);        \
+        if (single_row) LAUNCH_FAST2(CC, TT, 0);                                             \
+        else if (fixed_only) LAUNCH_FAST2(CC, TT, 1);                                        \
+        else LAUNCH_FAST2(CC, TT, 2);                                                        \
     } while (0)
         const int key = fc * 10000 + ft;
         switch (key) {

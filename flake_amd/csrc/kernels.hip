@@ -178,7 +178,7 @@ __device__ __forceinline__ int c_double_to_int(double x)
 // ---------------------------------------------------------------------------
 // K0  k_prepare
 // ---------------------------------------------------------------------------
-// Stereo frames that do not qualify for the register path (n > 4096 or n % 4):
+// Stereo frames that do not qualify for the register path (n > 8192 or n % 4):
 // one workgroup per frame, both channels resident in LDS (int32[2n]).  Other
 // channel counts go to k_prepare_multi.
 __global__ __launch_bounds__(NT)
@@ -360,7 +360,7 @@ void k_prepare_multi(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
     }
 }
 
-// K0 fast path for stereo frames with n % 4 == 0 and n <= 4096: the frame never
+// K0 fast path for stereo frames with n % 4 == 0 and n <= 8192: the frame never
 // touches LDS.  Thread t owns the sample-frame quads 4(t + 256m) .. +3,
 // m < M: two 16-byte loads per quad (coalesced 32 B per lane), both channels
 // stay in registers through the estimate, the decorrelation and the wasted-bits
@@ -2071,7 +2071,7 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 // K3 fast path  k_encode_pow2<C, T>
 // ---------------------------------------------------------------------------
 // Same contract as k_encode, for block sizes n = C*T with T (threads) a power
-// of two >= 64, C in {3, 4, 8, 9, 16} samples per thread and every partition at
+// of two >= 64, C in {3, 4, 8, 9, 16, 18} samples per thread and every partition at
 // least one thread wide ((n >> pmax) >= C): all of FLAC's standard block sizes
 // (192, 576, 1152, 2304, 4608 = 3 or 9 times a power of two; 256 .. 16384).  Then
 //   * no lane ever needs a bounds or partition-boundary test per sample: a
@@ -3259,14 +3259,18 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
 {
     const int nch = p.channels;
     if (nframes == 0) return hipSuccess;
-    if (nch == 2 && (n & 3) == 0 && n <= 4096) {
+    if (nch == 2 && (n & 3) == 0 && n <= 8192) {
         const int est = p.stereo_method == 1 ? 1 : 0;
         const int quads = n >> 2;
 #define LAUNCH_PS(M_, A_) hipLaunchKernelGGL((k_prepare_stereo<M_, A_>), dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est)
         if (decide_only) {
             if (quads <= NT) LAUNCH_PS(1, false); else if (quads <= 2 * NT) LAUNCH_PS(2, false); else LAUNCH_PS(4, false);
         } else {
-            if (quads <= NT) LAUNCH_PS(1, true); else if (quads <= 2 * NT) LAUNCH_PS(2, true); else LAUNCH_PS(4, true);
+            if (quads <= NT) LAUNCH_PS(1, true);
+            else if (quads <= 2 * NT) LAUNCH_PS(2, true);
+            else if (quads <= 4 * NT) LAUNCH_PS(4, true);
+            else if (quads <= 5 * NT) LAUNCH_PS(5, true);       // 4608
+            else LAUNCH_PS(8, true);                            // 8192
         }
 #undef LAUNCH_PS
         return hipGetLastError();
@@ -3443,12 +3447,18 @@ static bool fast_geometry(const fhip_params &p, int n, int *C, int *T)
         else if (n == 256) { c = 4; t = 64; }
         else return false;
     } else if (odd == 9) {                // 576, 1152, 2304, 4608, 9216
+        // 256 threads where the block allows (measured at 4608: (18,256) 84 us, (9,512) 100)
         c = 9; t = 1 << lg;
+        if (t >= 512) { c = 18; t >>= 1; }
     } else if (odd == 3) {                // 192, 384, 768, 1536, ...
         c = 3; t = 1 << lg;
         if (t > 1024) { c = 0; }
     } else {
         return false;
+    }
+    if (const char *g = getenv("FHIP_K3_GEOM")) {     // measurements only: "C,T" of an instantiated pair
+        int gc = 0, gt = 0;
+        if (sscanf(g, "%d,%d", &gc, &gt) == 2 && gc * gt == n) { c = gc; t = gt; }
     }
     if (c == 0 || t < 64 || t > 1024) return false;
     // every partition at least one thread wide at the finest level that can occur
@@ -3500,10 +3510,10 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
         case 80064: LAUNCH_FAST(8, 64); break;
         case 40064: LAUNCH_FAST(4, 64); break;
         case 90064: LAUNCH_FAST(9, 64); break;
+        case 180256: LAUNCH_FAST(18, 256); break;
+        case 180512: LAUNCH_FAST(18, 512); break;
         case 90128: LAUNCH_FAST(9, 128); break;
         case 90256: LAUNCH_FAST(9, 256); break;
-        case 90512: LAUNCH_FAST(9, 512); break;
-        case 91024: LAUNCH_FAST(9, 1024); break;
         case 30064: LAUNCH_FAST(3, 64); break;
         case 30128: LAUNCH_FAST(3, 128); break;
         case 30256: LAUNCH_FAST(3, 256); break;

@@ -2146,9 +2146,18 @@ struct FastLds {
     uint32_t *bits;                      // [ENC_WWORDS]
 };
 
+// Emit window of the fast path, in words: a section of typical density fits one
+// window (n/2 words = 16 bits per sample, rounded up to a power of two); denser
+// sections take more passes.  Small blocks thus leave LDS for more workgroups.
+__host__ __device__ inline int fast_window_words(int n)
+{
+    int w = 256;
+    while (w < ENC_WWORDS && 2 * w < n) w <<= 1;
+    return w;
+}
+
 __host__ __device__ inline size_t fast_lds_layout(int n, size_t img_doubles, size_t off[11])
 {
-    (void)n;
     size_t o = 0;
     off[0] = o; o += 8 * 512;                                   // sums
     off[1] = o; o += 8 * 48;                                    // coefd (zero-padded past 32)
@@ -2161,7 +2170,7 @@ __host__ __device__ inline size_t fast_lds_layout(int n, size_t img_doubles, siz
     off[8] = o; o += 4 * 16;                                    // misc
     off[9] = o; o += 4 * 32;                                    // trial
     o = (o + 15) & ~(size_t)15;
-    off[10] = o; o += 4 * ENC_WWORDS;                           // bits
+    off[10] = o; o += 4 * fast_window_words(n);                 // bits
     return o;
 }
 
@@ -2519,7 +2528,8 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     // zeros in front: columns 0 .. COL0-1 of every row
     if (tid < SmpImg<C, T>::COL0 * C) l.smp[(tid % C) * SmpImg<C, T>::S + tid / C] = 0;
     // the first emit window is cleared here, under the shadow of the loads above
-    if (bits_out) for (int q = tid; q < ENC_WWORDS; q += T) l.bits[q] = 0;
+    const int wwords = fast_window_words(n);
+    if (bits_out) for (int q = tid; q < wwords; q += T) l.bits[q] = 0;
     if (tid < 16) l.coefd[32 + tid] = 0.0;
     if (pre_row && tid < FHIP_MAX_ORDER) {
         l.coef[tid] = fcoef_n;
@@ -2767,8 +2777,8 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                 // samples), which thread 0 overwrites with the section header after
                 // the barrier.
                 const long long start = (long long)my_off - (long long)(nwarm * k1);
-                for (int wlo = 0; wlo < nwords; wlo += ENC_WWORDS) {
-                    const int nw = min(ENC_WWORDS, nwords - wlo);
+                for (int wlo = 0; wlo < nwords; wlo += wwords) {
+                    const int nw = min(wwords, nwords - wlo);
                     if (wlo > 0) {
                         // later windows reuse the buffer (the first was cleared at the top)
                         __syncthreads();

@@ -2369,7 +2369,7 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
             const int k = rice_k_fast(sum, cnt, &b);
             l.kpar[q] = k;
             atomicAdd(&l.lvl_bits[p], b);
-            if (k > 14) atomicOr(&l.lvl_meth[p], 1u);
+            if (k > 14) atomicOr(&l.lvl_meth[0], 1u << p);      // one flag word: bit p = level p needs RICE2
         }
     }
     __syncthreads();
@@ -2377,18 +2377,16 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
     // rice.c:127-138, evaluated redundantly by every wave (no broadcast
     // barrier).  The inputs are workgroup-uniform: readfirstlane moves them to
     // SGPRs so that the comparison chain runs on the scalar unit.
-    uint32_t lb[9], lm[9];
+    uint32_t lb[9];
 #pragma unroll
-    for (int p = 0; p < 9; p++) {
-        lb[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.lvl_bits[p]);
-        lm[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.lvl_meth[p]);
-    }
+    for (int p = 0; p < 9; p++) lb[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.lvl_bits[p]);
+    const uint32_t lmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.lvl_meth[0]);
     int bp = pmin;
     uint32_t best = 0, method = 0;
 #pragma unroll
     for (int p = 0; p < 9; p++) {
         const uint32_t b = lb[p] + 4u * (1u << p);
-        if (p >= pmin && p <= pmax && (p == pmin || b <= best)) { best = b; bp = p; method = lm[p]; }
+        if (p >= pmin && p <= pmax && (p == pmin || b <= best)) { best = b; bp = p; method = (lmask >> p) & 1u; }
     }
     // rice.c:157-171
     uint32_t bits = (uint32_t)(order * e.obits + 2);

@@ -2571,7 +2571,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     if (tree == T_FIXED) { it = min_order; best = min_order; }
     if (HAS_LPC && tree == T_LPC) {
         if (omethod <= 1) { best = forder - 1; final_pass = true; }     // MAX: max_order, EST: est
-        else if (omethod <= 4) { it = (1 << (omethod - 1)) - 1; best = max_order - 1; }
+        else if (omethod <= 4) { it = (1 << ((omethod - 1) & 7)) - 1; best = max_order - 1; }
         else if (omethod == 5) { it = 0; best = 0; }
         else {
             best = min_order - 1 + (max_order - min_order) / 3;
@@ -2592,7 +2592,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                     if (it <= max_order) cand = it;
                 } else if (omethod <= 4) {
                     if (it >= 0) {
-                        const int levels = 1 << (omethod - 1);
+                        const int levels = 1 << ((omethod - 1) & 7);
                         cand = min_order + (((max_order - min_order + 1) * (it + 1)) / levels) - 2;
                         if (cand < 0) cand = 0;
                     }

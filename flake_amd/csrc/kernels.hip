@@ -2420,9 +2420,10 @@ __device__ __forceinline__ void put_bits32(uint32_t *win, int nw, long long pos,
 // only (prediction_type FIXED: no LPC code, no fp64); MODE 2: everything --
 // FIXED / NONE prediction and the order-search methods.
 template <int C, int T, int MODE>
-// 4 waves per SIMD (<= 128 VGPRs): four 256-thread workgroups per CU.  The
-// kernel is latency-bound (a dozen dependent phases), so the fourth workgroup
-// is worth 12 %; a fifth needs <= 96 VGPRs and spills (measured 125 us vs 96).
+// At least 4 waves per SIMD (<= 128 VGPRs).  The kernel is bound by vector-ALU
+// issue (PMC: ~910 VALU instructions per wave, > 80 % of the issue slots), so what
+// pays is fewer instructions, not more waves: MODE 0 needs 96 VGPRs and runs five
+// workgroups per CU (-3 %); forcing MODE 2 to 96 spills and is slower.
 // Geometry for n = 4096, measured: (C,T) = (16,256) 94 us, (8,512) 137, (4,1024)
 // 256, (32,128) 115 (206 VGPRs): cross-wave phases grow with T, serial ones with C.
 __global__ __launch_bounds__(T, 4)   // VGPR cap per waves/SIMD: 2 -> 256, 3 -> 168, 4 -> 128

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of the FLAC prediction/entropy hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 400 --warmup 150
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -35,13 +35,19 @@ HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # Defaults: the GPU's clocks need ~100 steps (20 ms) of this load to settle
+    # (tools/ramp.py: 0.206 ms/step in the first 20 steps, 0.179 from step ~120 on),
+    # so the warm-up covers that and the timed region is long enough to average.
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=150)
+    ap.add_argument("--settle-ms", type=float, default=40.0,
+                    help="untimed steps before the warm-up until this much wall time has passed: "
+                         "the clocks ramp for ~20 ms under this load whatever --warmup says")
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="rough budget of CPU work for the cpu_baseline leg")
-    ap.add_argument("--profile-steps", type=int, default=10,
+    ap.add_argument("--profile-steps", type=int, default=200,
                     help="extra steps with per-kernel hipEvent timing for the roofline object")
     ap.add_argument("--with-residual", action="store_true",
                     help="also write the int32 residual (stage A of SURVEY 8d)")
@@ -146,9 +152,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    step()
+    job_stats(0)                 # first use of these torch kernels loads their code objects
+    fence()                      # (seconds of host time: done before the clocks are ramped)
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
-    job_stats(0)                 # first use of these torch kernels loads their code objects
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -1390,8 +1390,10 @@ void k_lpc(const double *__restrict__ autoc_all, int nsub, int max_order, int pr
 // guards, so no array is indexed dynamically.
 template <int MO>
 __device__ __forceinline__ void quantize_row_reg(const double (&a)[MO], int order, int precision,
-                                                 int32_t *__restrict__ out, int32_t *__restrict__ shift_out)
+                                                 int32_t *__restrict__ out, int32_t *__restrict__ shift_out,
+                                                 int32_t *__restrict__ fin_out = nullptr, int max_order = 0)
 {
+    // fin_out: also the compact copy K3 prefetches (coefs, zeros up to max_order, shift, order)
     // lpc.c:167-219 on row = -a[0..order)
     const int qmax = (1 << (precision - 1)) - 1;
     double cmax = 0.0;
@@ -1404,6 +1406,12 @@ __device__ __forceinline__ void quantize_row_reg(const double (&a)[MO], int orde
         *shift_out = 0;
 #pragma unroll
         for (int j = 0; j < MO; j++) if (j < order) out[j] = 0;
+        if (fin_out) {
+#pragma unroll
+            for (int j = 0; j < MO; j++) if (j < max_order) fin_out[j] = 0;
+            fin_out[32] = 0;
+            fin_out[33] = order;
+        }
         return;
     }
     int sh = 15;
@@ -1424,9 +1432,16 @@ __device__ __forceinline__ void quantize_row_reg(const double (&a)[MO], int orde
             if (q > qmax) q = qmax;
             carry = carry - (double)q;
             out[j] = q;
+            if (fin_out) fin_out[j] = q;
+        } else if (fin_out && j < max_order) {
+            fin_out[j] = 0;
         }
     }
     *shift_out = sh;
+    if (fin_out) {
+        fin_out[32] = sh;
+        fin_out[33] = order;
+    }
 }
 
 template <int MO>
@@ -1531,18 +1546,14 @@ void k_lpc_reg(const double *__restrict__ autoc_all, int nsub, int max_order, in
                 const double t = m * r;
                 a[h] = m + t;
             }
-            if (all_rows || i == levinson_order - 1)
+            if (all_rows)
                 quantize_row_reg<MO>(a, i + 1, precision, crow + i * FHIP_MAX_ORDER, srow + i);
+            else if (i == levinson_order - 1)       // the one row of MAX / EST, and its compact copy
+                quantize_row_reg<MO>(a, i + 1, precision, crow + i * FHIP_MAX_ORDER, srow + i,
+                                     fin + (size_t)s * FIN_STRIDE, max_order);
         }
     }
     opt_order[s] = levinson_order;
-    if (!all_rows) {
-        int32_t *f = fin + (size_t)s * FIN_STRIDE;
-        const int32_t *src = crow + (levinson_order - 1) * FHIP_MAX_ORDER;
-        for (int j = 0; j < max_order; j++) f[j] = (j < levinson_order) ? src[j] : 0;
-        f[32] = srow[levinson_order - 1];
-        f[33] = levinson_order;
-    }
 }
 
 // ---------------------------------------------------------------------------

@@ -180,12 +180,16 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
         HIP_TRY(c, fhip::launch_prepare(st, p, pcm, nframes, n, smp, info, fused));
     }
     if (lpc_path) {
+        // K2 rides on K1's tail where K1 is the wave-typed kernel and the order fits registers
+        const bool lpc_tail = !fused && fhip::autocorr_does_lpc(nsub, n, p.max_prediction_order);
+        const fhip::autocorr_lpc_out lo{p.lpc_precision, p.order_method, coefs, shift, opt, fin};
         {
             MaybeProf pr(c, prof, 1);
             HIP_TRY(c, fhip::launch_autocorr(st, smp, nsub, n, p.max_prediction_order, autoc,
-                                             fused ? pcm : nullptr, fused ? smp : nullptr, info));
+                                             fused ? pcm : nullptr, fused ? smp : nullptr, info,
+                                             lpc_tail ? &lo : nullptr));
         }
-        {
+        if (!lpc_tail) {
             MaybeProf pr(c, prof, 2);
             HIP_TRY(c, fhip::launch_lpc(st, autoc, nsub, p.max_prediction_order, p.lpc_precision,
                                         p.order_method, coefs, shift, opt, fin));

@@ -31,9 +31,14 @@ bool autocorr_fuses_prepare(const fhip_params &p, int nsub, int n);
 // smp [nsub][n] -> autoc [nsub][FHIP_MAX_LAGS].
 // With pcm_fused (stereo PCM) the producers read it instead of smp, apply info[]'s
 // channel mode / wasted bits and write smp_out.
+// With lpc_out (see autocorr_does_lpc) the kernel also does K2's work for its
+// subframes and launch_lpc is not needed.
+struct autocorr_lpc_out { int precision, omethod; int32_t *coefs, *shift, *opt_order, *fin; };
+bool autocorr_does_lpc(int nsub, int n, int max_order);
 hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                            int max_order, double *autoc, const int32_t *pcm_fused = nullptr,
-                           int32_t *smp_out = nullptr, const fhip_subframe_info *info = nullptr);
+                           int32_t *smp_out = nullptr, const fhip_subframe_info *info = nullptr,
+                           const autocorr_lpc_out *lpc_out = nullptr);
 
 // K2: compute_lpc_coefs / _est + quantize_lpc_coefs (lpc.c:77-257).
 // coefs [nsub][32][32], shift [nsub][32], opt_order [nsub].

@@ -951,14 +951,27 @@ constexpr bool wt_probe_nohalo = true;      // timing probe only: results are wr
 #else
 constexpr bool wt_probe_nohalo = false;
 #endif
-template <int NCH, bool FUSED>
+// LPCMO > 0: K2 as the kernel's tail.  The consumers leave their sums in LDS as
+// well, and after one more barrier the first 32 lanes of wave 0 run Levinson /
+// Schur and the quantiser for the workgroup's 32 subframes (max order <= LPCMO,
+// everything in registers): what a separate launch does in 8 us -- it is latency
+// bound, 128 waves on the whole chip -- costs about half of that here.
+struct wt_lpc_args { int precision, omethod; int32_t *coefs, *shift, *opt_order, *fin; };
+template <int MO>
+__device__ __forceinline__ void lpc_reg_one(const double (&ac)[MO + 1], int s, int max_order, int precision,
+                                            int omethod, int32_t *__restrict__ coefs,
+                                            int32_t *__restrict__ shift, int32_t *__restrict__ opt_order,
+                                            int32_t *__restrict__ fin);
+
+template <int NCH, bool FUSED, int LPCMO>
 __global__ __launch_bounds__(8 * WAVE)
 void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                    int nsub, int n, int maxlag, wt_groups grp, double c,
                    const int32_t *__restrict__ pcm, int32_t *__restrict__ smp_out,
-                   const fhip_subframe_info *__restrict__ info)
+                   const fhip_subframe_info *__restrict__ info, wt_lpc_args lpc)
 {
     extern __shared__ __attribute__((aligned(16))) double wt_lds[];
+    double *acbuf = wt_lds + WT_NBUF * WT_BUF;          // [32][FHIP_MAX_LAGS], LPCMO > 0 only
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -1086,6 +1099,7 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
         };
         if (wv == 4) produce(std::integral_constant<int, WT_ROWS0>{}, 0);
         else produce(std::integral_constant<int, WT_ROWS1>{}, WT_ROWS0 + (wv - 5) * WT_ROWS1);
+        if (LPCMO > 0) __syncthreads();                    // the tail's barrier (below)
         return;
     }
 
@@ -1220,7 +1234,21 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
         const double o = __shfl_xor(S[j], 32, WAVE);
-        if (live && pi == 0 && j < nch) autoc[(size_t)(sub0 + sl) * FHIP_MAX_LAGS + l0 + 2 * j] = S[j] + o;
+        if (live && pi == 0 && j < nch) {
+            const double v = S[j] + o;
+            autoc[(size_t)(sub0 + sl) * FHIP_MAX_LAGS + l0 + 2 * j] = v;
+            if (LPCMO > 0) acbuf[sl * FHIP_MAX_LAGS + l0 + 2 * j] = v;
+        }
+    }
+    if constexpr (LPCMO > 0) {
+        __syncthreads();                                   // all lags of the 32 subframes are in acbuf
+        if (wv == 0 && lane < WT_SUB && sub0 + lane < nsub) {
+            double ac[LPCMO + 1];
+#pragma unroll
+            for (int i = 0; i <= LPCMO; i++) ac[i] = (i <= maxlag) ? acbuf[lane * FHIP_MAX_LAGS + i] : 0.0;
+            lpc_reg_one<LPCMO>(ac, sub0 + lane, maxlag, lpc.precision, lpc.omethod, lpc.coefs, lpc.shift,
+                               lpc.opt_order, lpc.fin);
+        }
     }
 }
 
@@ -1444,18 +1472,15 @@ __device__ __forceinline__ void quantize_row_reg(const double (&a)[MO], int orde
     }
 }
 
+// K2 for one subframe with every array in registers (max_order <= MO): Levinson /
+// Schur, quantiser, outputs.  Called by k_lpc_reg (one lane per subframe) and by
+// the tail of k_autocorr_wt.
 template <int MO>
-__global__ __launch_bounds__(LPC_NT)
-void k_lpc_reg(const double *__restrict__ autoc_all, int nsub, int max_order, int precision,
-               int omethod, int32_t *__restrict__ coefs, int32_t *__restrict__ shift,
-               int32_t *__restrict__ opt_order, int32_t *__restrict__ fin)
+__device__ __forceinline__ void lpc_reg_one(const double (&ac)[MO + 1], int s, int max_order, int precision,
+                                            int omethod, int32_t *__restrict__ coefs,
+                                            int32_t *__restrict__ shift, int32_t *__restrict__ opt_order,
+                                            int32_t *__restrict__ fin)
 {
-    const int s = blockIdx.x * LPC_NT + threadIdx.x;
-    if (s >= nsub) return;
-    double ac[MO + 1];
-#pragma unroll
-    for (int i = 0; i <= MO; i++) ac[i] = (i <= max_order) ? autoc_all[(size_t)s * FHIP_MAX_LAGS + i] : 0.0;
-
     int32_t *crow = coefs + (size_t)s * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
     int32_t *srow = shift + (size_t)s * FHIP_MAX_ORDER;
     int levinson_order = max_order;
@@ -1554,6 +1579,20 @@ void k_lpc_reg(const double *__restrict__ autoc_all, int nsub, int max_order, in
         }
     }
     opt_order[s] = levinson_order;
+}
+
+template <int MO>
+__global__ __launch_bounds__(LPC_NT)
+void k_lpc_reg(const double *__restrict__ autoc_all, int nsub, int max_order, int precision,
+               int omethod, int32_t *__restrict__ coefs, int32_t *__restrict__ shift,
+               int32_t *__restrict__ opt_order, int32_t *__restrict__ fin)
+{
+    const int s = blockIdx.x * LPC_NT + threadIdx.x;
+    if (s >= nsub) return;
+    double ac[MO + 1];
+#pragma unroll
+    for (int i = 0; i <= MO; i++) ac[i] = (i <= max_order) ? autoc_all[(size_t)s * FHIP_MAX_LAGS + i] : 0.0;
+    lpc_reg_one<MO>(ac, s, max_order, precision, omethod, coefs, shift, opt_order, fin);
 }
 
 // ---------------------------------------------------------------------------
@@ -3355,6 +3394,14 @@ ac_choice pick_autocorr(int nsub, int n, int max_order)
 }
 }  // namespace
 
+// True when K1 will also run K2 (launch_autocorr with lpc outputs): the wave-typed
+// kernel and a maximum order the register version of K2 covers.
+bool autocorr_does_lpc(int nsub, int n, int max_order)
+{
+    static const bool off = getenv("FHIP_NO_LPC_TAIL") != nullptr;      // measurements only
+    return !off && max_order <= 12 && pick_autocorr(nsub, n, max_order).kernel == 2;
+}
+
 bool autocorr_fuses_prepare(const fhip_params &p, int nsub, int n)
 {
     // Off by default: measured on configs[1] the decision-only K0 saves 18 us and 134 MB
@@ -3367,7 +3414,8 @@ bool autocorr_fuses_prepare(const fhip_params &p, int nsub, int n)
 
 hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                            int max_order, double *autoc, const int32_t *pcm_fused,
-                           int32_t *smp_out, const fhip_subframe_info *info)
+                           int32_t *smp_out, const fhip_subframe_info *info,
+                           const autocorr_lpc_out *lpc_out)
 {
     if (nsub == 0) return hipSuccess;
     // the window constant is computed on the host exactly as lpc.c:34 does
@@ -3376,7 +3424,7 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
     const int ne = ch.ne, no = ch.no, Gp = ch.Gp, lps = ch.lps, ge = ch.ge, nl2 = ch.nl2;
     int G = ch.G;
     const bool use_wt = ch.kernel == 2, use_ps = ch.kernel == 1;
-    if (pcm_fused && !use_wt) return hipErrorInvalidValue;
+    if ((pcm_fused || lpc_out) && !use_wt) return hipErrorInvalidValue;
     const int e0 = (ne + 1) / 2, e1 = ne - e0, o0 = (no + 1) / 2, o1 = no - o0;
     if (use_wt) {
         wt_groups gr;
@@ -3387,25 +3435,52 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
         const int nch = e0;                                    // e0 >= e1, o0, o1
         const int blocks = (nsub + WT_SUB - 1) / WT_SUB;
         const size_t lds = sizeof(double) * (size_t)WT_NBUF * WT_BUF;
-#define LAUNCH_WT2(N_, F_)                                                                   \
+        wt_lpc_args la{};
+        int lpcmo = 0;
+        if (lpc_out) {
+            if (max_order > 12 || pcm_fused) return hipErrorInvalidValue;
+            la.precision = lpc_out->precision; la.omethod = lpc_out->omethod;
+            la.coefs = lpc_out->coefs; la.shift = lpc_out->shift; la.opt_order = lpc_out->opt_order;
+            la.fin = lpc_out->fin;
+            lpcmo = (max_order <= 8) ? 8 : 12;
+        }
+        const size_t lds_all = lds + (lpcmo ? sizeof(double) * (size_t)WT_SUB * FHIP_MAX_LAGS : 0);
+#define LAUNCH_WT3(N_, F_, L_)                                                               \
     do {                                                                                     \
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_autocorr_wt<N_, F_>), \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_autocorr_wt<N_, F_, L_>), \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all); \
         if (er != hipSuccess) return er;                                                     \
-        hipLaunchKernelGGL((k_autocorr_wt<N_, F_>), dim3(blocks), dim3(8 * WAVE), lds, st, smp, \
-                           autoc, nsub, n, max_order, gr, c, pcm_fused, smp_out, info);      \
+        hipLaunchKernelGGL((k_autocorr_wt<N_, F_, L_>), dim3(blocks), dim3(8 * WAVE), lds_all, st, smp, \
+                           autoc, nsub, n, max_order, gr, c, pcm_fused, smp_out, info, la);  \
     } while (0)
 #define LAUNCH_WT(N_)                                                                        \
     case N_:                                                                                 \
-        if (pcm_fused) LAUNCH_WT2(N_, true); else LAUNCH_WT2(N_, false);                     \
+        if (pcm_fused) LAUNCH_WT3(N_, true, 0); else LAUNCH_WT3(N_, false, 0);               \
         break;
+        if (lpcmo == 8) {                      // max_order <= 8: NCH <= 3
+            switch (nch) {
+            case 1: LAUNCH_WT3(1, false, 8); break;
+            case 2: LAUNCH_WT3(2, false, 8); break;
+            case 3: LAUNCH_WT3(3, false, 8); break;
+            default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
+        if (lpcmo == 12) {                     // max_order 9..12: NCH 3 or 4
+            switch (nch) {
+            case 3: LAUNCH_WT3(3, false, 12); break;
+            case 4: LAUNCH_WT3(4, false, 12); break;
+            default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
         switch (nch) {
             LAUNCH_WT(1) LAUNCH_WT(2) LAUNCH_WT(3) LAUNCH_WT(4) LAUNCH_WT(5)
             LAUNCH_WT(6) LAUNCH_WT(7) LAUNCH_WT(8) LAUNCH_WT(9)
         default: return hipErrorInvalidValue;
         }
 #undef LAUNCH_WT
-#undef LAUNCH_WT2
+#undef LAUNCH_WT3
         return hipGetLastError();
     }
     if (use_ps) {

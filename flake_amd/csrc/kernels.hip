@@ -2908,8 +2908,17 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                         l.bits[0] = (l.bits[0] & (0xFFFFFFFFu >> hb)) | (hdr << (32 - hb));
                     }
                     STAMP(11);
-                    for (int q = tid; q < nw; q += T)
-                        dst32[wlo + q] = __builtin_bswap32(l.bits[q]);
+                    // 16 bytes per lane where whole quads of words are left (the LDS window
+                    // is 16-byte aligned; a slot need only be dword aligned, which is all a
+                    // global dwordx4 store asks for), single words for the last 1..3
+                    const int nq = nw >> 2;
+                    for (int q = tid; q < nq; q += T) {
+                        const uint4 v = reinterpret_cast<const uint4 *>(l.bits)[q];
+                        reinterpret_cast<uint4 *>(dst32 + wlo)[q] =
+                            make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y),
+                                       __builtin_bswap32(v.z), __builtin_bswap32(v.w));
+                    }
+                    if (tid < (nw & 3)) dst32[wlo + 4 * nq + tid] = __builtin_bswap32(l.bits[4 * nq + tid]);
                 }
             }
         }

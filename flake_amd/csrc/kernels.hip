@@ -2578,7 +2578,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     if (tid < SmpImg<C, T>::COL0 * C) l.smp[(tid % C) * SmpImg<C, T>::S + tid / C] = 0;
     // the first emit window is cleared here, under the shadow of the loads above
     const int wwords = fast_window_words(n);
-    if (bits_out) for (int q = tid; q < wwords; q += T) l.bits[q] = 0;
+    if (bits_out) for (int q = tid; q < wwords / 4; q += T) reinterpret_cast<uint4 *>(l.bits)[q] = make_uint4(0, 0, 0, 0);
     if (tid < 16) l.coefd[32 + tid] = 0.0;
     if (pre_row && tid < FHIP_MAX_ORDER) {
         l.coef[tid] = fcoef_n;
@@ -2831,7 +2831,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                     if (wlo > 0) {
                         // later windows reuse the buffer (the first was cleared at the top)
                         __syncthreads();
-                        for (int q = tid; q < nw; q += T) l.bits[q] = 0;
+                        for (int q = tid; q < (nw + 3) / 4; q += T) reinterpret_cast<uint4 *>(l.bits)[q] = make_uint4(0, 0, 0, 0);
                         __syncthreads();
                     }
                     const long long rel = start - (long long)wlo * 32;

@@ -2134,24 +2134,36 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 //     31-step scan only where its modular arithmetic can bite (see rice_k_fast).
 constexpr int HIST = 32;                 // zeroed samples in front of the block
 
-// The block sits in LDS transposed in chunks: sample i (>= -HIST) is at row
-// (i mod C), column (i div C) + HIST/C of a [C][T + pad] int32 image.  Thread t's
-// run is then one column, lanes of a wave touch consecutive words (no bank
-// conflicts), and every sample a thread needs at offset c from its run start
-// is at a thread base + a compile-time offset: the FIR window loads carry no
-// address arithmetic.  (An fp64 image saves the int->double conversions but its
-// 33 KB cost the fourth workgroup per CU: measured 108 vs 96 us.)
+// The block sits in LDS transposed: thread t's run of C samples is column t.
+//  * C % 4 != 0: sample i (>= -HIST) is at row (i mod C), column (i div C) + COL0 of
+//    a [C][S] int32 image; lanes of a wave touch consecutive words.
+//  * C % 4 == 0 (V4): the rows are groups of four samples, [C/4][S] of int4 -- a
+//    thread stages its run with C/4 16-byte stores and the FIR fetches its window
+//    with 16-byte loads (a quarter of the LDS instructions; lanes touch
+//    consecutive 16-byte slots, conflict-free).
+// Either way every sample a thread needs at offset c from its run start is at the
+// thread's base + a compile-time offset: the window loads carry no address
+// arithmetic.  (An fp64 image saves the int->double conversions but its 33 KB cost
+// a workgroup per CU: measured 108 vs 96 us.)
 template <int C, int T>
 struct SmpImg {
+    static constexpr bool V4 = (C % 4 == 0);
+    static constexpr int CS = V4 ? 4 : 1;             // int32 per column step
     // columns of zeros in front: the FIR looks back 32 samples in tap blocks
-    // of 16 (C | 16) or 36 in tap blocks of 9 (C = 3, 9)
+    // of 16 (C | 16) or 36 in tap blocks of 9 (C = 3, 9, 18)
     static constexpr int COL0 = (16 % C == 0) ? HIST / C : (36 + C - 1) / C;
-    static constexpr int S = T + COL0 + 2;           // row stride in words
-    static constexpr int SIZE = C * S;
-    // offset of sample (run start of thread t) + c, relative to &img[t]
+    static constexpr int ROWS = V4 ? C / 4 : C;
+    static constexpr int S = T + COL0 + (V4 ? 1 : 2);  // row stride in columns
+    static constexpr int SIZE = ROWS * S * CS;         // int32
+    // int32 index of sample r (0 <= r < C) of column col
+    __host__ __device__ static constexpr int at(int col, int r)
+    {
+        return V4 ? ((r / 4) * S + col) * 4 + (r % 4) : r * S + col;
+    }
+    // offset of sample (run start of thread t) + c, relative to &img[t * CS]
     __host__ __device__ static constexpr int off(int c)
     {
-        return (((c % C) + C) % C) * S + ((c - (((c % C) + C) % C)) / C) + COL0;
+        return at((c - (((c % C) + C) % C)) / C + COL0, ((c % C) + C) % C);
     }
 };
 
@@ -2247,7 +2259,7 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
     // taps per block: a multiple of C (going back C*k samples is going back k
     // columns of the image, so every block sees the same immediate offsets)
     constexpr int TB = (16 % C == 0) ? 16 : C * ((8 + C - 1) / C);
-    const int32_t *mine = l.smp + e.tid;             // column of this thread's run
+    const int32_t *mine = l.smp + e.tid * Img::CS;   // column of this thread's run
 #pragma unroll
     for (int ob = 0; ob < C; ob += OB) {
         // keep the register blocks apart: interleaving them only costs VGPRs
@@ -2257,7 +2269,7 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
         for (int o = 0; o < OB; o++) acc[o] = 0.0;
 #pragma unroll 1
         for (int tb = 0; tb < order; tb += TB) {
-            const int32_t *base = mine - tb / C;
+            const int32_t *base = mine - (tb / C) * Img::CS;
 #pragma unroll
             for (int sb = 0; sb < TB; sb += 8) {
                 constexpr int dummy = 0; (void)dummy;
@@ -2265,9 +2277,22 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
                     // taps tb+sb+1 .. tb+sb+NT_ : samples c = ob+o-(sb+jj+1)
                     const int NT_ = (TB - sb < 8) ? TB - sb : 8;
                     double W[OB + 7];
+                    if constexpr (Img::V4) {
+                        // the window starts on a group of four: 16-byte loads
+                        static_assert(!Img::V4 || (TB == 16 && OB % 4 == 0), "aligned windows");
 #pragma unroll
-                    for (int m = 0; m < OB + 7; m++)
-                        if (m < OB + NT_ - 1) W[m] = (double)base[Img::off(ob - sb - NT_ + m)];
+                        for (int m4 = 0; m4 < OB + 7; m4 += 4) {
+                            const int4 v = *reinterpret_cast<const int4 *>(base + Img::off(ob - sb - 8 + m4));
+                            W[m4] = (double)v.x;
+                            if (m4 + 1 < OB + 7) W[m4 + 1] = (double)v.y;
+                            if (m4 + 2 < OB + 7) W[m4 + 2] = (double)v.z;
+                            if (m4 + 3 < OB + 7) W[m4 + 3] = (double)v.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < OB + 7; m++)
+                            if (m < OB + NT_ - 1) W[m] = (double)base[Img::off(ob - sb - NT_ + m)];
+                    }
 #pragma unroll
                     for (int jj = 0; jj < 8; jj++) {
                         if (jj < NT_) {
@@ -2289,7 +2314,14 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
             // two's complement.  (int32)(x - (pred >> shift)) only needs those.
             const double z = __builtin_fma(acc[o], inv, 6755399441055744.0);
             const uint32_t qlo = (uint32_t)__double2loint(z);
-            r[ob + o] = (int32_t)((uint32_t)mine[Img::off(ob + o)] - qlo);
+            uint32_t x;
+            if constexpr (Img::V4) {
+                const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob + (o & ~3)));   // one load per four
+                x = (uint32_t)((o & 3) == 0 ? v.x : (o & 3) == 1 ? v.y : (o & 3) == 2 ? v.z : v.w);
+            } else {
+                x = (uint32_t)mine[Img::off(ob + o)];
+            }
+            r[ob + o] = (int32_t)(x - qlo);
         }
     }
     // warm-up samples pass through (optimize.c:84-86): only the first threads
@@ -2308,13 +2340,26 @@ __device__ __forceinline__ void fir_fixed(const FastCtx<C, T> &e, int32_t (&r)[C
 {
     using Img = SmpImg<C, T>;
     const FastLds &l = e.l;
-    const int32_t *mine = l.smp + e.tid;
+    const int32_t *mine = l.smp + e.tid * Img::CS;
     uint32_t h[4];
+    uint32_t xs[C];
+    if constexpr (Img::V4) {
+        const int4 p = *reinterpret_cast<const int4 *>(mine + Img::off(-4));      // samples -4 .. -1
+        h[0] = (uint32_t)p.w; h[1] = (uint32_t)p.z; h[2] = (uint32_t)p.y; h[3] = (uint32_t)p.x;
 #pragma unroll
-    for (int k = 0; k < 4; k++) h[k] = (uint32_t)mine[Img::off(-1 - k)];
+        for (int o = 0; o < C; o += 4) {
+            const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(o));
+            xs[o] = (uint32_t)v.x; xs[o + 1] = (uint32_t)v.y; xs[o + 2] = (uint32_t)v.z; xs[o + 3] = (uint32_t)v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) h[k] = (uint32_t)mine[Img::off(-1 - k)];
+#pragma unroll
+        for (int o = 0; o < C; o++) xs[o] = (uint32_t)mine[Img::off(o)];
+    }
 #pragma unroll
     for (int o = 0; o < C; o++) {
-        const uint32_t x0 = (uint32_t)mine[Img::off(o)];
+        const uint32_t x0 = xs[o];
         uint32_t acc;
         if (order == 0) acc = x0;
         else if (order == 1) acc = x0 - h[0];
@@ -2476,7 +2521,7 @@ template <int C, int T, int MODE>
 // workgroups per CU (-3 %); forcing MODE 2 to 96 spills and is slower.
 // Geometry for n = 4096, measured: (C,T) = (16,256) 94 us, (8,512) 137, (4,1024)
 // 256, (32,128) 115 (206 VGPRs): cross-wave phases grow with T, serial ones with C.
-__global__ __launch_bounds__(T, 4)   // VGPR cap per waves/SIMD: 2 -> 256, 3 -> 168, 4 -> 128
+__global__ __launch_bounds__(T, (MODE == 2 || C >= 16) ? 4 : 5)   // VGPR cap per waves/SIMD: 4 -> 128, 5 -> 96
 void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ smp_all,
                    const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                    const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,
@@ -2566,16 +2611,22 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
         for (int o = 0; o < C; o++) {
             const int32_t v = xn[o];
             // own-run mapping: sample i0 + o; coalesced mapping: sample tid + T*o
-            const int idx = (C % 4 == 0) ? tid + SmpImg<C, T>::off(o)
-                                         : ((tid + T * o) % C) * SmpImg<C, T>::S + (tid + T * o) / C + SmpImg<C, T>::COL0;
-            l.smp[idx] = v;
+            if (C % 4 != 0)       // coalesced mapping: this register holds sample tid + T*o of the block
+                l.smp[SmpImg<C, T>::at((tid + T * o) / C + SmpImg<C, T>::COL0, (tid + T * o) % C)] = v;
             mx = max(mx, v);
             mn = min(mn, v);
         }
         differs = (mx != mn);
+        if constexpr (C % 4 == 0) {
+            // own-run mapping: the registers are samples i0 .. i0+C-1: 16-byte stores
+#pragma unroll
+            for (int g4 = 0; g4 < C; g4 += 4)
+                *reinterpret_cast<int4 *>(l.smp + tid * 4 + SmpImg<C, T>::off(g4)) =
+                    make_int4(xn[g4], xn[g4 + 1], xn[g4 + 2], xn[g4 + 3]);
+        }
     }
     // zeros in front: columns 0 .. COL0-1 of every row
-    if (tid < SmpImg<C, T>::COL0 * C) l.smp[(tid % C) * SmpImg<C, T>::S + tid / C] = 0;
+    if (tid < SmpImg<C, T>::COL0 * C) l.smp[SmpImg<C, T>::at(tid / C, tid % C)] = 0;
     // the first emit window is cleared here, under the shadow of the loads above
     const int wwords = fast_window_words(n);
     if (bits_out) for (int q = tid; q < wwords / 4; q += T) reinterpret_cast<uint4 *>(l.bits)[q] = make_uint4(0, 0, 0, 0);
@@ -2737,7 +2788,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     if (res_out) {
         // FlacSubframe.residual: the samples themselves for CONSTANT / VERBATIM and
         // for warm-up positions, else the fold undone (a bijection on 32 bits)
-        const int32_t *mine_s = l.smp + tid;
+        const int32_t *mine_s = l.smp + tid * SmpImg<C, T>::CS;
 #pragma unroll
         for (int o = 0; o < C; o++) {
             const int32_t back = (int32_t)((u[o] >> 1) ^ (0u - (u[o] & 1u)));
@@ -2939,7 +2990,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     if (tid < FHIP_MAX_ORDER) {
         out->coefs[tid] = (type == FHIP_SUB_LPC && tid < order) ? l.coef[tid] : 0;
         const int nw = (type == FHIP_SUB_CONSTANT) ? 1 : order;
-        out->warmup[tid] = (tid < nw) ? l.smp[(tid % C) * SmpImg<C, T>::S + tid / C + SmpImg<C, T>::COL0] : 0;
+        out->warmup[tid] = (tid < nw) ? l.smp[SmpImg<C, T>::at(tid / C + SmpImg<C, T>::COL0, tid % C)] : 0;
     }
     {
         const int np = has_rice ? (1 << porder) : 0;

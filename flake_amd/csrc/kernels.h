@@ -44,7 +44,8 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
 // coefs [nsub][32][32], shift [nsub][32], opt_order [nsub].
 // fin [nsub][FIN_STRIDE]: for the MAX/EST order methods the one row the
 // reference quantises, compact: coefs[0..32), shift, order (prefetched by K3).
-constexpr int FIN_STRIDE = 36;
+constexpr int FIN_STRIDE = 52;      // int32 per row: 32 coefs, shift, order, 2 spare, then
+constexpr int FIN_DBL = 36;         // ... the first 8 coefficients once more as doubles
 hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_order,
                       int precision, int omethod, int32_t *coefs, int32_t *shift,
                       int32_t *opt_order, int32_t *fin);

@@ -1408,6 +1408,8 @@ void k_lpc(const double *__restrict__ autoc_all, int nsub, int max_order, int pr
         for (int j = 0; j < max_order; j++) f[j] = (j < levinson_order) ? src[j] : 0;
         f[32] = srow[levinson_order - 1];
         f[33] = levinson_order;
+        double *fd = reinterpret_cast<double *>(f + FIN_DBL);     // the first 8 as doubles (K3 reads them as scalars)
+        for (int j = 0; j < 8; j++) fd[j] = (j < levinson_order && j < max_order) ? (double)src[j] : 0.0;
     }
 }
 
@@ -1439,6 +1441,9 @@ __device__ __forceinline__ void quantize_row_reg(const double (&a)[MO], int orde
             for (int j = 0; j < MO; j++) if (j < max_order) fin_out[j] = 0;
             fin_out[32] = 0;
             fin_out[33] = order;
+            double *fd = reinterpret_cast<double *>(fin_out + FIN_DBL);
+#pragma unroll
+            for (int j = 0; j < 8; j++) fd[j] = 0.0;
         }
         return;
     }
@@ -1460,9 +1465,13 @@ __device__ __forceinline__ void quantize_row_reg(const double (&a)[MO], int orde
             if (q > qmax) q = qmax;
             carry = carry - (double)q;
             out[j] = q;
-            if (fin_out) fin_out[j] = q;
-        } else if (fin_out && j < max_order) {
-            fin_out[j] = 0;
+            if (fin_out) {
+                fin_out[j] = q;
+                if (j < 8) reinterpret_cast<double *>(fin_out + FIN_DBL)[j] = (double)q;
+            }
+        } else if (fin_out) {
+            if (j < max_order) fin_out[j] = 0;
+            if (j < 8) reinterpret_cast<double *>(fin_out + FIN_DBL)[j] = 0.0;
         }
     }
     *shift_out = sh;
@@ -2332,6 +2341,66 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
     }
 }
 
+// The same FIR for orders <= 8 with the coefficients as wave-uniform doubles read
+// from K2's compact row by scalar loads (MODE 0): no coefficient traffic through
+// LDS, no vector registers for them.
+template <int C, int T>
+__device__ __forceinline__ void fir_lpc_o8(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
+                                           const double *__restrict__ cd)
+{
+    using Img = SmpImg<C, T>;
+    const double inv = __builtin_ldexp(1.0, -shift);
+    constexpr int OB = (C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : 1;
+    const int32_t *mine = e.l.smp + e.tid * Img::CS;
+    double cf[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) cf[jj] = cd[jj];
+#pragma unroll
+    for (int ob = 0; ob < C; ob += OB) {
+        __builtin_amdgcn_sched_barrier(0);
+        double acc[OB];
+#pragma unroll
+        for (int o = 0; o < OB; o++) acc[o] = 0.0;
+        double W[OB + 7];
+        if constexpr (Img::V4) {
+#pragma unroll
+            for (int m4 = 0; m4 < OB + 7; m4 += 4) {
+                const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob - 8 + m4));
+                W[m4] = (double)v.x;
+                if (m4 + 1 < OB + 7) W[m4 + 1] = (double)v.y;
+                if (m4 + 2 < OB + 7) W[m4 + 2] = (double)v.z;
+                if (m4 + 3 < OB + 7) W[m4 + 3] = (double)v.w;
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < OB + 7; m++) W[m] = (double)mine[Img::off(ob - 8 + m)];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++)
+#pragma unroll
+            for (int o = 0; o < OB; o++)
+                acc[o] = __builtin_fma(cf[jj], W[o + 7 - jj], acc[o]);
+#pragma unroll
+        for (int o = 0; o < OB; o++) {
+            const double z = __builtin_fma(acc[o], inv, 6755399441055744.0);   // floor under round-down, see fir_lpc
+            const uint32_t qlo = (uint32_t)__double2loint(z);
+            uint32_t x;
+            if constexpr (Img::V4) {
+                const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob + (o & ~3)));
+                x = (uint32_t)((o & 3) == 0 ? v.x : (o & 3) == 1 ? v.y : (o & 3) == 2 ? v.z : v.w);
+            } else {
+                x = (uint32_t)mine[Img::off(ob + o)];
+            }
+            r[ob + o] = (int32_t)(x - qlo);
+        }
+    }
+    if (e.i0 < order) {
+#pragma unroll
+        for (int o = 0; o < C; o++)
+            if (e.i0 + o < order) r[o] = mine[Img::off(o)];
+    }
+}
+
 // optimize.c:34-68 encode_residual_fixed on the thread's run.  The reference
 // computes in long long and stores to int32: the low 32 bits, which wrapping
 // 32-bit arithmetic yields directly.
@@ -2743,7 +2812,11 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                     __syncthreads();
                 }
                 STAMP(2);
-                fir_lpc<C, T>(e, r, ord, cshift);
+                if (pre_row && ord <= 8)
+                    fir_lpc_o8<C, T>(e, r, ord, cshift,
+                                     reinterpret_cast<const double *>(fin_all + (size_t)s * FIN_STRIDE + FIN_DBL));
+                else
+                    fir_lpc<C, T>(e, r, ord, cshift);
                 STAMP(3);
                 b = rice_search_fast<C, T>(e, r, u, ord, true, &porder, &method);
                 STAMP(8);

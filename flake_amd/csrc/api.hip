@@ -158,7 +158,7 @@ struct FrameOut { uint8_t *frames; int64_t stride; int32_t *bytes; uint32_t firs
 static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm, int nframes, int n,
                      fhip_subframe_info *info, int32_t *residual, uint8_t *bits,
                      int64_t slot_bytes, int32_t *smp, double *autoc, size_t sub0,
-                     const FrameOut &fo)
+                     const FrameOut &fo, bool want_rows = false)
 {
     const fhip_params &p = c->p;
     const int nsub = nframes * p.channels;
@@ -175,9 +175,12 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
     // stereo batches in whole tiles: K0 only decides (ch_mode, wasted bits), the K1
     // producers apply that to the PCM they stream anyway and write smp
     const bool fused = lpc_path && fhip::autocorr_fuses_prepare(p, nsub, n);
+    // rows of 16-bit samples where every kernel of this batch reads them that way and
+    // nobody outside asked for the int32 rows
+    const bool narrow = !fused && !want_rows && fhip::narrow_rows_ok(p, nsub, n, lpc_path);
     {
         MaybeProf pr(c, prof, 0);
-        HIP_TRY(c, fhip::launch_prepare(st, p, pcm, nframes, n, smp, info, fused));
+        HIP_TRY(c, fhip::launch_prepare(st, p, pcm, nframes, n, smp, info, fused, narrow));
     }
     if (lpc_path) {
         // K2 rides on K1's tail where K1 is the wave-typed kernel and the order fits registers
@@ -187,7 +190,7 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
             MaybeProf pr(c, prof, 1);
             HIP_TRY(c, fhip::launch_autocorr(st, smp, nsub, n, p.max_prediction_order, autoc,
                                              fused ? pcm : nullptr, fused ? smp : nullptr, info,
-                                             lpc_tail ? &lo : nullptr));
+                                             lpc_tail ? &lo : nullptr, narrow));
         }
         if (!lpc_tail) {
             MaybeProf pr(c, prof, 2);
@@ -198,7 +201,7 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
     {
         MaybeProf pr(c, prof, 3);
         HIP_TRY(c, fhip::launch_encode(st, p, smp, nsub, n, coefs, shift, opt, fin, info, residual,
-                                       bits, slot_bytes));
+                                       bits, slot_bytes, -1, 0, narrow));
     }
     if (fo.frames) {
         MaybeProf pr(c, prof, 4);
@@ -218,8 +221,9 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
 int run_pipeline(fhip_ctx *c, const int32_t *pcm, int nframes, int n,
                  fhip_subframe_info *info, int32_t *residual, uint8_t *bits,
                  int64_t slot_bytes, int32_t *samples_out, double *autoc_out,
-                 const FrameOut &fo = FrameOut{nullptr, 0, nullptr, 0})
+                 const FrameOut &fo = FrameOut{nullptr, 0, nullptr, 0}, bool want_rows = false)
 {
+    want_rows = want_rows || samples_out != nullptr;     // somebody reads FlacSubframe.samples as int32
     const fhip_params &p = c->p;
     int32_t *smp = samples_out ? samples_out : c->d_smp;
     double *autoc = autoc_out ? autoc_out : c->d_autoc;
@@ -227,7 +231,7 @@ int run_pipeline(fhip_ctx *c, const int32_t *pcm, int nframes, int n,
     const bool split = !c->profiling && c->overlap && nframes >= 512 && c->aux[0] && c->aux[1];
     if (!split)
         return run_range(c, c->stream, c->profiling, pcm, nframes, n, info, residual, bits,
-                         slot_bytes, smp, autoc, 0, fo);
+                         slot_bytes, smp, autoc, 0, fo, want_rows);
 
     HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
     const int parts[3] = {0, nframes / 2, nframes};
@@ -242,7 +246,7 @@ int run_pipeline(fhip_ctx *c, const int32_t *pcm, int nframes, int n,
                            FrameOut{fo.frames ? fo.frames + f0 * (size_t)fo.stride : nullptr, fo.stride,
                                     fo.bytes ? fo.bytes + f0 : nullptr,
                                     fo.first + (uint32_t)f0 * (p.allow_vbs ? (uint32_t)n : 1u),
-                                    fo.numbers ? fo.numbers + f0 : nullptr});
+                                    fo.numbers ? fo.numbers + f0 : nullptr}, want_rows);
         if (rc != FHIP_OK) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_join[h], c->aux[h]));
     }
@@ -484,7 +488,7 @@ int fhip_encode_subframes(fhip_ctx *c, const fhip_batch *b)
     }
     rc = run_pipeline(c, c->d_pcm, b->nframes, b->block_size, c->d_info,
                       b->residual ? c->d_res : nullptr, want_bits ? c->d_bits : nullptr,
-                      b->rice_slot_bytes, nullptr, d_autoc_out, fo);
+                      b->rice_slot_bytes, nullptr, d_autoc_out, fo, b->samples != nullptr);
     if (rc != FHIP_OK) return rc;
     if (b->info)
         HIP_TRY(c, hipMemcpyAsync(b->info, c->d_info, nsub * sizeof(fhip_subframe_info), hipMemcpyDeviceToHost, c->stream));

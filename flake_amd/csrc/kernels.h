@@ -19,9 +19,15 @@ struct EncodeArgs {
 // K0: copy_samples + channel_decorrelation + remove_wasted_bits
 // (encode.c:541-694).  pcm [nframes][n][ch] -> smp [nframes][ch][n].
 // decide_only: write obits / wasted / ch_mode to info[] and leave smp to the fused K1.
+// allow_narrow: a channel whose samples all fit 16 bits is stored as int16[n] at the
+// start of its row and flagged in info.reserved (see narrow_rows_ok).
 hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *pcm,
                           int nframes, int n, int32_t *smp, fhip_subframe_info *info,
-                          bool decide_only = false);
+                          bool decide_only = false, bool allow_narrow = false);
+
+// True when K0, K1 and K3 all handle 16-bit sample rows for such a batch; the
+// caller then passes allow_narrow / narrow_ok to the three launches of the batch.
+bool narrow_rows_ok(const fhip_params &p, int nsub, int n, bool lpc_path);
 
 // True when K1 will also do K0's apply stage for such a batch (stereo, whole
 // tiles, the wave-typed kernel): launch_prepare(decide_only) + launch_autocorr(pcm).
@@ -38,7 +44,7 @@ bool autocorr_does_lpc(int nsub, int n, int max_order);
 hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                            int max_order, double *autoc, const int32_t *pcm_fused = nullptr,
                            int32_t *smp_out = nullptr, const fhip_subframe_info *info = nullptr,
-                           const autocorr_lpc_out *lpc_out = nullptr);
+                           const autocorr_lpc_out *lpc_out = nullptr, bool narrow_ok = false);
 
 // K2: compute_lpc_coefs / _est + quantize_lpc_coefs (lpc.c:77-257).
 // coefs [nsub][32][32], shift [nsub][32], opt_order [nsub].
@@ -57,7 +63,7 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
                          const int32_t *opt_order, const int32_t *fin,
                          fhip_subframe_info *info,
                          int32_t *residual, uint8_t *bits, int64_t slot_bytes,
-                         int raw_order = -1, int raw_lpc = 0);
+                         int raw_order = -1, int raw_lpc = 0, bool narrow_ok = false);
 
 // K4: whole frames on the device (encode.c:718-764, :800-917, :949-964):
 // frames [nframes][frame_stride] bytes, frame_bytes [nframes].

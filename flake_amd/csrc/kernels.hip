@@ -372,11 +372,15 @@ void k_prepare_multi(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
 // load anyway and write smp (k_autocorr_wt<NCH, true>).
 template <int M, bool APPLY>
 __global__ __launch_bounds__(NT)
+// allow_narrow: a channel whose samples (after the shift) all fit 16 bits is stored
+// as int16[n] at the start of its row (info.reserved = 1 tells K1's producers and
+// K3's staging; K3 resets the field) -- half the bytes written here and read there.
 void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
-                      fhip_subframe_info *__restrict__ info, int n, int bps, int estimate)
+                      fhip_subframe_info *__restrict__ info, int n, int bps, int estimate,
+                      int allow_narrow)
 {
     __shared__ unsigned long long s_sum[4][4];
-    __shared__ uint32_t s_or[4][2];
+    __shared__ uint32_t s_or[4][4];
     __shared__ int s_mode;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -444,6 +448,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
 
     // encode.c:668-693 apply, then OR of every sample per channel
     uint32_t or0 = 0, or1 = 0;
+    uint32_t mg0 = 0, mg1 = 0;            // OR of x ^ (x >> 31): the magnitude bits in use
 #pragma unroll
     for (int m = 0; m < M; m++) {
         const bool on = (tid + NT * m) < nquads;
@@ -462,10 +467,13 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
             L[m][q] = a; R[m][q] = b;
             or0 |= on ? (uint32_t)a : 0u;
             or1 |= on ? (uint32_t)b : 0u;
+            mg0 |= on ? (uint32_t)(a ^ (a >> 31)) : 0u;
+            mg1 |= on ? (uint32_t)(b ^ (b >> 31)) : 0u;
         }
     }
     or0 = wave_or_u32(or0); or1 = wave_or_u32(or1);
-    if (lane == 0) { s_or[wv][0] = or0; s_or[wv][1] = or1; }
+    mg0 = wave_or_u32(mg0); mg1 = wave_or_u32(mg1);
+    if (lane == 0) { s_or[wv][0] = or0; s_or[wv][1] = or1; s_or[wv][2] = mg0; s_or[wv][3] = mg1; }
     __syncthreads();
 
     int wasted[2], obits[2];
@@ -480,6 +488,13 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
     }
     if (mode == FHIP_CH_MID_SIDE || mode == FHIP_CH_LEFT_SIDE) obits[1]++;
     if (mode == FHIP_CH_RIGHT_SIDE) obits[0]++;
+    bool narrow[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        // (x >> w) ^ sign == (x ^ sign) >> w: every shifted sample within int16
+        const uint32_t mg = s_or[0][2 + c] | s_or[1][2 + c] | s_or[2][2 + c] | s_or[3][2 + c];
+        narrow[c] = allow_narrow && ((mg >> wasted[c]) < 32768u);
+    }
 
     int4 *dl = reinterpret_cast<int4 *>(smp + (size_t)f * 2 * n);
     int4 *dr = reinterpret_cast<int4 *>(smp + (size_t)f * 2 * n + n);
@@ -487,8 +502,12 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
     for (int m = 0; m < M; m++) {
         const int g = tid + NT * m;
         if (APPLY && g < nquads) {
-            dl[g] = make_int4(L[m][0] >> wasted[0], L[m][1] >> wasted[0], L[m][2] >> wasted[0], L[m][3] >> wasted[0]);
-            dr[g] = make_int4(R[m][0] >> wasted[1], R[m][1] >> wasted[1], R[m][2] >> wasted[1], R[m][3] >> wasted[1]);
+            const int4 vl = make_int4(L[m][0] >> wasted[0], L[m][1] >> wasted[0], L[m][2] >> wasted[0], L[m][3] >> wasted[0]);
+            const int4 vr = make_int4(R[m][0] >> wasted[1], R[m][1] >> wasted[1], R[m][2] >> wasted[1], R[m][3] >> wasted[1]);
+            if (narrow[0]) reinterpret_cast<int2 *>(dl)[g] = make_int2((vl.x & 0xFFFF) | (vl.y << 16), (vl.z & 0xFFFF) | (vl.w << 16));
+            else dl[g] = vl;
+            if (narrow[1]) reinterpret_cast<int2 *>(dr)[g] = make_int2((vr.x & 0xFFFF) | (vr.y << 16), (vr.z & 0xFFFF) | (vr.w << 16));
+            else dr[g] = vr;
         }
     }
     if (tid < 2) {
@@ -496,6 +515,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
         o->obits = obits[tid];
         o->wasted = wasted[tid];
         o->ch_mode = mode;
+        o->reserved = narrow[tid] ? 1 : 0;
     }
 }
 
@@ -968,7 +988,7 @@ __global__ __launch_bounds__(8 * WAVE)
 void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                    int nsub, int n, int maxlag, wt_groups grp, double c,
                    const int32_t *__restrict__ pcm, int32_t *__restrict__ smp_out,
-                   const fhip_subframe_info *__restrict__ info, wt_lpc_args lpc)
+                   const fhip_subframe_info *__restrict__ info, wt_lpc_args lpc, int narrow_ok)
 {
     extern __shared__ __attribute__((aligned(16))) double wt_lds[];
     double *acbuf = wt_lds + WT_NBUF * WT_BUF;          // [32][FHIP_MAX_LAGS], LPCMO > 0 only
@@ -1001,6 +1021,7 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
             // row bases are wave-uniform: SGPR base + lane offset addressing
             unsigned long long rowb[NL], outb[NR];
             int mode[NL], w0s[NL], w1s[NL];
+            int nar[NL];                                       // row stored as int16 (K0: info.reserved)
 #pragma unroll
             for (int r = 0; r < NL; r++) {
                 if (FUSED) {
@@ -1012,7 +1033,9 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                     w0s[r] = __builtin_amdgcn_readfirstlane(info[sub].wasted);
                     w1s[r] = __builtin_amdgcn_readfirstlane(info[sub + 1].wasted);
                 } else {
-                    rowb[r] = uni64((unsigned long long)(smp + (size_t)min(sub0 + q0 + r, nsub - 1) * n));
+                    const int sub = min(sub0 + q0 + r, nsub - 1);
+                    rowb[r] = uni64((unsigned long long)(smp + (size_t)sub * n));
+                    nar[r] = narrow_ok ? __builtin_amdgcn_readfirstlane(info[sub].reserved) : 0;
                 }
             }
             typedef typename std::conditional<FUSED, int4, int2>::type ld_t;
@@ -1020,8 +1043,12 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
             auto issue_loads = [&](ld_t (&dst)[NL], int tb) {
                 const int p = min(tb + 2 * lane, n - 2);       // past the block: clamped, weight 0
 #pragma unroll
-                for (int r = 0; r < NL; r++)
-                    dst[r] = *reinterpret_cast<const ld_t *>(reinterpret_cast<const int32_t *>(rowb[r]) + (FUSED ? 2 * p : p));
+                for (int r = 0; r < NL; r++) {
+                    // a narrow row holds the pair (2 lane, 2 lane + 1) in ONE dword, at int index p / 2;
+                    // the same 8-byte load serves both widths (the second dword is then unused)
+                    const int idx = FUSED ? 2 * p : (nar[r] ? (p >> 1) : p);
+                    dst[r] = *reinterpret_cast<const ld_t *>(reinterpret_cast<const int32_t *>(rowb[r]) + idx);
+                }
             };
 #pragma unroll
             for (int a = 0; a < WT_AHEAD; a++) issue_loads(pre[a], a * AC_TILE);
@@ -1073,7 +1100,9 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                             *reinterpret_cast<int2 *>(reinterpret_cast<int32_t *>(outb[r]) + pst) = make_int2(x0, x1);
                         } else {
                             const int2 v = *reinterpret_cast<const int2 *>(&pre[a][r]);
-                            x0 = v.x; x1 = v.y;
+                            const bool nr = nar[FUSED ? 0 : r] != 0;        // wave-uniform
+                            x0 = nr ? (int32_t)(int16_t)v.x : v.x;
+                            x1 = nr ? (v.x >> 16) : v.y;
                         }
                         const double v0 = (double)x0 * w0;
                         const double v1 = (double)x1 * w1;
@@ -2595,7 +2624,8 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                    const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                    const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,
                    fhip_subframe_info *__restrict__ info,
-                   int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes)
+                   int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
+                   int narrow_ok)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     size_t off[12];
@@ -2641,7 +2671,21 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     int32_t first_n, obits_n, fcoef_n = 0, fshift_n = 0, forder_n = 0;
     {
         const int32_t *srcp = smp_all + (size_t)s * n;
-        if (C % 4 == 0) {
+        // K0 may have stored this row as int16 (info.reserved, honoured only when the
+        // launcher says the flag is K0's): half the loads, one sign extension per sample
+        const bool narrow = (C % 8 == 0) && narrow_ok && info[s].reserved != 0;
+        if (C % 8 == 0 && narrow) {
+            const int4 *src4 = reinterpret_cast<const int4 *>(reinterpret_cast<const int16_t *>(srcp) + e.i0);
+#pragma unroll
+            for (int q = 0; q < C / 8; q++) {
+                const int4 t4 = src4[q];
+                xn[8 * q] = (int32_t)(int16_t)t4.x;     xn[8 * q + 1] = t4.x >> 16;
+                xn[8 * q + 2] = (int32_t)(int16_t)t4.y; xn[8 * q + 3] = t4.y >> 16;
+                xn[8 * q + 4] = (int32_t)(int16_t)t4.z; xn[8 * q + 5] = t4.z >> 16;
+                xn[8 * q + 6] = (int32_t)(int16_t)t4.w; xn[8 * q + 7] = t4.w >> 16;
+            }
+            first_n = (int32_t)*reinterpret_cast<const int16_t *>(srcp);
+        } else if (C % 4 == 0) {
             // 16-byte lane accesses of the thread's own run
             const int4 *src4 = reinterpret_cast<const int4 *>(srcp + e.i0);
 #pragma unroll
@@ -2654,7 +2698,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
 #pragma unroll
             for (int q = 0; q < C; q++) xn[q] = srcp[tid + T * q];
         }
-        first_n = srcp[0];
+        if (!narrow) first_n = srcp[0];
         obits_n = info[s].obits;
         if (pre_row) {
             const int32_t *f = fin_all + (size_t)s * FIN_STRIDE;
@@ -3447,14 +3491,16 @@ void k_vbs_split(const int32_t *__restrict__ pcm, int nblocks, int block_size, i
 // ---------------------------------------------------------------------------
 
 hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *pcm,
-                          int nframes, int n, int32_t *smp, fhip_subframe_info *info, bool decide_only)
+                          int nframes, int n, int32_t *smp, fhip_subframe_info *info, bool decide_only,
+                          bool allow_narrow)
 {
     const int nch = p.channels;
     if (nframes == 0) return hipSuccess;
     if (nch == 2 && (n & 3) == 0 && n <= 8192) {
         const int est = p.stereo_method == 1 ? 1 : 0;
         const int quads = n >> 2;
-#define LAUNCH_PS(M_, A_) hipLaunchKernelGGL((k_prepare_stereo<M_, A_>), dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est)
+        const int nar = (allow_narrow && !decide_only) ? 1 : 0;
+#define LAUNCH_PS(M_, A_) hipLaunchKernelGGL((k_prepare_stereo<M_, A_>), dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est, nar)
         if (decide_only) {
             if (quads <= NT) LAUNCH_PS(1, false); else if (quads <= 2 * NT) LAUNCH_PS(2, false); else LAUNCH_PS(4, false);
         } else {
@@ -3467,7 +3513,7 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
 #undef LAUNCH_PS
         return hipGetLastError();
     }
-    if (decide_only) return hipErrorInvalidValue;
+    if (decide_only || allow_narrow) return hipErrorInvalidValue;
     if (nch != 2) {
         hipLaunchKernelGGL(k_prepare_multi, dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, nch,
                            p.bits_per_sample);
@@ -3548,7 +3594,7 @@ bool autocorr_fuses_prepare(const fhip_params &p, int nsub, int n)
 hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                            int max_order, double *autoc, const int32_t *pcm_fused,
                            int32_t *smp_out, const fhip_subframe_info *info,
-                           const autocorr_lpc_out *lpc_out)
+                           const autocorr_lpc_out *lpc_out, bool narrow_ok)
 {
     if (nsub == 0) return hipSuccess;
     // the window constant is computed on the host exactly as lpc.c:34 does
@@ -3557,7 +3603,8 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
     const int ne = ch.ne, no = ch.no, Gp = ch.Gp, lps = ch.lps, ge = ch.ge, nl2 = ch.nl2;
     int G = ch.G;
     const bool use_wt = ch.kernel == 2, use_ps = ch.kernel == 1;
-    if ((pcm_fused || lpc_out) && !use_wt) return hipErrorInvalidValue;
+    if ((pcm_fused || lpc_out || narrow_ok) && !use_wt) return hipErrorInvalidValue;
+    if (narrow_ok && (!info || pcm_fused)) return hipErrorInvalidValue;
     const int e0 = (ne + 1) / 2, e1 = ne - e0, o0 = (no + 1) / 2, o1 = no - o0;
     if (use_wt) {
         wt_groups gr;
@@ -3584,7 +3631,7 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all); \
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_autocorr_wt<N_, F_, L_>), dim3(blocks), dim3(8 * WAVE), lds_all, st, smp, \
-                           autoc, nsub, n, max_order, gr, c, pcm_fused, smp_out, info, la);  \
+                           autoc, nsub, n, max_order, gr, c, pcm_fused, smp_out, info, la, narrow_ok ? 1 : 0); \
     } while (0)
 #define LAUNCH_WT(N_)                                                                        \
     case N_:                                                                                 \
@@ -3695,12 +3742,25 @@ static bool fast_geometry(const fhip_params &p, int n, int *C, int *T)
     return true;
 }
 
+// True when every kernel of the pipeline that touches the sample rows understands
+// 16-bit rows for such a batch: the register K0 for stereo, the wave-typed K1 (or
+// no K1 at all) and a K3 fast-path geometry with runs of 8 or 16 samples.
+bool narrow_rows_ok(const fhip_params &p, int nsub, int n, bool lpc_path)
+{
+    static const bool off = getenv("FHIP_NO_NARROW") != nullptr;        // measurements only
+    if (off || p.channels != 2 || (n & 3) != 0 || n > 8192) return false;
+    int fc = 0, ft = 0;
+    if (!fast_geometry(p, n, &fc, &ft) || (fc % 8) != 0) return false;
+    if (lpc_path && pick_autocorr(nsub, n, p.max_prediction_order).kernel != 2) return false;
+    return true;
+}
+
 hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *smp,
                          int nsub, int n, const int32_t *coefs, const int32_t *shift,
                          const int32_t *opt_order, const int32_t *fin,
                          fhip_subframe_info *info,
                          int32_t *residual, uint8_t *bits, int64_t slot_bytes,
-                         int raw_order, int raw_lpc)
+                         int raw_order, int raw_lpc, bool narrow_ok)
 {
     if (nsub == 0) return hipSuccess;
     int fc = 0, ft = 0;
@@ -3717,7 +3777,7 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_encode_pow2<CC, TT, MM>), dim3(nsub), dim3(TT), lds, st, p, n, \
                            nsub, smp, coefs, shift, opt_order, fin, info, residual, bits,    \
-                           (long long)slot_bytes);                                           \
+                           (long long)slot_bytes, narrow_ok ? 1 : 0);                        \
     } while (0)
         // one quantised row known up front (MAX / EST): the lean instance
         const bool single_row = (p.prediction_type == 2) && (n > p.max_prediction_order) && (p.order_method <= 1);

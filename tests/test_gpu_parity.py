@@ -393,3 +393,46 @@ def test_fused_prepare_path_subprocess():
     env = dict(os.environ, FHIP_FUSE="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fused ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("n", [512, 2048, 4096, 8192])
+def test_narrow_sample_rows(oracle, n):
+    """K0 stores a channel as int16 when all its (shifted) samples fit: both channels
+    narrow, only one (a 17-bit side / a loud right channel), none (24-bit), and narrow
+    only thanks to wasted bits.  Outputs must not depend on the storage width, and
+    the int32 rows are still what a caller of `samples` gets."""
+    r = np.random.RandomState(n)
+    t = np.arange(n)
+    quiet = (3000 * np.sin(t * 0.01)).astype(np.int64)
+    frames16 = [
+        np.stack([quiet + r.randint(-50, 50, n), quiet + r.randint(-50, 50, n)], 1),          # narrow / narrow
+        np.stack([30000 * np.sign(np.sin(t * 0.3)), -30000 * np.sign(np.sin(t * 0.3))], 1),   # side needs 17 bits
+        np.stack([r.randint(-32768, 32768, n), r.randint(-100, 100, n)], 1),                  # noise left, quiet right
+        np.stack([np.full(n, -32768), np.full(n, 32767)], 1),                                 # constants at the rails
+    ]
+    pcm16 = np.stack(frames16).astype(np.int32)
+    for om, kw in ((flake_amd.OM_MAX, {}), (flake_amd.OM_EST, {}), (flake_amd.OM_4LEVEL, {}),
+                   (flake_amd.OM_EST, dict(prediction_type=flake_amd.PRED_FIXED, min_prediction_order=0,
+                                           max_prediction_order=4))):
+        p = flake_amd.level_params(5, block_size=n, order_method=om, **kw)
+        with flake_amd.Encoder(p, max_frames=pcm16.shape[0]) as enc:
+            got = enc.encode_subframes(pcm16, n)                       # narrow rows allowed
+            rows = enc.encode_subframes(pcm16, n, want_samples=True)   # int32 rows requested
+        exp = oracle.encode_subframes_batch(p, pcm16, n, slot_bytes=got["slot_bytes"])
+        for g in (got, rows):
+            assert_info_equal(g["info"], exp["info"], f"narrow16 n{n} om{om}")
+            assert_residual_equal(g["residual"], exp["residual"], exp["info"], f"narrow16 n{n}")
+            assert_bits_equal(g["rice_bits"], exp["rice_bits"], exp["info"], f"narrow16 n{n}")
+        assert (got["info"]["reserved"] == 0).all()
+    # 24-bit: wide as such, narrow when the low byte is all zeros (wasted bits)
+    loud = (r.randint(-2 ** 22, 2 ** 22, (2, n, 2))).astype(np.int32)
+    shifted = (r.randint(-20000, 20000, (2, n, 2)) << 8).astype(np.int32)
+    pcm24 = np.concatenate([loud, shifted])
+    p = flake_amd.level_params(5, bits_per_sample=24, block_size=n)
+    with flake_amd.Encoder(p, max_frames=4) as enc:
+        got = enc.encode_subframes(pcm24, n)
+    exp = oracle.encode_subframes_batch(p, pcm24, n, slot_bytes=got["slot_bytes"])
+    assert_info_equal(got["info"], exp["info"], f"narrow24 n{n}")
+    assert_residual_equal(got["residual"], exp["residual"], exp["info"], f"narrow24 n{n}")
+    assert_bits_equal(got["rice_bits"], exp["rice_bits"], exp["info"], f"narrow24 n{n}")
+    assert (exp["info"]["wasted"][4:] >= 8).all()

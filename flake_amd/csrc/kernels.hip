@@ -404,6 +404,33 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
     if (estimate && n > 32) {
         // encode.c:598-643 calc_decorr_scores
         unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (bps <= 24) {
+            // |2nd-order residual| < 2^(bps+2) and never INT_MIN: the 4*M values of a
+            // thread add up in 32 bits, no wrap_abs corner, no per-sample predicate
+            uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const int g = tid + NT * m;
+                if (g < nquads) {
+                    int32_t l2 = prev[m].x, r2 = prev[m].y, l1 = prev[m].z, r1 = prev[m].w;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int32_t l0 = L[m][q], r0 = R[m][q];
+                        int32_t lt = l0 - 2 * l1 + l2;
+                        int32_t rt = r0 - 2 * r1 + r2;
+                        if (q < 2 && g == 0) { lt = 0; rt = 0; }        // no history for the first two (encode.c:607)
+                        const int32_t mm = (lt + rt) >> 1;
+                        const int32_t ss = lt - rt;
+                        s0 += (uint32_t)max(lt, -lt);
+                        s1 += (uint32_t)max(rt, -rt);
+                        s2 += (uint32_t)max(mm, -mm);
+                        s3 += (uint32_t)max(ss, -ss);
+                        l2 = l1; r2 = r1; l1 = l0; r1 = r0;
+                    }
+                }
+            }
+            a0 = s0; a1 = s1; a2 = s2; a3 = s3;
+        } else {
 #pragma unroll
         for (int m = 0; m < M; m++) {
             const int g = tid + NT * m;
@@ -423,6 +450,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
                 a3 += on ? (unsigned long long)(long long)wrap_abs(ss) : 0ull;
                 l2 = l1; r2 = r1; l1 = l0; r1 = r0;
             }
+        }
         }
         a0 = wave_sum_u64(a0); a1 = wave_sum_u64(a1);
         a2 = wave_sum_u64(a2); a3 = wave_sum_u64(a3);

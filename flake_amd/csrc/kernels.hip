@@ -517,11 +517,13 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
     if (mode == FHIP_CH_MID_SIDE || mode == FHIP_CH_LEFT_SIDE) obits[1]++;
     if (mode == FHIP_CH_RIGHT_SIDE) obits[0]++;
     bool narrow[2];
+    int magbits[2];                       // |x| < 2^magbits for every shifted sample of the channel
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         // (x >> w) ^ sign == (x ^ sign) >> w: every shifted sample within int16
-        const uint32_t mg = s_or[0][2 + c] | s_or[1][2 + c] | s_or[2][2 + c] | s_or[3][2 + c];
-        narrow[c] = allow_narrow && ((mg >> wasted[c]) < 32768u);
+        const uint32_t mg = (s_or[0][2 + c] | s_or[1][2 + c] | s_or[2][2 + c] | s_or[3][2 + c]) >> wasted[c];
+        narrow[c] = allow_narrow && (mg < 32768u);
+        magbits[c] = 32 - __clz((int)mg);
     }
 
     int4 *dl = reinterpret_cast<int4 *>(smp + (size_t)f * 2 * n);
@@ -543,7 +545,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
         o->obits = obits[tid];
         o->wasted = wasted[tid];
         o->ch_mode = mode;
-        o->reserved = narrow[tid] ? 1 : 0;
+        o->reserved = narrow[tid] ? 1 + magbits[tid] : 0;     // 1..16: narrow row, |x| <= 2^(reserved-1)
     }
 }
 
@@ -1467,6 +1469,11 @@ void k_lpc(const double *__restrict__ autoc_all, int nsub, int max_order, int pr
         f[33] = levinson_order;
         double *fd = reinterpret_cast<double *>(f + FIN_DBL);     // the first 8 as doubles (K3 reads them as scalars)
         for (int j = 0; j < 8; j++) fd[j] = (j < levinson_order && j < max_order) ? (double)src[j] : 0.0;
+        int32_t cabs = 0, c8[8];
+        for (int j = 0; j < 8; j++) c8[j] = (j < levinson_order && j < max_order) ? src[j] : 0;
+        for (int j = 0; j < levinson_order; j++) cabs += (src[j] < 0) ? -src[j] : src[j];
+        f[34] = cabs;
+        for (int j = 0; j < 4; j++) f[FIN_PAIRS + j] = (c8[2 * j + 1] & 0xFFFF) | (int32_t)((uint32_t)c8[2 * j] << 16);
     }
 }
 
@@ -1501,6 +1508,9 @@ __device__ __forceinline__ void quantize_row_reg(const double (&a)[MO], int orde
             double *fd = reinterpret_cast<double *>(fin_out + FIN_DBL);
 #pragma unroll
             for (int j = 0; j < 8; j++) fd[j] = 0.0;
+            fin_out[34] = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) fin_out[FIN_PAIRS + j] = 0;
         }
         return;
     }
@@ -1510,6 +1520,9 @@ __device__ __forceinline__ void quantize_row_reg(const double (&a)[MO], int orde
     const double scale = rescale ? ((double)qmax / cmax) : 1.0;
     const double mul = (double)(1 << sh);
     double carry = 0.0;
+    int32_t cabs = 0, c8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) c8[j] = 0;
 #pragma unroll
     for (int j = 0; j < MO; j++) {
         if (j < order) {
@@ -1522,6 +1535,8 @@ __device__ __forceinline__ void quantize_row_reg(const double (&a)[MO], int orde
             if (q > qmax) q = qmax;
             carry = carry - (double)q;
             out[j] = q;
+            cabs += (q < 0) ? -q : q;
+            if (j < 8) c8[j] = q;
             if (fin_out) {
                 fin_out[j] = q;
                 if (j < 8) reinterpret_cast<double *>(fin_out + FIN_DBL)[j] = (double)q;
@@ -1535,6 +1550,12 @@ __device__ __forceinline__ void quantize_row_reg(const double (&a)[MO], int orde
     if (fin_out) {
         fin_out[32] = sh;
         fin_out[33] = order;
+        // for K3's 16-bit dot-product FIR: sum |coef| and the first 8 coefficients as
+        // int16 pairs (lo: tap 2j+2, hi: tap 2j+1)
+        fin_out[34] = cabs;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            fin_out[FIN_PAIRS + j] = (c8[2 * j + 1] & 0xFFFF) | (int32_t)((uint32_t)c8[2 * j] << 16);
     }
 }
 
@@ -2458,6 +2479,52 @@ __device__ __forceinline__ void fir_lpc_o8(const FastCtx<C, T> &e, int32_t (&r)[
     }
 }
 
+// Orders <= 8 on a channel whose samples fit 16 bits (K0's narrow rows), when the
+// prediction provably stays inside int32 (sum|coef| * 2^magbits < 2^31, checked by
+// the caller): v_dot2_i32_i16 does two taps per instruction on int16 pairs and
+// costs about what one fp64 FMA does, with no int -> fp64 conversions in front.
+// Sample pairs R(k) = (lo: x[k], hi: x[k+1]) are packed from the int32 window;
+// cp[j] = (lo: coef of tap 2j+2, hi: coef of tap 2j+1) comes from K2 (scalars).
+template <int C, int T>
+__device__ __forceinline__ void fir_lpc_dot8(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
+                                             const int32_t *__restrict__ cp)
+{
+    using Img = SmpImg<C, T>;
+    static_assert(Img::V4 && C % 8 == 0, "fir_lpc_dot8: runs of 8 or 16");
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const int32_t *mine = e.l.smp + e.tid * Img::CS;
+    const s2 q0 = __builtin_bit_cast(s2, cp[0]), q1 = __builtin_bit_cast(s2, cp[1]);
+    const s2 q2 = __builtin_bit_cast(s2, cp[2]), q3 = __builtin_bit_cast(s2, cp[3]);
+#pragma unroll
+    for (int ob = 0; ob < C; ob += 8) {
+        __builtin_amdgcn_sched_barrier(0);
+        int32_t W[16];                                     // samples ob-8 .. ob+7
+#pragma unroll
+        for (int m4 = 0; m4 < 16; m4 += 4) {
+            const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob - 8 + m4));
+            W[m4] = v.x; W[m4 + 1] = v.y; W[m4 + 2] = v.z; W[m4 + 3] = v.w;
+        }
+        s2 R[14];                                          // R[m] = (x[ob-8+m], x[ob-7+m])
+#pragma unroll
+        for (int m = 0; m < 14; m++)
+            R[m] = __builtin_bit_cast(s2, (int32_t)__builtin_amdgcn_perm((uint32_t)W[m + 1], (uint32_t)W[m], 0x05040100u));
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            // taps (1,2) use x[o-2], x[o-1] = R at window index o+6; (3,4): o+4; (5,6): o+2; (7,8): o
+            int32_t acc = __builtin_amdgcn_sdot2(R[o + 6], q0, 0, false);
+            acc = __builtin_amdgcn_sdot2(R[o + 4], q1, acc, false);
+            acc = __builtin_amdgcn_sdot2(R[o + 2], q2, acc, false);
+            acc = __builtin_amdgcn_sdot2(R[o], q3, acc, false);
+            r[ob + o] = (int32_t)((uint32_t)W[8 + o] - (uint32_t)(acc >> shift));
+        }
+    }
+    if (e.i0 < order) {
+#pragma unroll
+        for (int o = 0; o < C; o++)
+            if (e.i0 + o < order) r[o] = mine[Img::off(o)];
+    }
+}
+
 // optimize.c:34-68 encode_residual_fixed on the thread's run.  The reference
 // computes in long long and stores to int32: the low 32 bits, which wrapping
 // 32-bit arithmetic yields directly.
@@ -2696,12 +2763,14 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     // fresh workgroup per subframe balances better and costs no VGPRs).
     const int s = blockIdx.x;
     int32_t xn[C];
-    int32_t first_n, obits_n, fcoef_n = 0, fshift_n = 0, forder_n = 0;
+    int32_t first_n, obits_n, fcoef_n = 0, fshift_n = 0, forder_n = 0, fcabs_n = 0, magbits_n = -1;
     {
         const int32_t *srcp = smp_all + (size_t)s * n;
         // K0 may have stored this row as int16 (info.reserved, honoured only when the
         // launcher says the flag is K0's): half the loads, one sign extension per sample
-        const bool narrow = (C % 8 == 0) && narrow_ok && info[s].reserved != 0;
+        const int nflag = (C % 8 == 0 && narrow_ok) ? info[s].reserved : 0;     // 0, or 1 + bit length of max |x|
+        const bool narrow = nflag != 0;
+        magbits_n = nflag - 1;
         if (C % 8 == 0 && narrow) {
             const int4 *src4 = reinterpret_cast<const int4 *>(reinterpret_cast<const int16_t *>(srcp) + e.i0);
 #pragma unroll
@@ -2733,6 +2802,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
             fcoef_n = f[tid & 31];
             fshift_n = f[32];
             forder_n = f[33];
+            fcabs_n = f[34];
         }
     }
   {
@@ -2884,7 +2954,23 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                     __syncthreads();
                 }
                 STAMP(2);
-                if (pre_row && ord <= 8)
+                bool done = false;
+                if constexpr (C % 8 == 0) {
+                    // 16-bit samples and a prediction that cannot leave int32: packed dot products
+#if defined(FHIP_FORCE_DOT)
+                    if (pre_row && ord <= 8 && magbits_n >= 0) {
+#elif defined(FHIP_NO_DOT)
+                    if (false) {
+#else
+                    if (pre_row && ord <= 8 && magbits_n >= 0 &&
+                        ((unsigned long long)(uint32_t)fcabs_n << magbits_n) < (1ull << 31)) {
+#endif
+                        fir_lpc_dot8<C, T>(e, r, ord, cshift, fin_all + (size_t)s * FIN_STRIDE + FIN_PAIRS);
+                        done = true;
+                    }
+                }
+                if (done) {
+                } else if (pre_row && ord <= 8)
                     fir_lpc_o8<C, T>(e, r, ord, cshift,
                                      reinterpret_cast<const double *>(fin_all + (size_t)s * FIN_STRIDE + FIN_DBL));
                 else

@@ -31,6 +31,8 @@ __global__ void k(double *out, long long *cyc, double seed, int iseed)
                 else if (OP == 4) ia[c] = (int)ia[c] * im + 1;                                // 32-bit mul lo
                 else if (OP == 5) ia[c] = __mul24((int)ia[c], im) + 7;       // mul_i24
                 else if (OP == 6) a[c] = (double)(int)ia[c] + a[c], ia[c] += 1;               // cvt_f64_i32 + add
+                else if (OP == 8) ia[c] = __builtin_amdgcn_sdot2(__builtin_bit_cast(short __attribute__((ext_vector_type(2))), (int)ia[c]), __builtin_bit_cast(short __attribute__((ext_vector_type(2))), im), (int)ia[c], false);   // v_dot2_i32_i16
+                else if (OP == 9) ia[c] = __builtin_amdgcn_sdot4((int)ia[c], im, (int)ia[c], false);            // v_dot4_i32_i8
                 else if (OP == 7) { const double pr = m * (m + (double)(u + c)); a[c] = a[c] + pr; }   // mul + dependent add (autocorr step)
             }
         }
@@ -86,6 +88,9 @@ int main()
     run<2, 8>("fma_f64 8ch full", 1024, 256);
     run<3, 8>("mad_i64_i32 8ch full", 1024, 256);
     run<4, 8>("mul_lo_i32 8ch full", 1024, 256);
+    run<8, 8>("dot2_i32_i16 8ch", 64, 64);
+    run<9, 8>("dot4_i32_i8 8ch", 64, 64);
+    run<8, 8>("dot2_i32_i16 8ch full", 1024, 256);
     // the autocorrelation step: CHAINS x (one multiply + one add into a running sum)
     run<7, 3>("mul+add 3 chains, 1 wave", 1, 64);
     run<7, 3>("mul+add 3ch 1 wave/SIMD, 1 CU", 1, 256);

@@ -968,8 +968,17 @@ void k_autocorr_ps(const int32_t *__restrict__ smp, double *__restrict__ autoc,
 //    buffers: while the consumers walk buffer t%3 and its halo, the producers
 //    fill buffer (t+1)%3 and the halo of buffer (t+2)%3 (the last 32 positions
 //    of a tile are the next tile's halo).  One barrier per tile.
-// Per step a consumer issues 2*NCH fp64 operations and one or two LDS reads, so
-// the walk is bound by fp64 issue: n/2 steps x 2*NCH x ~4.6 cycles.
+// Per step a consumer issues 2*NCH fp64 operations and one or two LDS reads.
+// Measured (tools/ubench_walk.hip, s_memtime = core cycles at ~2.1 GHz): a lone
+// wave issues an fp64 multiply or add every 3.9 cycles, and every double it
+// takes from the LDS costs it another ~8.5 cycles of issue time (17 per
+// ds_read_b128, whatever the prefetch depth: the return path, not the latency) --
+// about as much as a multiply and an add.  The walk of a 3-chain group is
+// therefore 6 x 3.9 + 8.5 = 32 cycles per step in isolation and 41 in the kernel
+// (four consumers and the producers share the LDS), of which the kernel's other
+// phases add 8 us (barriers, K2 tail).  Producers alone need 24 us per launch,
+// consumers alone 41: they overlap to 56.  Two waves per SIMD doing fp64 pull
+// the clock to ~1.3 GHz (power), so more fp64 waves per SIMD would not help.
 // Requires n % AC_TILE == 0 (launch_autocorr falls back otherwise).
 constexpr int WT_SUB = 32;                           // subframes per workgroup
 #ifndef FHIP_WT_ROWS0
@@ -989,13 +998,31 @@ constexpr int WT_STRIDE = 2 * WT_ROW + 2;            // per subframe (166)
 static_assert(WT_ROW % 2 == 0 && WT_STRIDE % 4 == 2, "16-byte aligned arrays, odd slot stride");
 constexpr int WT_BUF = WT_SUB * WT_STRIDE;           // doubles per tile buffer
 constexpr int WT_NBUF = 3;
-constexpr int WT_AHEAD = 3;                          // tiles of loads in flight per producer
+#ifndef FHIP_WT_AHEAD
+#define FHIP_WT_AHEAD 3
+#endif
+constexpr int WT_AHEAD = FHIP_WT_AHEAD;              // tiles of loads in flight per producer
 
 struct wt_groups { int l0[4]; int nch[4]; };
 
 // FUSED: the producers read the interleaved stereo PCM instead of smp, apply the
 // channel mode and wasted-bits shift that the decision pass of K0 left in info[]
 // (encode.c:668-693, :586-590), write smp for K3 and window the same values.
+#ifdef FHIP_PROBE_NOB
+constexpr bool wt_probe_nob = true;         // timing probes only: results are wrong
+#else
+constexpr bool wt_probe_nob = false;
+#endif
+#ifdef FHIP_PROBE_NOPROD
+constexpr bool wt_probe_noprod = true;
+#else
+constexpr bool wt_probe_noprod = false;
+#endif
+#ifdef FHIP_PROBE_NOWALK
+constexpr bool wt_probe_nowalk = true;
+#else
+constexpr bool wt_probe_nowalk = false;
+#endif
 #ifdef FHIP_PROBE_NOHALO
 constexpr bool wt_probe_nohalo = true;      // timing probe only: results are wrong
 #else
@@ -1040,8 +1067,11 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
         // between the producer next to consumer 0 (largest lag group) and the other
         // three is a build constant; measured 2/10/10/10: 60.3 us, 5/9/9/9 and
         // 8/8/8/8: 58.2 -- the walk of consumer 0, not the staging, sets the time.
-        auto produce = [&](auto nrows_c, int q0) {
+        // ALLNAR: every row of this wave is a 16-bit row (the usual case for 16-bit input):
+        // 4-byte loads and no per-row width select
+        auto produce = [&](auto nrows_c, int q0, auto allnar_c) {
             constexpr int NR = decltype(nrows_c)::value;
+            constexpr bool ALLNAR = decltype(allnar_c)::value;
             constexpr int NL = FUSED ? (NR + 1) / 2 : NR;      // loads per tile: one per frame when fused
             // (FUSED needs even row counts: rows come in channel pairs; the launcher checks)
             auto uni64 = [](unsigned long long v) {            // wave-uniform value -> SGPR pair
@@ -1070,18 +1100,32 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
             }
             typedef typename std::conditional<FUSED, int4, int2>::type ld_t;
             ld_t pre[WT_AHEAD][NL];
-            auto issue_loads = [&](ld_t (&dst)[NL], int tb) {
+            // pinned: keep the loads in program order.  The waits in the loop are counted, and a
+            // prologue whose loads the scheduler shuffled makes the compiler merge both ways into
+            // the loop to the smaller count (vmcnt(2) instead of 16: no prefetch left).
+            auto issue_loads = [&](ld_t (&dst)[NL], int tb, bool pinned = false) {
                 const int p = min(tb + 2 * lane, n - 2);       // past the block: clamped, weight 0
 #pragma unroll
                 for (int r = 0; r < NL; r++) {
                     // a narrow row holds the pair (2 lane, 2 lane + 1) in ONE dword, at int index p / 2;
                     // the same 8-byte load serves both widths (the second dword is then unused)
-                    const int idx = FUSED ? 2 * p : (nar[r] ? (p >> 1) : p);
-                    dst[r] = *reinterpret_cast<const ld_t *>(reinterpret_cast<const int32_t *>(rowb[r]) + idx);
+                    const int idx = FUSED ? 2 * p : ((ALLNAR || nar[r]) ? (p >> 1) : p);
+                    // address space 1 spelled out: from an integer the pointer would be generic, the
+                    // loads flat_load, and every wait on them vmcnt(0) lgkmcnt(0) -- no prefetch left
+                    typedef const int32_t __attribute__((address_space(1))) *g_i32;
+                    typedef int ldv_t __attribute__((ext_vector_type(FUSED ? 4 : 2)));
+                    typedef const ldv_t __attribute__((address_space(1))) *g_ld;
+                    if constexpr (ALLNAR) {
+                        dst[r].x = *((g_i32)rowb[r] + idx);
+                    } else {
+                        const ldv_t v = *(g_ld)((g_i32)rowb[r] + idx);
+                        __builtin_memcpy(&dst[r], &v, sizeof(ld_t));
+                    }
+                    if (pinned) __builtin_amdgcn_sched_barrier(0);
                 }
             };
 #pragma unroll
-            for (int a = 0; a < WT_AHEAD; a++) issue_loads(pre[a], a * AC_TILE);
+            for (int a = 0; a < WT_AHEAD; a++) issue_loads(pre[a], a * AC_TILE, true);
             // the halo of the first tile is zeros (positions -32 .. -1)
             for (int idx = lane; idx < NR * 2 * PS_HH; idx += WAVE) {
                 const int r = idx / (2 * PS_HH), k = idx - r * 2 * PS_HH;
@@ -1107,8 +1151,11 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                     const double w0 = weight(tb + 2 * lane), w1 = weight(tb + 2 * lane + 1);
                     const bool tail = lane >= PS_HALF - PS_HH;        // positions 96..127
                     const int pst = min(tb + 2 * lane, n - 2);        // padding tiles rewrite the last pair
+                    // all rows in one basic block (the scheduler interleaves their dependent
+                    // chains: a producer is alone with its latencies), the halo copies after it
+                    double hv0[NR], hv1[NR];
 #pragma unroll
-                    for (int r = 0; r < NR; r++) {
+                    for (int r = 0; r < (wt_probe_noprod ? 0 : NR); r++) {
                         int32_t x0, x1;                               // samples 2*lane, 2*lane+1 of row r
                         if (FUSED) {
                             const int4 v = *reinterpret_cast<const int4 *>(&pre[a][r / 2]);   // l0 r0 l1 r1
@@ -1130,17 +1177,27 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                             *reinterpret_cast<int2 *>(reinterpret_cast<int32_t *>(outb[r]) + pst) = make_int2(x0, x1);
                         } else {
                             const int2 v = *reinterpret_cast<const int2 *>(&pre[a][r]);
-                            const bool nr = nar[FUSED ? 0 : r] != 0;        // wave-uniform
+                            const bool nr = ALLNAR || nar[FUSED ? 0 : r] != 0;        // wave-uniform
                             x0 = nr ? (int32_t)(int16_t)v.x : v.x;
                             x1 = nr ? (v.x >> 16) : v.y;
                         }
                         const double v0 = (double)x0 * w0;
                         const double v1 = (double)x1 * w1;
+#ifdef FHIP_PROBE_NOLDSW
+                        if (r == 0) { hv0[0] = 0; hv1[0] = 0; }
+                        hv0[0] += v0; hv1[0] += v1;
+                        if (r == NR - 1) { bw[0] = hv0[0]; bw[WT_ROW] = hv1[0]; }
+#else
                         bw[r * WT_STRIDE] = v0;
                         bw[r * WT_STRIDE + WT_ROW] = v1;
-                        if (tail && !wt_probe_nohalo) {                // = positions -32..-1 of the next tile
-                            bn[r * WT_STRIDE] = v0;
-                            bn[r * WT_STRIDE + WT_ROW] = v1;
+                        hv0[r] = v0; hv1[r] = v1;
+#endif
+                    }
+                    if (tail && !wt_probe_nohalo && !wt_probe_noprod) {   // = positions -32..-1 of the next tile
+#pragma unroll
+                        for (int r = 0; r < NR; r++) {
+                            bn[r * WT_STRIDE] = hv0[r];
+                            bn[r * WT_STRIDE + WT_ROW] = hv1[r];
                         }
                     }
                     TICK(tp1);
@@ -1156,8 +1213,18 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                 }
             }
         };
-        if (wv == 4) produce(std::integral_constant<int, WT_ROWS0>{}, 0);
-        else produce(std::integral_constant<int, WT_ROWS1>{}, WT_ROWS0 + (wv - 5) * WT_ROWS1);
+        const int q0w = (wv == 4) ? 0 : WT_ROWS0 + (wv - 5) * WT_ROWS1;
+        const int nrw = (wv == 4) ? WT_ROWS0 : WT_ROWS1;
+        bool alln = !FUSED && narrow_ok != 0;
+        for (int r = 0; alln && r < nrw; r++) alln = info[min(sub0 + q0w + r, nsub - 1)].reserved != 0;
+        alln = __builtin_amdgcn_readfirstlane((int)alln) != 0;
+        if (wv == 4) {
+            if (alln) produce(std::integral_constant<int, WT_ROWS0>{}, q0w, std::true_type{});
+            else produce(std::integral_constant<int, WT_ROWS0>{}, q0w, std::false_type{});
+        } else {
+            if (alln) produce(std::integral_constant<int, WT_ROWS1>{}, q0w, std::true_type{});
+            else produce(std::integral_constant<int, WT_ROWS1>{}, q0w, std::false_type{});
+        }
         if (LPCMO > 0) __syncthreads();                    // the tail's barrier (below)
         return;
     }
@@ -1204,12 +1271,12 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                 const dbl2 v = rowA[(stage * PS_CH + u) / 2];
                 A[set][u] = v.x; A[set][u + 1] = v.y;
             }
-            if (!SAME) {
+            if (!SAME && !wt_probe_nob) {
 #pragma unroll
                 for (int u = 0; u < PS_CH; u++) B[set][u] = rowB[stage * PS_CH + u];
             }
         };
-        constexpr int PER_STAGE = PS_CH / 2 + (SAME ? 0 : PS_CH);     // LDS reads per stage
+        constexpr int PER_STAGE = PS_CH / 2 + ((SAME || wt_probe_nob) ? 0 : PS_CH);     // LDS reads per stage
 #pragma unroll
         for (int k = 0; k < DEPTH; k++) fetch(k, k);
 #pragma unroll
@@ -1231,7 +1298,7 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < PS_CH; u++) {
-                const double x = SAME ? A[st % NSET][u] : B[st % NSET][u];
+                const double x = (SAME || wt_probe_nob) ? A[st % NSET][u] : B[st % NSET][u];
                 double a = A[st % NSET][u];
                 if (FIRST && 2 * (st * PS_CH + u) <= FHIP_MAX_ORDER)            // steps that can hold p <= maxlag
                     a = (2 * (st * PS_CH + u) + pi > maxlag) ? a : 0.0;
@@ -1256,7 +1323,7 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
         __syncthreads();                                   // tile t is in buffer bi
         TICK(tc1);
         ACCUM(40, tc0, tc1);
-        if (t >= ntiles) continue;                         // padding of the producers' unroll
+        if (t >= ntiles || wt_probe_nowalk) continue;      // padding of the producers' unroll
         const double *buf = wt_lds + bi * WT_BUF;
         if (t == 0 && pi == pih) {
             // head (lpc.c:60-61): positions lag..maxlag of BOTH parities, in order,
@@ -2957,14 +3024,8 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                 bool done = false;
                 if constexpr (C % 8 == 0) {
                     // 16-bit samples and a prediction that cannot leave int32: packed dot products
-#if defined(FHIP_FORCE_DOT)
-                    if (pre_row && ord <= 8 && magbits_n >= 0) {
-#elif defined(FHIP_NO_DOT)
-                    if (false) {
-#else
                     if (pre_row && ord <= 8 && magbits_n >= 0 &&
                         ((unsigned long long)(uint32_t)fcabs_n << magbits_n) < (1ull << 31)) {
-#endif
                         fir_lpc_dot8<C, T>(e, r, ord, cshift, fin_all + (size_t)s * FIN_STRIDE + FIN_PAIRS);
                         done = true;
                     }

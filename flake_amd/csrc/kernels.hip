@@ -2754,6 +2754,201 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
     return bits;
 }
 
+// optimize.c:170-181 for the fixed predictors: the size estimates of all orders
+// min_order..max_order (<= 4) from ONE pass over the samples.  The residual of order
+// k+1 is the first difference of the residual of order k (optimize.c:34-68 written
+// out), so a thread forms all five from its run and four samples of history, folds
+// them (rice.c:122) and keeps five sums; one in-wave pyramid, one node pass and one
+// level selection then serve all orders (five separate searches cost five times the
+// barriers and LDS traffic).  Returns the order the reference picks (first strict
+// minimum from min_order upward) together with its Rice result: the caller only has
+// to form that order's residuals once more.  Needs pmax_req <= 5 (64 heap nodes per
+// order).  LDS use: l.sums[k * 64 + node], wave totals l.sums[320 + k * 16 + wave],
+// level bits l.kpar[k * 9 + p], RICE2 flags l.kpar[48 + k], parameters of every
+// node l.kpar[64 + k * 64 + node] (the winner's move to l.kpar[node] at the end).
+template <int C, int T>
+__device__ __forceinline__ int fixed_search5(const FastCtx<C, T> &e, int min_order, int max_order,
+                                             uint32_t *bits_out, int *porder_out, int *method_out)
+{
+    using Img = SmpImg<C, T>;
+    constexpr int LT = clog2(T);
+    constexpr int NW = T / WAVE;
+    const FastLds &l = e.l;
+    const int n = e.n, tid = e.tid, lane = e.lane;
+    const int32_t *mine = l.smp + tid * Img::CS;
+
+    uint32_t xs[C], h[4];
+    if constexpr (Img::V4) {
+        const int4 p = *reinterpret_cast<const int4 *>(mine + Img::off(-4));      // samples -4 .. -1
+        h[0] = (uint32_t)p.w; h[1] = (uint32_t)p.z; h[2] = (uint32_t)p.y; h[3] = (uint32_t)p.x;
+#pragma unroll
+        for (int o = 0; o < C; o += 4) {
+            const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(o));
+            xs[o] = (uint32_t)v.x; xs[o + 1] = (uint32_t)v.y; xs[o + 2] = (uint32_t)v.z; xs[o + 3] = (uint32_t)v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) h[k] = (uint32_t)mine[Img::off(-1 - k)];
+#pragma unroll
+        for (int o = 0; o < C; o++) xs[o] = (uint32_t)mine[Img::off(o)];
+    }
+    // differences of orders 1..3 at the sample in front of the run
+    uint32_t p1 = h[0] - h[1];
+    uint32_t p2 = h[0] - 2u * h[1] + h[2];
+    uint32_t p3 = h[0] - 3u * h[1] + 3u * h[2] - h[3];
+    uint32_t p0 = h[0];
+
+    // folded sums per order; a folded value is below 2^(obits+4)
+    const bool sum32 = e.obits + 4 + clog2(C) <= 32;
+    unsigned long long v[5];
+    uint32_t a32[5] = {0, 0, 0, 0, 0};
+    unsigned long long a64[5] = {0, 0, 0, 0, 0};
+    const bool head = e.i0 < 4;                      // this run holds warm-up samples of some order
+#pragma unroll
+    for (int o = 0; o < C; o++) {
+        const uint32_t d0 = xs[o];
+        const uint32_t d1 = d0 - p0;
+        const uint32_t d2 = d1 - p1;
+        const uint32_t d3 = d2 - p2;
+        const uint32_t d4 = d3 - p3;
+        p0 = d0; p1 = d1; p2 = d2; p3 = d3;
+        uint32_t z[5] = {zigzag32((int32_t)d0), zigzag32((int32_t)d1), zigzag32((int32_t)d2),
+                         zigzag32((int32_t)d3), zigzag32((int32_t)d4)};
+        if (head) {
+#pragma unroll
+            for (int k = 1; k < 5; k++)
+                if (e.i0 + o < k) z[k] = 0u;         // rice.c:85-94: partition 0 starts at `order`
+        }
+        if (sum32) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) a32[k] += z[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; k++) a64[k] += z[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = sum32 ? (unsigned long long)a32[k] : a64[k];
+
+    // partition-order window over all orders: order 0 has the loosest clamp, the
+    // highest order the tightest (rice.c:148-155)
+    const int pmin_lo = clamp_porder(e.pmin_req, n, max_order);
+    const int pmax_hi = clamp_porder(e.pmax_req, n, min_order);
+
+    if (tid < 64) l.kpar[tid] = 0;                   // level bits and RICE2 flags
+#define PYR5_STORE(S_)                                                                      \
+    do {                                                                                    \
+        const int lev_ = LT - (S_);                                                         \
+        if (lev_ <= pmax_hi && lev_ >= pmin_lo && (lane & ((1 << (S_)) - 1)) == 0) {        \
+            _Pragma("unroll") for (int k = 0; k < 5; k++)                                   \
+                l.sums[k * 64 + (1 << lev_) - 1 + (tid >> (S_))] = v[k];                    \
+        }                                                                                   \
+    } while (0)
+    // a wave's total is below 2^(obits + 4 + log2(64 C)): in 32 bits one DPP add per step
+    const bool wave32 = e.obits + 4 + clog2(C) + 6 <= 32;
+    if (wave32) {
+        uint32_t w[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) w[k] = (uint32_t)v[k];
+#define PYR5_STEP32(S_, CTRL_)                                                              \
+    do {                                                                                    \
+        PYR5_STORE(S_);                                                                     \
+        _Pragma("unroll") for (int k = 0; k < 5; k++) { w[k] += dpp_u32<CTRL_>(w[k]); v[k] = w[k]; } \
+    } while (0)
+        PYR5_STEP32(0, 0x101);
+        PYR5_STEP32(1, 0x102);
+        PYR5_STEP32(2, 0x104);
+        PYR5_STEP32(3, 0x108);
+#undef PYR5_STEP32
+        PYR5_STORE(4);
+#pragma unroll
+        for (int k = 0; k < 5; k++) { w[k] += (uint32_t)__shfl_down((int)w[k], 16, WAVE); v[k] = w[k]; }
+        PYR5_STORE(5);
+#pragma unroll
+        for (int k = 0; k < 5; k++) { w[k] += (uint32_t)__shfl_down((int)w[k], 32, WAVE); v[k] = w[k]; }
+        PYR5_STORE(6);
+    } else {
+        PYR5_STORE(0);
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] += row_shl_u64<1>(v[k]);
+        PYR5_STORE(1);
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] += row_shl_u64<2>(v[k]);
+        PYR5_STORE(2);
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] += row_shl_u64<4>(v[k]);
+        PYR5_STORE(3);
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] += row_shl_u64<8>(v[k]);
+        PYR5_STORE(4);
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] += __shfl_down(v[k], 16, WAVE);
+        PYR5_STORE(5);
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] += __shfl_down(v[k], 32, WAVE);
+        PYR5_STORE(6);
+    }
+#undef PYR5_STORE
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) l.sums[320 + k * 16 + e.wv] = v[k];
+    }
+    __syncthreads();
+
+    {
+        // one thread per (order, level, partition) node
+        const int first = (1 << pmin_lo) - 1, last = (2 << pmax_hi) - 2;
+        const int nn = last - first + 1;
+        for (int it = tid; it < 5 * nn; it += T) {
+            const int k = it / nn;
+            const int q = first + (it - k * nn);
+            const int p = ilog2_dev((uint32_t)(q + 1));
+            const int jn = q + 1 - (1 << p);
+            const int cnt = (n >> p) - (jn == 0 ? k : 0);
+            unsigned long long sum;
+            if (p <= LT - 7) {
+                const int span = NW >> p;              // waves per node
+                sum = 0;
+                for (int w = 0; w < span; w++) sum += l.sums[320 + k * 16 + jn * span + w];
+            } else {
+                sum = l.sums[k * 64 + q];
+            }
+            uint32_t b;
+            const int kk = rice_k_fast(sum, cnt, &b);
+            l.kpar[64 + k * 64 + q] = kk;
+            atomicAdd(reinterpret_cast<uint32_t *>(&l.kpar[k * 9 + p]), b);
+            if (kk > 14) atomicOr(reinterpret_cast<uint32_t *>(&l.kpar[48 + k]), 1u << p);
+        }
+    }
+    __syncthreads();
+
+    // rice.c:127-138 and :157-171 per order, optimize.c:171-180 across them;
+    // evaluated by every thread from workgroup-uniform LDS words
+    int best = min_order, best_p = 0, best_m = 0;
+    uint32_t best_bits = 0;
+    for (int k = min_order; k <= max_order; k++) {
+        const int pmin = clamp_porder(e.pmin_req, n, k);
+        const int pmax = clamp_porder(e.pmax_req, n, k);
+        const uint32_t lmask = (uint32_t)__builtin_amdgcn_readfirstlane(l.kpar[48 + k]);
+        uint32_t lb = 0, method = 0;
+        int bp = pmin;
+        for (int p = pmin; p <= pmax; p++) {
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(l.kpar[k * 9 + p]) + 4u * (1u << p);
+            if (p == pmin || b <= lb) { lb = b; bp = p; method = (lmask >> p) & 1u; }
+        }
+        const uint32_t bits = (uint32_t)(k * e.obits + 2) + lb + method + 4u;
+        if (k == min_order || bits < best_bits) { best_bits = bits; best = k; best_p = bp; best_m = (int)method; }
+    }
+    // the winner's parameters to where the emit and the info record read them
+    __syncthreads();                                 // level words (l.kpar[0..52]) fully read
+    if (tid < 64) l.kpar[tid] = l.kpar[64 + best * 64 + tid];
+    __syncthreads();
+    *bits_out = best_bits;
+    *porder_out = best_p;
+    *method_out = best_m;
+    return best;
+}
+
 // OR `len` (<= 31) bits of val into the MSB-first bit string at bit `pos` of a
 // zeroed LDS window, 32-bit arithmetic only; words outside [0, nw) are skipped.
 __device__ __forceinline__ void put_bits32(uint32_t *win, int nw, long long pos, int len, uint32_t val)
@@ -2949,6 +3144,14 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     // state costs a wave of occupancy and the kernel ends up 15 % slower.)
 
     if (tree == T_FIXED) { it = min_order; best = min_order; }
+    bool five_wide = false;
+    if constexpr (MODE == 1) {
+        // all fixed orders from one pass; the winner is then encoded like a single candidate
+        if (tree == T_FIXED && max_order > min_order && max_order <= 4 && min_order >= 0 &&
+            P.max_partition_order <= 5) {
+            five_wide = true;
+        }
+    }
     if (HAS_LPC && tree == T_LPC) {
         if (omethod <= 1) { best = forder - 1; final_pass = true; }     // MAX: max_order, EST: est
         else if (omethod <= 4) { it = (1 << ((omethod - 1) & 7)) - 1; best = max_order - 1; }
@@ -2965,7 +3168,14 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
         type = type_code = (tree == T_CONST) ? FHIP_SUB_CONSTANT : FHIP_SUB_VERBATIM;
         est_bits = (uint32_t)(tree == T_CONST ? e.obits : e.obits * n);
     } else {
-        for (;;) {
+        if constexpr (MODE == 1) {
+            if (five_wide) {
+                best = fixed_search5<C, T>(e, min_order, max_order, &est_bits, &porder, &method);
+                fir_fixed<C, T>(e, r, best);
+                fold_residuals<C, T>(e, r, u, best);
+            }
+        }
+        if (!five_wide) for (;;) {
             int cand = -1;
             if (!final_pass) {
                 if (tree == T_FIXED) {

@@ -436,3 +436,22 @@ def test_narrow_sample_rows(oracle, n):
     assert_residual_equal(got["residual"], exp["residual"], exp["info"], f"narrow24 n{n}")
     assert_bits_equal(got["rice_bits"], exp["rice_bits"], exp["info"], f"narrow24 n{n}")
     assert (exp["info"]["wasted"][4:] >= 8).all()
+
+
+@pytest.mark.parametrize("n", [192, 512, 1152, 2048, 4096, 4608])
+@pytest.mark.parametrize("orders", [(0, 4), (1, 3), (2, 4), (0, 1), (3, 4), (2, 2)])
+def test_fixed_order_and_partition_ranges(oracle, n, orders):
+    """optimize.c:170-188 on the one-pass search over all fixed orders (and on the
+    candidate loop it replaces when the partition orders go past 5): every order
+    window, partition windows that clamp differently per order, edge signals whose
+    warm-up samples dominate the first partition."""
+    edges = edge_blocks(n, 16)
+    mono = np.stack([edges[k] for k in sorted(edges)])[:, :, None]
+    for (pmin, pmax) in ((0, 0), (0, 3), (2, 5), (5, 5), (0, 8)):
+        kw = dict(prediction_type=flake_amd.PRED_FIXED, min_prediction_order=orders[0],
+                  max_prediction_order=orders[1], min_partition_order=pmin, max_partition_order=pmax)
+        p = flake_amd.level_params(5, channels=1, bits_per_sample=16, block_size=n, **kw)
+        check(oracle, p, mono, n, f"fixed_mono_n{n}_{orders}_{pmin}-{pmax}")
+        p = flake_amd.level_params(5, channels=2, bits_per_sample=24, block_size=n, **kw)
+        pcm = flake_amd.synth_pcm(3, n, 2, 24, first_frame=7)
+        check(oracle, p, pcm, n, f"fixed_stereo24_n{n}_{orders}_{pmin}-{pmax}")

@@ -18,8 +18,10 @@ PKG = os.path.join(ROOT, "flake_amd")
 LIB = os.path.join(PKG, "lib")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HIP_SRCS = ["csrc/kernels.hip", "csrc/api.hip"]
-HIP_DEPS = HIP_SRCS + ["csrc/kernels.h", "../include/flakehip.h"]
+HIP_SRCS = ["csrc/k0_prepare.hip", "csrc/k1_autocorr.hip", "csrc/k2_lpc.hip", "csrc/k3_encode.hip",
+            "csrc/k4_assemble.hip", "csrc/api.hip"]
+HIP_HDRS = ["csrc/kernels.h", "csrc/device_util.h", "csrc/lpc_reg.h", "../include/flakehip.h"]
+HIP_DEPS = HIP_SRCS + HIP_HDRS
 HOST_SRCS = ["host/flake_host.c", "host/synth.c", "host/md5.c"]
 HOST_DEPS = HOST_SRCS + ["../include/flakehip.h", "../include/flake_amd.h"]
 
@@ -43,13 +45,30 @@ def _run(cmd: list[str]) -> None:
     subprocess.run(cmd, check=True)
 
 
-def build_hip(force: bool = False, extra: list[str] | None = None) -> str:
-    out = os.path.join(LIB, "libflakehip.so")
+def build_hip(force: bool = False, extra: list[str] | None = None, out_name: str = "libflakehip.so") -> str:
+    """One object per kernel file, compiled side by side, then one link."""
+    out = os.path.join(LIB, out_name)
     if force or _stale(out, HIP_DEPS):
         os.makedirs(LIB, exist_ok=True)
-        _run([HIPCC, *HIP_FLAGS, *(extra or []), "-I", os.path.join(ROOT, "include"),
-              "-I", os.path.join(PKG, "csrc"),
-              *[os.path.join(PKG, s) for s in HIP_SRCS], "-o", out])
+        objdir = os.path.join(PKG, "build", os.path.splitext(out_name)[0])
+        os.makedirs(objdir, exist_ok=True)
+        cflags = [f for f in HIP_FLAGS if f != "-shared"]
+        hdr_t = max(os.path.getmtime(os.path.join(PKG, h)) for h in HIP_HDRS)
+        jobs = []
+        for s in HIP_SRCS:
+            src = os.path.join(PKG, s)
+            obj = os.path.join(objdir, os.path.basename(s) + ".o")
+            if (force or extra or not os.path.exists(obj)
+                    or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t)):
+                cmd = [HIPCC, *cflags, *(extra or []), "-I", os.path.join(ROOT, "include"),
+                       "-I", os.path.join(PKG, "csrc"), "-c", src, "-o", obj]
+                print("+", " ".join(cmd), flush=True)
+                jobs.append((cmd, subprocess.Popen(cmd)))
+        for cmd, proc in jobs:
+            if proc.wait() != 0:
+                raise subprocess.CalledProcessError(proc.returncode, cmd)
+        objs = [os.path.join(objdir, os.path.basename(s) + ".o") for s in HIP_SRCS]
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
     return out
 
 

@@ -1,0 +1,175 @@
+// device_util.h -- what every kernel file of libflakehip.so shares: the phase-stamp
+// macros of the diagnostic build, workgroup constants and the small wave-level
+// device helpers (folds, Rice counts, DPP scans).  Internal; included by the
+// k*.hip files only.  Compile everything with -ffp-contract=off (see k1_autocorr.hip).
+#pragma once
+
+#include "kernels.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+#ifdef FHIP_STAMPS
+// Diagnostic build only (tools/stamps.py): phase time stamps of workgroup 0.
+static __device__ long long g_fhip_stamps[64];   // one per kernel file; api.hip merges them
+#define STAMP(i)                                                                       \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                     \
+            unsigned long long t_;                                                     \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
+            g_fhip_stamps[i] = (long long)t_;                                          \
+        }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    } while (0)
+// every stamped kernel file has its own array; it exports a reader under its own name
+#define FHIP_DEFINE_STAMP_READER(fn_)                                                  \
+    extern "C" __attribute__((visibility("default"))) int fn_(long long *out)          \
+    {                                                                                  \
+        return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fhip_stamps), sizeof(long long) * 64); \
+    }
+// accumulating timers (tools/stamps_k1.py): TICK reads the clock, ACCUM adds an
+// interval to slot i for the first wave pair of workgroup 0
+#define TICK(v_)                                                                       \
+    unsigned long long v_;                                                             \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v_)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    } while (0)
+#define ACCUM(i, a_, b_)                                                               \
+    do {                                                                               \
+        if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) g_fhip_stamps[i] += (long long)((b_) - (a_)); \
+    } while (0)
+#define ACC_RESET(lo, hi)                                                              \
+    do {                                                                               \
+        if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) for (int z_ = lo; z_ < hi; z_++) g_fhip_stamps[z_] = 0; \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#define TICK(v_) do { } while (0)
+#define ACCUM(i, a_, b_) do { } while (0)
+#define ACC_RESET(lo, hi) do { } while (0)
+#endif
+
+namespace fhip {
+namespace {
+
+constexpr int NT = 256;        // threads per workgroup (4 waves)
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t zigzag32(int32_t x)
+{
+    // rice.c:122 (search side) and bitio.h:128-129 (emit side): same map
+    return ((uint32_t)x << 1) ^ (uint32_t)(x >> 31);
+}
+
+// bitio.h:128-129, the emit-side fold (v = -2*val-1; v ^= v>>31 in int):
+// equal to zigzag32 only for |x| < 2^30, so the emit uses this one.
+__device__ __forceinline__ uint32_t emit_fold32(int32_t x)
+{
+    int32_t v = (int32_t)(0u - 2u * (uint32_t)x - 1u);
+    v ^= (v >> 31);
+    return (uint32_t)v;
+}
+
+__device__ __forceinline__ int32_t wrap_abs(int32_t a)
+{
+    return a < 0 ? (int32_t)(0u - (uint32_t)a) : a;
+}
+
+// rice.h:48 rice_encode_count evaluated in uint64 like the C macro:
+// n*(k+1) is an int, sum-(n>>1) wraps, the shift is logical.
+__device__ __forceinline__ uint64_t rice_count64(uint64_t sum, int n, int k)
+{
+    return (uint64_t)(int64_t)(n * (k + 1)) + ((sum - (uint64_t)(int64_t)(n >> 1)) >> k);
+}
+
+// rice.c:30-45 find_optimal_rice_param: first strict minimum over k=0..30 of
+// the count truncated to uint32.
+__device__ __forceinline__ int rice_best_k(uint64_t sum, int n, uint32_t *bits_out)
+{
+    const uint64_t s = sum - (uint64_t)(int64_t)(n >> 1);
+    uint32_t best = (uint32_t)((uint64_t)(int64_t)n + s);
+    int kb = 0;
+#pragma unroll 1
+    for (int k = 1; k <= 30; k++) {
+        uint32_t b = (uint32_t)((uint64_t)(int64_t)(n * (k + 1)) + (s >> k));
+        if (b < best) { best = b; kb = k; }
+    }
+    *bits_out = best;
+    return kb;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;   // valid in lane 0
+}
+
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= (uint32_t)__shfl_down((int)v, off, WAVE);
+    return v;   // valid in lane 0
+}
+
+// inclusive scan of a u64 across the wave
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        unsigned long long t = __shfl_up(v, off, WAVE);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// DPP controls (gfx9): row_shl:n = 0x100+n, row_shr:n = 0x110+n,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+    // lanes without a valid source (or outside ROW_MASK) receive 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+}
+
+// wave64 inclusive scan of a u32: 4 in-row steps + 2 row broadcasts, no LDS
+__device__ __forceinline__ uint32_t wave_incl_scan_u32_dpp(uint32_t x)
+{
+    x += dpp_u32<0x111>(x);
+    x += dpp_u32<0x112>(x);
+    x += dpp_u32<0x114>(x);
+    x += dpp_u32<0x118>(x);
+    x += dpp_u32<0x142, 0xA>(x);
+    x += dpp_u32<0x143, 0xC>(x);
+    return x;
+}
+
+// lane i receives lane i+D of the same 16-lane row (0 past the row end)
+template <int D>
+__device__ __forceinline__ unsigned long long row_shl_u64(unsigned long long v)
+{
+    const uint32_t lo = dpp_u32<0x100 + D>((uint32_t)v);
+    const uint32_t hi = dpp_u32<0x100 + D>((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// x86-64 cvttsd2si semantics for (int)double: out-of-range and NaN give
+// INT_MIN (the reference's `q = error + 0.5`, lpc.c:211).
+__device__ __forceinline__ int c_double_to_int(double x)
+{
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return (int)0x80000000;
+    return (int)x;
+}
+
+// floor(log2 v), 0 for v = 0 (the reference's log2i)
+__device__ __forceinline__ int ilog2_dev(uint32_t v) { return v ? 31 - __clz((int)v) : 0; }
+
+}  // namespace
+}  // namespace fhip

@@ -1,0 +1,429 @@
+// k0_prepare.hip -- K0: copy_samples + stereo estimate / decorrelation + wasted bits
+// (encode.c:541-694).  pcm [nframes][n][ch] -> smp [nframes][ch][n].
+#include "device_util.h"
+
+namespace fhip {
+namespace {
+
+// ---------------------------------------------------------------------------
+// K0  k_prepare
+// ---------------------------------------------------------------------------
+// Stereo frames that do not qualify for the register path (n > 8192 or n % 4):
+// one workgroup per frame, both channels resident in LDS (int32[2n]).  Other
+// channel counts go to k_prepare_multi.
+__global__ __launch_bounds__(NT)
+void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
+               fhip_subframe_info *__restrict__ info, int n, int nch, int bps, int estimate)
+{
+    extern __shared__ int32_t lds_i32[];
+    __shared__ unsigned long long s_sum[4][4];
+    __shared__ uint32_t s_or[4][2];
+    __shared__ int s_mode;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    if (nch == 2) {
+        const int f = blockIdx.x;
+        const int32_t *src = pcm + (size_t)f * n * 2;
+        int32_t *L = lds_i32, *R = lds_i32 + n;
+        const int2 *src2 = reinterpret_cast<const int2 *>(src);
+        for (int i = tid; i < n; i += NT) {
+            int2 v = src2[i];
+            L[i] = v.x;
+            R[i] = v.y;
+        }
+        __syncthreads();
+
+        int mode = FHIP_CH_LEFT_RIGHT;
+        if (estimate && n > 32) {
+            // encode.c:598-643 calc_decorr_scores
+            unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (int i = tid + 2; i < n; i += NT) {
+                int32_t lt = (int32_t)((uint32_t)L[i] - 2u * (uint32_t)L[i - 1] + (uint32_t)L[i - 2]);
+                int32_t rt = (int32_t)((uint32_t)R[i] - 2u * (uint32_t)R[i - 1] + (uint32_t)R[i - 2]);
+                int32_t m = (int32_t)((uint32_t)lt + (uint32_t)rt) >> 1;
+                int32_t s = (int32_t)((uint32_t)lt - (uint32_t)rt);
+                a0 += (unsigned long long)(long long)wrap_abs(lt);
+                a1 += (unsigned long long)(long long)wrap_abs(rt);
+                a2 += (unsigned long long)(long long)wrap_abs(m);
+                a3 += (unsigned long long)(long long)wrap_abs(s);
+            }
+            a0 = wave_sum_u64(a0); a1 = wave_sum_u64(a1);
+            a2 = wave_sum_u64(a2); a3 = wave_sum_u64(a3);
+            if (lane == 0) { s_sum[wv][0] = a0; s_sum[wv][1] = a1; s_sum[wv][2] = a2; s_sum[wv][3] = a3; }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long cost[4];
+                for (int q = 0; q < 4; q++) {
+                    unsigned long long sm = s_sum[0][q] + s_sum[1][q] + s_sum[2][q] + s_sum[3][q];
+                    uint32_t dummy;
+                    int k = rice_best_k(2 * sm, n, &dummy);
+                    cost[q] = rice_count64(2 * sm, n, k);     // no 32-bit truncation here (encode.c:620)
+                }
+                unsigned long long sc[4] = {cost[0] + cost[1], cost[0] + cost[3],
+                                            cost[1] + cost[3], cost[2] + cost[3]};
+                int best = 0;
+                for (int q = 1; q < 4; q++) if (sc[q] < sc[best]) best = q;
+                const int modes[4] = {FHIP_CH_LEFT_RIGHT, FHIP_CH_LEFT_SIDE,
+                                      FHIP_CH_RIGHT_SIDE, FHIP_CH_MID_SIDE};
+                s_mode = modes[best];
+            }
+            __syncthreads();
+            mode = s_mode;
+        }
+
+        // encode.c:668-693 apply, then OR of every sample per channel
+        uint32_t or0 = 0, or1 = 0;
+        for (int i = tid; i < n; i += NT) {
+            int32_t a = L[i], b = R[i];
+            if (mode == FHIP_CH_MID_SIDE) {
+                int32_t mid = (int32_t)((uint32_t)a + (uint32_t)b) >> 1;
+                int32_t sd = (int32_t)((uint32_t)a - (uint32_t)b);
+                a = mid; b = sd;
+            } else if (mode == FHIP_CH_LEFT_SIDE) {
+                b = (int32_t)((uint32_t)a - (uint32_t)b);
+            } else if (mode == FHIP_CH_RIGHT_SIDE) {
+                a = (int32_t)((uint32_t)a - (uint32_t)b);
+            }
+            L[i] = a; R[i] = b;
+            or0 |= (uint32_t)a; or1 |= (uint32_t)b;
+        }
+        or0 = wave_or_u32(or0); or1 = wave_or_u32(or1);
+        if (lane == 0) { s_or[wv][0] = or0; s_or[wv][1] = or1; }
+        __syncthreads();
+
+        int wasted[2], obits[2];
+        for (int c = 0; c < 2; c++) {
+            // encode.c:558-593: min(bps-1, trailing zeros over non-zero samples);
+            // bps-1 (also the all-zero case) is reset to 0
+            uint32_t o = s_or[0][c] | s_or[1][c] | s_or[2][c] | s_or[3][c];
+            int w = o ? min(__ffs((int)o) - 1, bps - 1) : bps - 1;
+            if (w == bps - 1) w = 0;
+            wasted[c] = w;
+            obits[c] = bps - w;
+        }
+        if (mode == FHIP_CH_MID_SIDE || mode == FHIP_CH_LEFT_SIDE) obits[1]++;
+        if (mode == FHIP_CH_RIGHT_SIDE) obits[0]++;
+
+        int32_t *dst = smp + (size_t)f * 2 * n;
+        for (int i = tid; i < n; i += NT) {
+            dst[i] = L[i] >> wasted[0];
+            dst[n + i] = R[i] >> wasted[1];
+        }
+        if (tid < 2) {
+            fhip_subframe_info *o = &info[(size_t)f * 2 + tid];
+            o->obits = obits[tid];
+            o->wasted = wasted[tid];
+            o->ch_mode = mode;
+        }
+    }
+}
+
+// K0 for 1 or 3..8 channels (no decorrelation, encode.c:660-663): one
+// workgroup per frame walks it in tiles of 256 sample-frames.  A tile is read
+// with coalesced dword loads, transposed through a padded LDS tile, and each
+// thread then owns one sample-frame with all its channels in registers.  Pass 1
+// ORs every sample per channel (wasted bits, encode.c:558-593), pass 2 re-reads
+// (L2), shifts and writes channel rows coalesced.
+__global__ __launch_bounds__(NT)
+void k_prepare_multi(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
+                     fhip_subframe_info *__restrict__ info, int n, int nch, int bps)
+{
+    __shared__ int32_t s_tile[NT * (FHIP_MAX_CH + 1)];
+    __shared__ uint32_t s_orr[4][FHIP_MAX_CH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = blockIdx.x;
+    const int32_t *src = pcm + (size_t)f * n * nch;
+    const int stride = nch + 1;
+    const int total = n * nch;
+
+    uint32_t orv[FHIP_MAX_CH];
+#pragma unroll
+    for (int c = 0; c < FHIP_MAX_CH; c++) orv[c] = 0;
+    int wasted[FHIP_MAX_CH];
+
+    for (int pass = 0; pass < 2; pass++) {
+        for (int t0 = 0; t0 < n; t0 += NT) {
+            const int base = t0 * nch;
+            __syncthreads();
+            for (int j = 0; j < nch; j++) {
+                const int e = base + j * NT + tid;               // linear element of the tile
+                const int le = j * NT + tid;
+                const int32_t v = src[min(e, total - 1)];
+                s_tile[(le / nch) * stride + (le % nch)] = v;
+            }
+            __syncthreads();
+            const int i = t0 + tid;
+#pragma unroll
+            for (int c = 0; c < FHIP_MAX_CH; c++) {
+                if (c < nch) {
+                    const int32_t v = s_tile[tid * stride + c];
+                    if (pass == 0) orv[c] |= (i < n) ? (uint32_t)v : 0u;
+                    else if (i < n) smp[((size_t)f * nch + c) * n + i] = v >> wasted[c];
+                }
+            }
+        }
+        if (pass == 0) {
+#pragma unroll
+            for (int c = 0; c < FHIP_MAX_CH; c++) {
+                const uint32_t o = wave_or_u32(orv[c]);
+                if (lane == 0) s_orr[wv][c] = o;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < FHIP_MAX_CH; c++) {
+                const uint32_t o = s_orr[0][c] | s_orr[1][c] | s_orr[2][c] | s_orr[3][c];
+                int w = o ? min(__ffs((int)o) - 1, bps - 1) : bps - 1;
+                if (w == bps - 1) w = 0;
+                wasted[c] = w;
+            }
+            if (tid < nch) {
+                fhip_subframe_info *oi = &info[(size_t)f * nch + tid];
+                const uint32_t o = s_orr[0][tid] | s_orr[1][tid] | s_orr[2][tid] | s_orr[3][tid];
+                int w = o ? min(__ffs((int)o) - 1, bps - 1) : bps - 1;
+                if (w == bps - 1) w = 0;
+                oi->obits = bps - w;
+                oi->wasted = w;
+                oi->ch_mode = FHIP_CH_NOT_STEREO;
+            }
+        }
+    }
+}
+
+// K0 fast path for stereo frames with n % 4 == 0 and n <= 8192: the frame never
+// touches LDS.  Thread t owns the sample-frame quads 4(t + 256m) .. +3,
+// m < M: two 16-byte loads per quad (coalesced 32 B per lane), both channels
+// stay in registers through the estimate, the decorrelation and the wasted-bits
+// shift, and leave as one 16-byte store per channel and quad.  The two
+// sample-frames in front of a quad (for the 2nd-order residual) are one more
+// 16-byte load that hits L1/L2.
+// APPLY = false is the decision pass of the fused pipeline: it writes only
+// obits / wasted / ch_mode; the K1 producers then apply them to the PCM they
+// load anyway and write smp (k_autocorr_wt<NCH, true>).
+template <int M, bool APPLY>
+__global__ __launch_bounds__(NT)
+// allow_narrow: a channel whose samples (after the shift) all fit 16 bits is stored
+// as int16[n] at the start of its row (info.reserved = 1 tells K1's producers and
+// K3's staging; K3 resets the field) -- half the bytes written here and read there.
+void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
+                      fhip_subframe_info *__restrict__ info, int n, int bps, int estimate,
+                      int allow_narrow)
+{
+    __shared__ unsigned long long s_sum[4][4];
+    __shared__ uint32_t s_or[4][4];
+    __shared__ int s_mode;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = blockIdx.x;
+    const int4 *src = reinterpret_cast<const int4 *>(pcm + (size_t)f * n * 2);
+    const int nquads = n >> 2;
+
+    int32_t L[M][4], R[M][4];
+    int4 prev[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const int g = tid + NT * m;
+        const int gc = min(g, nquads - 1);                 // clamped: loads stay unconditional
+        const int4 a = src[2 * gc], b = src[2 * gc + 1];   // (l0 r0 l1 r1) (l2 r2 l3 r3)
+        prev[m] = src[max(2 * gc - 1, 0)];                 // (l-2 r-2 l-1 r-1)
+        L[m][0] = a.x; R[m][0] = a.y; L[m][1] = a.z; R[m][1] = a.w;
+        L[m][2] = b.x; R[m][2] = b.y; L[m][3] = b.z; R[m][3] = b.w;
+    }
+
+    int mode = FHIP_CH_LEFT_RIGHT;
+    if (estimate && n > 32) {
+        // encode.c:598-643 calc_decorr_scores
+        unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (bps <= 24) {
+            // |2nd-order residual| < 2^(bps+2) and never INT_MIN: the 4*M values of a
+            // thread add up in 32 bits, no wrap_abs corner, no per-sample predicate
+            uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const int g = tid + NT * m;
+                if (g < nquads) {
+                    int32_t l2 = prev[m].x, r2 = prev[m].y, l1 = prev[m].z, r1 = prev[m].w;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int32_t l0 = L[m][q], r0 = R[m][q];
+                        int32_t lt = l0 - 2 * l1 + l2;
+                        int32_t rt = r0 - 2 * r1 + r2;
+                        if (q < 2 && g == 0) { lt = 0; rt = 0; }        // no history for the first two (encode.c:607)
+                        const int32_t mm = (lt + rt) >> 1;
+                        const int32_t ss = lt - rt;
+                        s0 += (uint32_t)max(lt, -lt);
+                        s1 += (uint32_t)max(rt, -rt);
+                        s2 += (uint32_t)max(mm, -mm);
+                        s3 += (uint32_t)max(ss, -ss);
+                        l2 = l1; r2 = r1; l1 = l0; r1 = r0;
+                    }
+                }
+            }
+            a0 = s0; a1 = s1; a2 = s2; a3 = s3;
+        } else {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const int g = tid + NT * m;
+            uint32_t l2 = (uint32_t)prev[m].x, r2 = (uint32_t)prev[m].y;
+            uint32_t l1 = (uint32_t)prev[m].z, r1 = (uint32_t)prev[m].w;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t l0 = (uint32_t)L[m][q], r0 = (uint32_t)R[m][q];
+                const int32_t lt = (int32_t)(l0 - 2u * l1 + l2);
+                const int32_t rt = (int32_t)(r0 - 2u * r1 + r2);
+                const int32_t mm = (int32_t)((uint32_t)lt + (uint32_t)rt) >> 1;
+                const int32_t ss = (int32_t)((uint32_t)lt - (uint32_t)rt);
+                const bool on = (g < nquads) && (4 * g + q >= 2);
+                a0 += on ? (unsigned long long)(long long)wrap_abs(lt) : 0ull;
+                a1 += on ? (unsigned long long)(long long)wrap_abs(rt) : 0ull;
+                a2 += on ? (unsigned long long)(long long)wrap_abs(mm) : 0ull;
+                a3 += on ? (unsigned long long)(long long)wrap_abs(ss) : 0ull;
+                l2 = l1; r2 = r1; l1 = l0; r1 = r0;
+            }
+        }
+        }
+        a0 = wave_sum_u64(a0); a1 = wave_sum_u64(a1);
+        a2 = wave_sum_u64(a2); a3 = wave_sum_u64(a3);
+        if (lane == 0) { s_sum[wv][0] = a0; s_sum[wv][1] = a1; s_sum[wv][2] = a2; s_sum[wv][3] = a3; }
+        __syncthreads();
+        if (tid < 4) {
+            const unsigned long long sm = s_sum[0][tid] + s_sum[1][tid] + s_sum[2][tid] + s_sum[3][tid];
+            uint32_t dummy;
+            const int k = rice_best_k(2 * sm, n, &dummy);
+            s_sum[0][tid] = rice_count64(2 * sm, n, k);       // no 32-bit truncation (encode.c:620)
+        }
+        __syncthreads();
+        {
+            const unsigned long long c0 = s_sum[0][0], c1 = s_sum[0][1], c2 = s_sum[0][2], c3 = s_sum[0][3];
+            const unsigned long long sc[4] = {c0 + c1, c0 + c3, c1 + c3, c2 + c3};
+            int best = 0;
+#pragma unroll
+            for (int q = 1; q < 4; q++) if (sc[q] < sc[best]) best = q;
+            mode = (best == 0) ? FHIP_CH_LEFT_RIGHT : (best == 1) ? FHIP_CH_LEFT_SIDE
+                 : (best == 2) ? FHIP_CH_RIGHT_SIDE : FHIP_CH_MID_SIDE;
+        }
+    }
+
+    // encode.c:668-693 apply, then OR of every sample per channel
+    uint32_t or0 = 0, or1 = 0;
+    uint32_t mg0 = 0, mg1 = 0;            // OR of x ^ (x >> 31): the magnitude bits in use
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const bool on = (tid + NT * m) < nquads;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int32_t a = L[m][q], b = R[m][q];
+            if (mode == FHIP_CH_MID_SIDE) {
+                const int32_t mid = (int32_t)((uint32_t)a + (uint32_t)b) >> 1;
+                const int32_t sd = (int32_t)((uint32_t)a - (uint32_t)b);
+                a = mid; b = sd;
+            } else if (mode == FHIP_CH_LEFT_SIDE) {
+                b = (int32_t)((uint32_t)a - (uint32_t)b);
+            } else if (mode == FHIP_CH_RIGHT_SIDE) {
+                a = (int32_t)((uint32_t)a - (uint32_t)b);
+            }
+            L[m][q] = a; R[m][q] = b;
+            or0 |= on ? (uint32_t)a : 0u;
+            or1 |= on ? (uint32_t)b : 0u;
+            mg0 |= on ? (uint32_t)(a ^ (a >> 31)) : 0u;
+            mg1 |= on ? (uint32_t)(b ^ (b >> 31)) : 0u;
+        }
+    }
+    or0 = wave_or_u32(or0); or1 = wave_or_u32(or1);
+    mg0 = wave_or_u32(mg0); mg1 = wave_or_u32(mg1);
+    if (lane == 0) { s_or[wv][0] = or0; s_or[wv][1] = or1; s_or[wv][2] = mg0; s_or[wv][3] = mg1; }
+    __syncthreads();
+
+    int wasted[2], obits[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        // encode.c:558-593
+        const uint32_t o = s_or[0][c] | s_or[1][c] | s_or[2][c] | s_or[3][c];
+        int w = o ? min(__ffs((int)o) - 1, bps - 1) : bps - 1;
+        if (w == bps - 1) w = 0;
+        wasted[c] = w;
+        obits[c] = bps - w;
+    }
+    if (mode == FHIP_CH_MID_SIDE || mode == FHIP_CH_LEFT_SIDE) obits[1]++;
+    if (mode == FHIP_CH_RIGHT_SIDE) obits[0]++;
+    bool narrow[2];
+    int magbits[2];                       // |x| < 2^magbits for every shifted sample of the channel
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        // (x >> w) ^ sign == (x ^ sign) >> w: every shifted sample within int16
+        const uint32_t mg = (s_or[0][2 + c] | s_or[1][2 + c] | s_or[2][2 + c] | s_or[3][2 + c]) >> wasted[c];
+        narrow[c] = allow_narrow && (mg < 32768u);
+        magbits[c] = 32 - __clz((int)mg);
+    }
+
+    int4 *dl = reinterpret_cast<int4 *>(smp + (size_t)f * 2 * n);
+    int4 *dr = reinterpret_cast<int4 *>(smp + (size_t)f * 2 * n + n);
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const int g = tid + NT * m;
+        if (APPLY && g < nquads) {
+            const int4 vl = make_int4(L[m][0] >> wasted[0], L[m][1] >> wasted[0], L[m][2] >> wasted[0], L[m][3] >> wasted[0]);
+            const int4 vr = make_int4(R[m][0] >> wasted[1], R[m][1] >> wasted[1], R[m][2] >> wasted[1], R[m][3] >> wasted[1]);
+            if (narrow[0]) reinterpret_cast<int2 *>(dl)[g] = make_int2((vl.x & 0xFFFF) | (vl.y << 16), (vl.z & 0xFFFF) | (vl.w << 16));
+            else dl[g] = vl;
+            if (narrow[1]) reinterpret_cast<int2 *>(dr)[g] = make_int2((vr.x & 0xFFFF) | (vr.y << 16), (vr.z & 0xFFFF) | (vr.w << 16));
+            else dr[g] = vr;
+        }
+    }
+    if (tid < 2) {
+        fhip_subframe_info *o = &info[(size_t)f * 2 + tid];
+        o->obits = obits[tid];
+        o->wasted = wasted[tid];
+        o->ch_mode = mode;
+        o->reserved = narrow[tid] ? 1 + magbits[tid] : 0;     // 1..16: narrow row, |x| <= 2^(reserved-1)
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+
+hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *pcm,
+                          int nframes, int n, int32_t *smp, fhip_subframe_info *info, bool decide_only,
+                          bool allow_narrow)
+{
+    const int nch = p.channels;
+    if (nframes == 0) return hipSuccess;
+    if (nch == 2 && (n & 3) == 0 && n <= 8192) {
+        const int est = p.stereo_method == 1 ? 1 : 0;
+        const int quads = n >> 2;
+        const int nar = (allow_narrow && !decide_only) ? 1 : 0;
+#define LAUNCH_PS(M_, A_) hipLaunchKernelGGL((k_prepare_stereo<M_, A_>), dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est, nar)
+        if (decide_only) {
+            if (quads <= NT) LAUNCH_PS(1, false); else if (quads <= 2 * NT) LAUNCH_PS(2, false); else LAUNCH_PS(4, false);
+        } else {
+            if (quads <= NT) LAUNCH_PS(1, true);
+            else if (quads <= 2 * NT) LAUNCH_PS(2, true);
+            else if (quads <= 4 * NT) LAUNCH_PS(4, true);
+            else if (quads <= 5 * NT) LAUNCH_PS(5, true);       // 4608
+            else LAUNCH_PS(8, true);                            // 8192
+        }
+#undef LAUNCH_PS
+        return hipGetLastError();
+    }
+    if (decide_only || allow_narrow) return hipErrorInvalidValue;
+    if (nch != 2) {
+        hipLaunchKernelGGL(k_prepare_multi, dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, nch,
+                           p.bits_per_sample);
+        return hipGetLastError();
+    }
+    const int blocks = nframes;
+    const size_t lds = sizeof(int32_t) * (size_t)n * (nch == 2 ? 2 : 1);
+    if (blocks == 0) return hipSuccess;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prepare),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (er != hipSuccess) return er;
+    hipLaunchKernelGGL(k_prepare, dim3(blocks), dim3(NT), lds, st, pcm, smp, info, n, nch,
+                       p.bits_per_sample, p.stereo_method == 1 ? 1 : 0);
+    return hipGetLastError();
+}
+
+}  // namespace fhip

@@ -1,0 +1,1912 @@
+// k3_encode.hip -- K3: encode_residual (optimize.c:34-276) incl. the Rice search
+// (rice.c:30-187) and the residual section of output_residual (encode.c:766-798,
+// bitio.h:120-141): k_encode<C> for any block size, k_encode_pow2<C,T,MODE> for
+// n = C*T.
+#include "device_util.h"
+
+#ifdef FHIP_STAMPS
+FHIP_DEFINE_STAMP_READER(fhip_debug_read_stamps_k3)      // slots 0..39 (tools/stamps.py)
+extern "C" int fhip_debug_read_stamps_k1(long long *out);
+// the tools' entry point: K3's slots, with K1's accumulators in 40..63
+extern "C" __attribute__((visibility("default"))) int fhip_debug_read_stamps(long long *out)
+{
+    long long k1[64];
+    int rc = fhip_debug_read_stamps_k3(out);
+    if (rc == 0) rc = fhip_debug_read_stamps_k1(k1);
+    for (int i = 40; i < 64 && rc == 0; i++) out[i] = k1[i];
+    return rc;
+}
+#endif
+
+namespace fhip {
+namespace {
+
+// ---------------------------------------------------------------------------
+// K3  k_encode
+// ---------------------------------------------------------------------------
+// One workgroup per subframe.  Thread t owns the contiguous run of `chunk`
+// samples starting at t*chunk: its residuals stay in registers from the FIR
+// through the partition sums to the bit emit.  Samples sit in LDS behind one
+// pad word per 16 so that lane-strided reads of x[16*t + d] spread over all
+// banks.
+struct EncLds {
+    int32_t *smp;                       // padded samples
+    unsigned long long *sums;           // [511] partition sums, heap order
+    int32_t *kpar;                      // [511] Rice parameter per node
+    uint32_t *lvl_bits;                 // [9]
+    uint32_t *lvl_meth;                 // [9]
+    int32_t *coef;                      // [32]
+    int32_t *misc;                      // [16]
+    uint32_t *trial;                    // [32] bits[] table of the log search
+    unsigned long long *scan;           // [8]
+    uint32_t *bits;                     // [ENC_WWORDS] emit window
+};
+constexpr int ENC_WWORDS = 2048;        // 64 Kbit emit window
+enum { M_PORDER = 0, M_METHOD = 1, M_BITS = 2, M_FLAG = 3 };
+
+__device__ __forceinline__ int padidx(int i) { return i + (i >> 4); }
+
+__host__ __device__ inline size_t enc_lds_layout(int n, size_t off[10])
+{
+    size_t o = 0;
+    off[0] = o; o += 8 * 511;                                   // sums
+    off[1] = o; o += 8 * 8;                                     // scan
+    off[2] = o; o += 4 * (size_t)(n + (n >> 4) + 1);            // smp
+    off[3] = o; o += 4 * 511;                                   // kpar
+    off[4] = o; o += 4 * 9;                                     // lvl_bits
+    off[5] = o; o += 4 * 9;                                     // lvl_meth
+    off[6] = o; o += 4 * 32;                                    // coef
+    off[7] = o; o += 4 * 16;                                    // misc
+    off[9] = o; o += 4 * 32;                                    // trial
+    o = (o + 15) & ~(size_t)15;
+    off[8] = o; o += 4 * ENC_WWORDS;                            // bits
+    return o;
+}
+
+struct EncCtx {
+    EncLds l;
+    int n, chunk, i0, tid;
+    int obits, precision;
+    int pmin_req, pmax_req;
+};
+
+
+// rice.c:148-155 limit_max_partition_order
+__device__ __forceinline__ int clamp_porder(int porder, int n, int order)
+{
+    int lim = ilog2_dev((uint32_t)(n ^ (n - 1)));
+    porder = min(porder, lim);
+    if (order > 0) porder = min(porder, ilog2_dev((uint32_t)(n / order)));
+    return porder;
+}
+
+// Rice search over the residuals held in r[] (rice.c:105-187).  Leaves the
+// per-node parameters in l.kpar, the chosen order/method in l.misc and
+// returns the subframe bit estimate.  All threads must call it.
+template <int C>
+__device__ __forceinline__ uint32_t rice_search(const EncCtx &e, const int32_t (&r)[C], int order, bool lpc)
+{
+    const EncLds &l = e.l;
+    const int n = e.n, tid = e.tid;
+    const int pmin = clamp_porder(e.pmin_req, n, order);
+    const int pmax = clamp_porder(e.pmax_req, n, order);
+    const int psize = n >> pmax;
+
+    for (int q = tid; q < 511; q += NT) l.sums[q] = 0;
+    if (tid < 9) { l.lvl_bits[tid] = 0; l.lvl_meth[tid] = 0; }
+    __syncthreads();
+
+    // rice.c:76-94 finest-level sums: partition 0 starts at `order`
+    {
+        const int heap0 = (1 << pmax) - 1;
+        unsigned long long run = 0;
+        int part = -1, bound = 0;
+#pragma unroll
+        for (int o = 0; o < C; o++) {
+            const int i = e.i0 + o;
+            if (o < e.chunk && i < n && i >= order) {
+                if (part < 0) { part = i / psize; bound = (part + 1) * psize; }
+                if (i == bound) {
+                    atomicAdd(&l.sums[heap0 + part], run);
+                    run = 0; part++; bound += psize;
+                }
+                run += zigzag32(r[o]);
+            }
+        }
+        if (part >= 0) atomicAdd(&l.sums[heap0 + part], run);
+    }
+    __syncthreads();
+    // rice.c:96-102 pyramid
+    for (int p = pmax - 1; p >= pmin; p--) {
+        const int np = 1 << p;
+        for (int j = tid; j < np; j += NT)
+            l.sums[np - 1 + j] = l.sums[2 * np - 1 + 2 * j] + l.sums[2 * np - 1 + 2 * j + 1];
+        __syncthreads();
+    }
+    // rice.c:47-74 per level, per partition: best k and its cost
+    {
+        const int first = (1 << pmin) - 1, last = (2 << pmax) - 2;
+        for (int q = first + tid; q <= last; q += NT) {
+            const int p = ilog2_dev((uint32_t)(q + 1));
+            const int j = q + 1 - (1 << p);
+            const int cnt = (n >> p) - (j == 0 ? order : 0);
+            uint32_t b;
+            const int k = rice_best_k(l.sums[q], cnt, &b);
+            l.kpar[q] = k;
+            atomicAdd(&l.lvl_bits[p], b);
+            if (k > 14) atomicOr(&l.lvl_meth[p], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // rice.c:127-138: ties go to the higher partition order
+        int bp = pmin;
+        uint32_t best = l.lvl_bits[pmin] + 4u * (1u << pmin);
+        for (int p = pmin + 1; p <= pmax; p++) {
+            uint32_t b = l.lvl_bits[p] + 4u * (1u << p);
+            if (b <= best) { best = b; bp = p; }
+        }
+        const uint32_t method = l.lvl_meth[bp];
+        // rice.c:157-171
+        uint32_t bits = (uint32_t)(order * e.obits + 2);
+        if (lpc) bits += (uint32_t)(4 + 5 + order * e.precision);
+        bits += best;
+        bits += method + 4u;
+        l.misc[M_PORDER] = bp;
+        l.misc[M_METHOD] = (int)method;
+        l.misc[M_BITS] = (int)bits;
+    }
+    __syncthreads();
+    return (uint32_t)l.misc[M_BITS];
+}
+
+// optimize.c:70-122 encode_residual_lpc for this thread's run
+template <int C>
+__device__ __forceinline__ void residual_lpc(const EncCtx &e, int32_t (&r)[C], int order,
+                                             const int32_t *__restrict__ coefs_row, int shift)
+{
+    const EncLds &l = e.l;
+    __syncthreads();                       // previous readers of l.coef are done
+    if (e.tid < order) l.coef[e.tid] = coefs_row[e.tid];
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < C; o++) {
+        const int i = e.i0 + o;
+        int32_t v = 0;
+        if (o < e.chunk && i < e.n) {
+            const int32_t x = l.smp[padidx(i)];
+            if (i < order) {
+                v = x;
+            } else {
+                long long pred = 0;
+                for (int j = order; j >= 1; j--)
+                    pred += (long long)l.coef[j - 1] * (long long)l.smp[padidx(i - j)];
+                v = (int32_t)((long long)x - (pred >> shift));
+            }
+        }
+        r[o] = v;
+    }
+}
+
+// optimize.c:34-68 encode_residual_fixed
+template <int C>
+__device__ __forceinline__ void residual_fixed(const EncCtx &e, int32_t (&r)[C], int order)
+{
+    const EncLds &l = e.l;
+#pragma unroll
+    for (int o = 0; o < C; o++) {
+        const int i = e.i0 + o;
+        int32_t v = 0;
+        if (o < e.chunk && i < e.n) {
+            const long long x0 = l.smp[padidx(i)];
+            if (i < order || order == 0) {
+                v = (int32_t)x0;
+            } else {
+                const long long x1 = l.smp[padidx(i - 1)];
+                long long acc;
+                if (order == 1) {
+                    acc = x0 - x1;
+                } else {
+                    const long long x2 = l.smp[padidx(i - 2)];
+                    if (order == 2) {
+                        acc = x0 - 2 * x1 + x2;
+                    } else {
+                        const long long x3 = l.smp[padidx(i - 3)];
+                        if (order == 3) {
+                            acc = x0 - 3 * x1 + 3 * x2 - x3;
+                        } else {
+                            const long long x4 = l.smp[padidx(i - 4)];
+                            acc = x0 - 4 * x1 + 6 * x2 - 4 * x3 + x4;
+                        }
+                    }
+                }
+                v = (int32_t)acc;
+            }
+        }
+        r[o] = v;
+    }
+}
+
+// OR a value of `len` (<= 31) bits into the MSB-first bit string at absolute
+// bit position pos, clipped to the LDS window [wlo, wlo + ENC_WWORDS) words.
+__device__ __forceinline__ void put_bits(uint32_t *win, long long wlo, long long pos, int len, uint32_t val)
+{
+    const long long wi = (pos >> 5) - wlo;
+    if (wi < -1 || wi >= ENC_WWORDS) return;
+    const int sh = 64 - len - (int)(pos & 31);
+    const unsigned long long x = (unsigned long long)val << sh;
+    const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+    if (wi >= 0 && hi) atomicOr(&win[wi], hi);
+    if (lo && wi + 1 < ENC_WWORDS) atomicOr(&win[wi + 1], lo);
+}
+
+template <int C>
+__global__ __launch_bounds__(NT)
+void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
+              const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
+              const int32_t *__restrict__ opt_all, fhip_subframe_info *__restrict__ info,
+              int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
+              int raw_order, int raw_lpc)
+{
+    // raw_order >= 0: the input already IS a residual; only calc_rice_params_*
+    // (rice.c:173-187) with that prediction order and the emit run.
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    size_t off[10];
+    enc_lds_layout(n, off);
+    EncCtx e;
+    e.l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
+    e.l.scan = reinterpret_cast<unsigned long long *>(lds_raw + off[1]);
+    e.l.smp = reinterpret_cast<int32_t *>(lds_raw + off[2]);
+    e.l.kpar = reinterpret_cast<int32_t *>(lds_raw + off[3]);
+    e.l.lvl_bits = reinterpret_cast<uint32_t *>(lds_raw + off[4]);
+    e.l.lvl_meth = reinterpret_cast<uint32_t *>(lds_raw + off[5]);
+    e.l.coef = reinterpret_cast<int32_t *>(lds_raw + off[6]);
+    e.l.misc = reinterpret_cast<int32_t *>(lds_raw + off[7]);
+    e.l.bits = reinterpret_cast<uint32_t *>(lds_raw + off[8]);
+    e.l.trial = reinterpret_cast<uint32_t *>(lds_raw + off[9]);
+    const EncLds &l = e.l;
+
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    fhip_subframe_info *out = &info[s];
+    e.n = n;
+    e.tid = tid;
+    e.chunk = (n + NT - 1) / NT;
+    e.i0 = tid * e.chunk;
+    e.obits = out->obits;
+    e.precision = P.lpc_precision;
+    e.pmin_req = P.min_partition_order;
+    e.pmax_req = P.max_partition_order;
+
+    const int32_t *src = smp_all + (size_t)s * n;
+    if (tid == 0) l.misc[M_FLAG] = 0;
+    __syncthreads();
+    {
+        const int32_t first = src[0];
+        int differs = 0;
+        for (int i = tid; i < n; i += NT) {
+            int32_t v = src[i];
+            l.smp[padidx(i)] = v;
+            differs |= (v != first);
+        }
+        if (differs) atomicOr(&l.misc[M_FLAG], 1);
+    }
+    __syncthreads();
+    const bool constant = (l.misc[M_FLAG] == 0);
+
+    int32_t r[C];
+    int type, type_code, order = 0, shift = 0;
+    uint32_t est_bits = 0;
+    bool has_rice = false;
+    const int32_t *crow_base = coefs_all + (size_t)s * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
+    const int32_t *srow = shift_all + (size_t)s * FHIP_MAX_ORDER;
+
+    // The decision tree of encode_residual() (optimize.c:124-276) as one
+    // candidate loop: `pick` walks the orders the reference would try, in its
+    // sequence; the last pass re-encodes the winner exactly as the reference
+    // does (optimize.c:184-188, :266-275).  Every variable below is uniform
+    // across the workgroup.
+    enum { T_CONST, T_VERB, T_FIXED, T_LPC, T_RAW } tree;
+    if (raw_order >= 0) tree = T_RAW;
+    else if (constant) tree = T_CONST;                                   // optimize.c:143-151
+    else if (n < 5 || P.prediction_type == 0) tree = T_VERB;             // optimize.c:153-158
+    else if (P.prediction_type == 1 || n <= P.max_prediction_order) tree = T_FIXED;
+    else tree = T_LPC;
+
+    const int omethod = P.order_method;
+    const int min_order = P.min_prediction_order;
+    const int max_order = (tree == T_FIXED) ? min(P.max_prediction_order, 4) : P.max_prediction_order;
+
+    // iteration state
+    int it = 0;                 // FIXED: order; LEVEL: index; SEARCH: row
+    int best = 0;               // FIXED: order; LPC: zero-based row
+    uint32_t best_bits = 0, last_bits = 0;
+    bool have_best = false;
+    int lg_step = 16, lg_last = 0, lg_pos = 3;      // log search
+    bool final_pass = false;
+
+    if (tree == T_FIXED) { it = min_order; best = min_order; }
+    if (tree == T_LPC) {
+        if (omethod == 0) { best = max_order - 1; final_pass = true; }
+        else if (omethod == 1) { best = opt_all[s] - 1; final_pass = true; }
+        else if (omethod <= 4) { it = (1 << (omethod - 1)) - 1; best = max_order - 1; }
+        else if (omethod == 5) { it = 0; best = 0; }
+        else {
+            best = min_order - 1 + (max_order - min_order) / 3;
+            if (tid < FHIP_MAX_ORDER) l.trial[tid] = 0xFFFFFFFFu;
+            __syncthreads();
+            lg_step = 32;       // first pick halves it to 16
+        }
+    }
+
+    if (tree == T_RAW) {
+        residual_fixed<C>(e, r, 0);
+        est_bits = rice_search<C>(e, r, raw_order, raw_lpc != 0);
+        order = raw_order;
+        type = raw_lpc ? FHIP_SUB_LPC : FHIP_SUB_FIXED;
+        type_code = type;
+        has_rice = true;
+    } else if (tree == T_CONST || tree == T_VERB) {
+        type = type_code = (tree == T_CONST) ? FHIP_SUB_CONSTANT : FHIP_SUB_VERBATIM;
+        est_bits = (uint32_t)(tree == T_CONST ? e.obits : e.obits * n);
+        residual_fixed<C>(e, r, 0);
+    } else {
+        for (;;) {
+            // ---- pick the next candidate (cand: FIXED order / LPC row) ----
+            int cand = -1;
+            if (!final_pass) {
+                if (tree == T_FIXED) {
+                    if (it <= max_order) cand = it;
+                } else if (omethod <= 4) {
+                    // optimize.c:202-223: level indices high -> low
+                    if (it >= 0) {
+                        const int levels = 1 << (omethod - 1);
+                        cand = min_order + (((max_order - min_order + 1) * (it + 1)) / levels) - 2;
+                        if (cand < 0) cand = 0;
+                    }
+                } else if (omethod == 5) {
+                    // optimize.c:224-238: rows 0..max-1, min_order ignored
+                    if (it < max_order) cand = it;
+                } else {
+                    // optimize.c:239-261 log search, bits[] in l.trial
+                    for (;;) {
+                        if (lg_pos == 3) {
+                            lg_step >>= 1;
+                            if (lg_step == 0) break;
+                            lg_last = best;
+                            lg_pos = 0;
+                        }
+                        const int i = lg_last + (lg_pos - 1) * lg_step;
+                        lg_pos++;
+                        if (i < min_order - 1 || i >= max_order || l.trial[i] < 0xFFFFFFFFu) continue;
+                        cand = i;
+                        break;
+                    }
+                }
+                if (cand < 0) {
+                    // candidates exhausted: FIXED keeps the last residual when
+                    // the winner was tried last (optimize.c:184-189)
+                    if (tree == T_FIXED && best == max_order) { est_bits = last_bits; break; }
+                    final_pass = true;
+                }
+            }
+            if (final_pass) cand = best;
+
+            // ---- evaluate it ----
+            uint32_t b;
+            if (tree == T_FIXED) {
+                residual_fixed<C>(e, r, cand);
+                b = rice_search<C>(e, r, cand, false);
+            } else {
+                residual_lpc<C>(e, r, cand + 1, crow_base + cand * FHIP_MAX_ORDER, srow[cand]);
+                b = rice_search<C>(e, r, cand + 1, true);
+            }
+            if (final_pass) { est_bits = b; break; }
+
+            // ---- fold it into the running decision ----
+            last_bits = b;
+            if (tree == T_FIXED) {
+                if (!have_best || b < best_bits) { best_bits = b; best = cand; }   // strict '<', optimize.c:177
+                it++;
+            } else if (omethod <= 4) {
+                if (!have_best) best_bits = b;              // index levels-1: opt_order stays max_order-1
+                else if (b < best_bits) { best_bits = b; best = cand; }
+                it--;
+            } else if (omethod == 5) {
+                if (!have_best || b < best_bits) { best_bits = b; best = cand; }
+                it++;
+            } else {
+                if (tid == 0) l.trial[cand] = b;
+                __syncthreads();
+                if (b < l.trial[best]) best = cand;         // optimize.c:256
+            }
+            have_best = true;
+        }
+        if (tree == T_FIXED) {
+            order = best;
+            type = FHIP_SUB_FIXED;
+            type_code = FHIP_SUB_FIXED | order;
+        } else {
+            order = best + 1;
+            shift = srow[best];
+            type = FHIP_SUB_LPC;
+            type_code = FHIP_SUB_LPC | (order - 1);
+        }
+        has_rice = true;
+    }
+
+    const int porder = has_rice ? l.misc[M_PORDER] : 0;
+    const int method = has_rice ? l.misc[M_METHOD] : 0;
+
+    // FlacSubframe.residual
+    if (res_out) {
+        int32_t *dst = res_out + (size_t)s * n;
+#pragma unroll
+        for (int o = 0; o < C; o++) {
+            const int i = e.i0 + o;
+            if (o < e.chunk && i < n) dst[i] = r[o];
+        }
+    }
+
+    // encode.c:766-798 output_residual, all partitions and codewords at once
+    long long total_bits = 0;
+    if (has_rice) {
+        const int psz = n >> porder;
+        const int pbits = 4 + method;
+        const int heap0 = (1 << porder) - 1;
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int o = 0; o < C; o++) {
+            const int i = e.i0 + o;
+            if (o < e.chunk && i < n && i >= order) {
+                const int part = i / psz;
+                const int k = l.kpar[heap0 + part];
+                if (part > 0 && i == part * psz) mine += pbits;
+                mine += (unsigned long long)(emit_fold32(r[o]) >> k) + 1 + k;
+            }
+        }
+        unsigned long long incl = wave_incl_scan_u64(mine, lane);
+        if (lane == 63) l.scan[wv] = incl;
+        __syncthreads();
+        unsigned long long base = 6 + pbits;           // section header + partition 0 parameter
+        for (int w = 0; w < wv; w++) base += l.scan[w];
+        const unsigned long long tot = 6 + pbits + l.scan[0] + l.scan[1] + l.scan[2] + l.scan[3];
+        const unsigned long long my_off = base + incl - mine;
+        total_bits = (tot > 0x7FFFFFFFull) ? 0x7FFFFFFFll : (long long)tot;
+
+        if (bits_out) {
+            if (tot > (unsigned long long)slot_bytes * 8ull) {
+                total_bits = -1;
+            } else {
+                uint32_t *dst32 = reinterpret_cast<uint32_t *>(bits_out + (size_t)s * slot_bytes);
+                const long long nwords = (long long)((tot + 31) >> 5);
+                for (long long wlo = 0; wlo < nwords; wlo += ENC_WWORDS) {
+                    __syncthreads();
+                    for (int q = tid; q < ENC_WWORDS; q += NT) l.bits[q] = 0;
+                    __syncthreads();
+                    if (tid == 0) {
+                        put_bits(l.bits, wlo, 0, 2, (uint32_t)method);
+                        put_bits(l.bits, wlo, 2, 4, (uint32_t)porder);
+                        put_bits(l.bits, wlo, 6, pbits, (uint32_t)l.kpar[heap0]);
+                    }
+                    long long pos = (long long)my_off;
+#pragma unroll
+                    for (int o = 0; o < C; o++) {
+                        const int i = e.i0 + o;
+                        if (o < e.chunk && i < n && i >= order) {
+                            const int part = i / psz;
+                            const int k = l.kpar[heap0 + part];
+                            if (part > 0 && i == part * psz) {
+                                put_bits(l.bits, wlo, pos, pbits, (uint32_t)k);
+                                pos += pbits;
+                            }
+                            // bitio.h:120-141: q zeros, a one, k low bits
+                            const uint32_t u = emit_fold32(r[o]);
+                            const uint32_t q = u >> k;
+                            put_bits(l.bits, wlo, pos + q, k + 1, (1u << k) | (u & ((1u << k) - 1u)));
+                            pos += (long long)q + 1 + k;
+                        }
+                    }
+                    __syncthreads();
+                    const long long cnt = (nwords - wlo < ENC_WWORDS) ? (nwords - wlo) : (long long)ENC_WWORDS;
+                    for (int q = tid; q < cnt; q += NT)
+                        dst32[wlo + q] = __builtin_bswap32(l.bits[q]);
+                }
+            }
+        }
+    }
+
+    // FlacSubframe / RiceContext fields
+    if (tid == 0) {
+        out->type = type;
+        out->type_code = type_code;
+        out->order = order;
+        out->shift = shift;
+        out->rice_method = method;
+        out->porder = porder;
+        out->est_bits = est_bits;
+        out->rice_nbits = (int32_t)total_bits;
+        out->reserved = 0;
+    }
+    if (tid < FHIP_MAX_ORDER)
+        out->coefs[tid] = (type == FHIP_SUB_LPC && tid < order && raw_order < 0) ? l.coef[tid] : 0;
+    {
+        const int np = has_rice ? (1 << porder) : 0;
+        out->rparams[tid] = (tid < np) ? l.kpar[np - 1 + tid] : 0;
+    }
+    // warm-up samples (= residual[0..order)); [0] carries a CONSTANT's value
+    if (tid < FHIP_MAX_ORDER) {
+        const int nw = (type == FHIP_SUB_CONSTANT) ? 1 : order;
+        out->warmup[tid] = (tid < nw && tid < n) ? l.smp[padidx(tid)] : 0;
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// K3 fast path  k_encode_pow2<C, T>
+// ---------------------------------------------------------------------------
+// Same contract as k_encode, for block sizes n = C*T with T (threads) a power
+// of two >= 64, C in {3, 4, 8, 9, 16, 18} samples per thread and every partition at
+// least one thread wide ((n >> pmax) >= C): all of FLAC's standard block sizes
+// (192, 576, 1152, 2304, 4608 = 3 or 9 times a power of two; 256 .. 16384).  Then
+//   * no lane ever needs a bounds or partition-boundary test per sample: a
+//     thread's run lies inside one partition of every level;
+//   * the FIR runs as exact fp64 FMAs (|coef| < 2^14, |sample| < 2^31, <= 32
+//     taps: every partial sum is an integer below 2^50 < 2^53), in register
+//     blocks of 8 taps -- v_fma_f64 issues 3-4x faster than v_mad_i64_i32;
+//   * partition sums are a wave shuffle pyramid (thread = finest level);
+//   * the best Rice parameter comes from a closed form, with the reference's
+//     31-step scan only where its modular arithmetic can bite (see rice_k_fast).
+constexpr int HIST = 32;                 // zeroed samples in front of the block
+
+// The block sits in LDS transposed: thread t's run of C samples is column t.
+//  * C % 4 != 0: sample i (>= -HIST) is at row (i mod C), column (i div C) + COL0 of
+//    a [C][S] int32 image; lanes of a wave touch consecutive words.
+//  * C % 4 == 0 (V4): the rows are groups of four samples, [C/4][S] of int4 -- a
+//    thread stages its run with C/4 16-byte stores and the FIR fetches its window
+//    with 16-byte loads (a quarter of the LDS instructions; lanes touch
+//    consecutive 16-byte slots, conflict-free).
+// Either way every sample a thread needs at offset c from its run start is at the
+// thread's base + a compile-time offset: the window loads carry no address
+// arithmetic.  (An fp64 image saves the int->double conversions but its 33 KB cost
+// a workgroup per CU: measured 108 vs 96 us.)
+template <int C, int T>
+struct SmpImg {
+    static constexpr bool V4 = (C % 4 == 0);
+    static constexpr int CS = V4 ? 4 : 1;             // int32 per column step
+    // columns of zeros in front: the FIR looks back 32 samples in tap blocks
+    // of 16 (C | 16) or 36 in tap blocks of 9 (C = 3, 9, 18)
+    static constexpr int COL0 = (16 % C == 0) ? HIST / C : (36 + C - 1) / C;
+    static constexpr int ROWS = V4 ? C / 4 : C;
+    static constexpr int S = T + COL0 + (V4 ? 1 : 2);  // row stride in columns
+    static constexpr int SIZE = ROWS * S * CS;         // int32
+    // int32 index of sample r (0 <= r < C) of column col
+    __host__ __device__ static constexpr int at(int col, int r)
+    {
+        return V4 ? ((r / 4) * S + col) * 4 + (r % 4) : r * S + col;
+    }
+    // offset of sample (run start of thread t) + c, relative to &img[t * CS]
+    __host__ __device__ static constexpr int off(int c)
+    {
+        return at((c - (((c % C) + C) % C)) / C + COL0, ((c % C) + C) % C);
+    }
+};
+
+// rice.c:30-45 find_optimal_rice_param without the scan.  With
+// S = sum - (n>>1):  f(k) = n(k+1) + (S>>k).
+//  * sum < n>>1: S wraps; f(k) = n(k+1) - ceil(d/2^k) (mod 2^32) with
+//    d = (n>>1)-sum <= n/2 is increasing, so k = 0.
+//  * no wrap and f < 2^32 for all k: f is convex in k (its increment
+//    n - ceil((S>>k)/2) never decreases), so the first minimum is the smallest
+//    k with (S>>k) <= 2n, capped at 30.
+//  * otherwise (sums near 2^32): the reference scan.
+__device__ __forceinline__ int rice_k_fast(uint64_t sum, int n, uint32_t *bits_out)
+{
+    const uint64_t half = (uint64_t)(n >> 1);
+    if (sum < half) {
+        *bits_out = (uint32_t)n - (uint32_t)(half - sum);
+        return 0;
+    }
+    const uint64_t S = sum - half;
+    if (n <= 0 || S >= 0xFFE00000ull) return rice_best_k(sum, n, bits_out);
+    const uint32_t two = 2u * (uint32_t)n;
+    int k = 0;
+    if (S > two) {
+        k = (64 - __clzll((long long)S)) - (32 - __clz((int)two));
+        if ((S >> k) > two) k++;
+        if (k > 30) k = 30;
+    }
+    *bits_out = (uint32_t)(n * (k + 1)) + (uint32_t)(S >> k);
+    return k;
+}
+
+struct FastLds {
+    int32_t *smp;                        // SmpImg<C,T>: samples, HIST zeros in front
+    unsigned long long *sums;            // [511] heap order
+    int32_t *kpar;                       // [511]
+    double *coefd;                       // [32] coefficients of the candidate as fp64
+    unsigned long long *wtot;            // [16] per-wave totals
+    uint32_t *lvl_bits, *lvl_meth;       // [9]
+    int32_t *coef;                       // [32]
+    int32_t *misc;                       // [16]
+    uint32_t *trial;                     // [32]
+    uint32_t *bits;                      // [ENC_WWORDS]
+};
+
+// Emit window of the fast path, in words: a section of typical density fits one
+// window (n/2 words = 16 bits per sample, rounded up to a power of two); denser
+// sections take more passes.  Small blocks thus leave LDS for more workgroups.
+__host__ __device__ inline int fast_window_words(int n)
+{
+    int w = 256;
+    while (w < ENC_WWORDS && 2 * w < n) w <<= 1;
+    return w;
+}
+
+__host__ __device__ inline size_t fast_lds_layout(int n, size_t img_doubles, size_t off[11])
+{
+    size_t o = 0;
+    off[0] = o; o += 8 * 512;                                   // sums
+    off[1] = o; o += 8 * 48;                                    // coefd (zero-padded past 32)
+    off[2] = o; o += 8 * 16;                                    // wtot
+    off[3] = o; o += 4 * img_doubles;                           // smp image (ints)
+    off[4] = o; o += 4 * 512;                                   // kpar
+    off[5] = o; o += 4 * 12;                                    // lvl_bits
+    off[6] = o; o += 4 * 12;                                    // lvl_meth
+    off[7] = o; o += 4 * 32;                                    // coef
+    off[8] = o; o += 4 * 16;                                    // misc
+    off[9] = o; o += 4 * 32;                                    // trial
+    o = (o + 15) & ~(size_t)15;
+    off[10] = o; o += 4 * fast_window_words(n);                 // bits
+    return o;
+}
+
+constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }
+
+template <int C, int T>
+struct FastCtx {
+    FastLds l;
+    int n, i0, tid, lane, wv;
+    int obits, precision, pmin_req, pmax_req;
+};
+
+// FIR residual of this thread's C samples x[] for an LPC candidate
+// (optimize.c:70-122).  l.coefd holds the coefficients as doubles, zero past
+// `order`, so the tap loop runs in whole blocks of 8.
+template <int C, int T>
+__device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift)
+{
+    using Img = SmpImg<C, T>;
+    const FastLds &l = e.l;
+    const double inv = __builtin_ldexp(1.0, -shift);
+    // outputs per register block: a divisor of C
+    constexpr int OB = (C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : 1;
+    // taps per block: a multiple of C (going back C*k samples is going back k
+    // columns of the image, so every block sees the same immediate offsets)
+    constexpr int TB = (16 % C == 0) ? 16 : C * ((8 + C - 1) / C);
+    const int32_t *mine = l.smp + e.tid * Img::CS;   // column of this thread's run
+#pragma unroll
+    for (int ob = 0; ob < C; ob += OB) {
+        // keep the register blocks apart: interleaving them only costs VGPRs
+        __builtin_amdgcn_sched_barrier(0);
+        double acc[OB];
+#pragma unroll
+        for (int o = 0; o < OB; o++) acc[o] = 0.0;
+#pragma unroll 1
+        for (int tb = 0; tb < order; tb += TB) {
+            const int32_t *base = mine - (tb / C) * Img::CS;
+#pragma unroll
+            for (int sb = 0; sb < TB; sb += 8) {
+                constexpr int dummy = 0; (void)dummy;
+                if (order > tb + sb) {
+                    // taps tb+sb+1 .. tb+sb+NT_ : samples c = ob+o-(sb+jj+1)
+                    const int NT_ = (TB - sb < 8) ? TB - sb : 8;
+                    double W[OB + 7];
+                    if constexpr (Img::V4) {
+                        // the window starts on a group of four: 16-byte loads
+                        static_assert(!Img::V4 || (TB == 16 && OB % 4 == 0), "aligned windows");
+#pragma unroll
+                        for (int m4 = 0; m4 < OB + 7; m4 += 4) {
+                            const int4 v = *reinterpret_cast<const int4 *>(base + Img::off(ob - sb - 8 + m4));
+                            W[m4] = (double)v.x;
+                            if (m4 + 1 < OB + 7) W[m4 + 1] = (double)v.y;
+                            if (m4 + 2 < OB + 7) W[m4 + 2] = (double)v.z;
+                            if (m4 + 3 < OB + 7) W[m4 + 3] = (double)v.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < OB + 7; m++)
+                            if (m < OB + NT_ - 1) W[m] = (double)base[Img::off(ob - sb - NT_ + m)];
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) {
+                        if (jj < NT_) {
+                            const double cd = l.coefd[tb + sb + jj];
+#pragma unroll
+                            for (int o = 0; o < OB; o++)
+                                acc[o] = __builtin_fma(cd, W[o + NT_ - 1 - jj], acc[o]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < OB; o++) {
+            // pred >> shift == floor(pred * 2^-shift).  The kernel runs with the
+            // fp64 rounding mode "toward -inf" (set_round_down): acc * 2^-shift is
+            // exact, |.| < 2^51, so the one rounding of fma(acc, 2^-shift, 1.5 * 2^52)
+            // is that floor, and the low mantissa word is the floor's low 32 bits in
+            // two's complement.  (int32)(x - (pred >> shift)) only needs those.
+            const double z = __builtin_fma(acc[o], inv, 6755399441055744.0);
+            const uint32_t qlo = (uint32_t)__double2loint(z);
+            uint32_t x;
+            if constexpr (Img::V4) {
+                const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob + (o & ~3)));   // one load per four
+                x = (uint32_t)((o & 3) == 0 ? v.x : (o & 3) == 1 ? v.y : (o & 3) == 2 ? v.z : v.w);
+            } else {
+                x = (uint32_t)mine[Img::off(ob + o)];
+            }
+            r[ob + o] = (int32_t)(x - qlo);
+        }
+    }
+    // warm-up samples pass through (optimize.c:84-86): only the first threads
+    if (e.i0 < order) {
+#pragma unroll
+        for (int o = 0; o < C; o++)
+            if (e.i0 + o < order) r[o] = mine[Img::off(o)];
+    }
+}
+
+// The same FIR for orders <= 8 with the coefficients as wave-uniform doubles read
+// from K2's compact row by scalar loads (MODE 0): no coefficient traffic through
+// LDS, no vector registers for them.
+template <int C, int T>
+__device__ __forceinline__ void fir_lpc_o8(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
+                                           const double *__restrict__ cd)
+{
+    using Img = SmpImg<C, T>;
+    const double inv = __builtin_ldexp(1.0, -shift);
+    constexpr int OB = (C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : 1;
+    const int32_t *mine = e.l.smp + e.tid * Img::CS;
+    double cf[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) cf[jj] = cd[jj];
+#pragma unroll
+    for (int ob = 0; ob < C; ob += OB) {
+        __builtin_amdgcn_sched_barrier(0);
+        double acc[OB];
+#pragma unroll
+        for (int o = 0; o < OB; o++) acc[o] = 0.0;
+        double W[OB + 7];
+        if constexpr (Img::V4) {
+#pragma unroll
+            for (int m4 = 0; m4 < OB + 7; m4 += 4) {
+                const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob - 8 + m4));
+                W[m4] = (double)v.x;
+                if (m4 + 1 < OB + 7) W[m4 + 1] = (double)v.y;
+                if (m4 + 2 < OB + 7) W[m4 + 2] = (double)v.z;
+                if (m4 + 3 < OB + 7) W[m4 + 3] = (double)v.w;
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < OB + 7; m++) W[m] = (double)mine[Img::off(ob - 8 + m)];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++)
+#pragma unroll
+            for (int o = 0; o < OB; o++)
+                acc[o] = __builtin_fma(cf[jj], W[o + 7 - jj], acc[o]);
+#pragma unroll
+        for (int o = 0; o < OB; o++) {
+            const double z = __builtin_fma(acc[o], inv, 6755399441055744.0);   // floor under round-down, see fir_lpc
+            const uint32_t qlo = (uint32_t)__double2loint(z);
+            uint32_t x;
+            if constexpr (Img::V4) {
+                const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob + (o & ~3)));
+                x = (uint32_t)((o & 3) == 0 ? v.x : (o & 3) == 1 ? v.y : (o & 3) == 2 ? v.z : v.w);
+            } else {
+                x = (uint32_t)mine[Img::off(ob + o)];
+            }
+            r[ob + o] = (int32_t)(x - qlo);
+        }
+    }
+    if (e.i0 < order) {
+#pragma unroll
+        for (int o = 0; o < C; o++)
+            if (e.i0 + o < order) r[o] = mine[Img::off(o)];
+    }
+}
+
+// Orders <= 8 on a channel whose samples fit 16 bits (K0's narrow rows), when the
+// prediction provably stays inside int32 (sum|coef| * 2^magbits < 2^31, checked by
+// the caller): v_dot2_i32_i16 does two taps per instruction on int16 pairs and
+// costs about what one fp64 FMA does, with no int -> fp64 conversions in front.
+// Sample pairs R(k) = (lo: x[k], hi: x[k+1]) are packed from the int32 window;
+// cp[j] = (lo: coef of tap 2j+2, hi: coef of tap 2j+1) comes from K2 (scalars).
+template <int C, int T>
+__device__ __forceinline__ void fir_lpc_dot8(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
+                                             const int32_t *__restrict__ cp)
+{
+    using Img = SmpImg<C, T>;
+    static_assert(Img::V4 && C % 8 == 0, "fir_lpc_dot8: runs of 8 or 16");
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    const int32_t *mine = e.l.smp + e.tid * Img::CS;
+    const s2 q0 = __builtin_bit_cast(s2, cp[0]), q1 = __builtin_bit_cast(s2, cp[1]);
+    const s2 q2 = __builtin_bit_cast(s2, cp[2]), q3 = __builtin_bit_cast(s2, cp[3]);
+#pragma unroll
+    for (int ob = 0; ob < C; ob += 8) {
+        __builtin_amdgcn_sched_barrier(0);
+        int32_t W[16];                                     // samples ob-8 .. ob+7
+#pragma unroll
+        for (int m4 = 0; m4 < 16; m4 += 4) {
+            const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob - 8 + m4));
+            W[m4] = v.x; W[m4 + 1] = v.y; W[m4 + 2] = v.z; W[m4 + 3] = v.w;
+        }
+        s2 R[14];                                          // R[m] = (x[ob-8+m], x[ob-7+m])
+#pragma unroll
+        for (int m = 0; m < 14; m++)
+            R[m] = __builtin_bit_cast(s2, (int32_t)__builtin_amdgcn_perm((uint32_t)W[m + 1], (uint32_t)W[m], 0x05040100u));
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            // taps (1,2) use x[o-2], x[o-1] = R at window index o+6; (3,4): o+4; (5,6): o+2; (7,8): o
+            int32_t acc = __builtin_amdgcn_sdot2(R[o + 6], q0, 0, false);
+            acc = __builtin_amdgcn_sdot2(R[o + 4], q1, acc, false);
+            acc = __builtin_amdgcn_sdot2(R[o + 2], q2, acc, false);
+            acc = __builtin_amdgcn_sdot2(R[o], q3, acc, false);
+            r[ob + o] = (int32_t)((uint32_t)W[8 + o] - (uint32_t)(acc >> shift));
+        }
+    }
+    if (e.i0 < order) {
+#pragma unroll
+        for (int o = 0; o < C; o++)
+            if (e.i0 + o < order) r[o] = mine[Img::off(o)];
+    }
+}
+
+// optimize.c:34-68 encode_residual_fixed on the thread's run.  The reference
+// computes in long long and stores to int32: the low 32 bits, which wrapping
+// 32-bit arithmetic yields directly.
+template <int C, int T>
+__device__ __forceinline__ void fir_fixed(const FastCtx<C, T> &e, int32_t (&r)[C], int order)
+{
+    using Img = SmpImg<C, T>;
+    const FastLds &l = e.l;
+    const int32_t *mine = l.smp + e.tid * Img::CS;
+    uint32_t h[4];
+    uint32_t xs[C];
+    if constexpr (Img::V4) {
+        const int4 p = *reinterpret_cast<const int4 *>(mine + Img::off(-4));      // samples -4 .. -1
+        h[0] = (uint32_t)p.w; h[1] = (uint32_t)p.z; h[2] = (uint32_t)p.y; h[3] = (uint32_t)p.x;
+#pragma unroll
+        for (int o = 0; o < C; o += 4) {
+            const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(o));
+            xs[o] = (uint32_t)v.x; xs[o + 1] = (uint32_t)v.y; xs[o + 2] = (uint32_t)v.z; xs[o + 3] = (uint32_t)v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) h[k] = (uint32_t)mine[Img::off(-1 - k)];
+#pragma unroll
+        for (int o = 0; o < C; o++) xs[o] = (uint32_t)mine[Img::off(o)];
+    }
+#pragma unroll
+    for (int o = 0; o < C; o++) {
+        const uint32_t x0 = xs[o];
+        uint32_t acc;
+        if (order == 0) acc = x0;
+        else if (order == 1) acc = x0 - h[0];
+        else if (order == 2) acc = x0 - 2u * h[0] + h[1];
+        else if (order == 3) acc = x0 - 3u * h[0] + 3u * h[1] - h[2];
+        else acc = x0 - 4u * h[0] + 6u * h[1] - 4u * h[2] + h[3];
+        r[o] = (int32_t)acc;
+        h[3] = h[2]; h[2] = h[1]; h[1] = h[0]; h[0] = x0;
+    }
+    if (e.i0 < order) {
+#pragma unroll
+        for (int o = 0; o < C; o++)
+            if (e.i0 + o < order) r[o] = mine[Img::off(o)];
+    }
+}
+
+// rice.c:122 folded residuals.  They stay in registers for the emit; the warm-up
+// samples (partition 0 of every level starts at `order`, rice.c:85-94) are
+// zeroed, which only the first threads have to do.
+template <int C, int T>
+__device__ __forceinline__ void fold_residuals(const FastCtx<C, T> &e, const int32_t (&r)[C],
+                                               uint32_t (&u)[C], int order)
+{
+#pragma unroll
+    for (int o = 0; o < C; o++) u[o] = zigzag32(r[o]);
+    if (e.i0 < order) {
+#pragma unroll
+        for (int o = 0; o < C; o++)
+            if (e.i0 + o < order) u[o] = 0u;
+    }
+}
+
+// rice.c:105-187 on the residuals in r[]; all threads call it.
+template <int C, int T>
+__device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, const int32_t (&r)[C],
+                                                     uint32_t (&u)[C], int order, bool lpc,
+                                                     int *porder_out, int *method_out)
+{
+    constexpr int LT = clog2(T);                      // the thread level
+    const FastLds &l = e.l;
+    const int n = e.n, tid = e.tid, lane = e.lane;
+    const int pmin = clamp_porder(e.pmin_req, n, order);
+    const int pmax = clamp_porder(e.pmax_req, n, order);
+
+    fold_residuals<C, T>(e, r, u, order);
+    // thread-level sum
+    unsigned long long v;
+    if (e.obits <= 31 - clog2(C)) {
+        // C folded values below 2^(32 - log2 C) each: the thread's sum fits 32 bits
+        uint32_t v32 = 0;
+#pragma unroll
+        for (int o = 0; o < C; o++) v32 += u[o];
+        v = v32;
+    } else {
+        v = 0;
+#pragma unroll
+        for (int o = 0; o < C; o++) v += u[o];
+    }
+
+    // (callers guarantee a barrier between the previous search's reads of
+    // lvl_bits/lvl_meth and this reset)
+    if (tid < 12) { l.lvl_bits[tid] = 0; l.lvl_meth[tid] = 0; }
+    // levels LT .. LT-6 inside the wave: after s steps, lanes with the low s
+    // bits clear hold the sums of level LT-s.  Steps 1,2,4,8 stay inside a
+    // 16-lane row (DPP row_shl, no LDS); 16 and 32 cross rows.
+#define PYR_STORE(S_)                                                                       \
+    do {                                                                                    \
+        const int lev_ = LT - (S_);                                                         \
+        if (lev_ <= pmax && lev_ >= pmin && lev_ <= 8 && (lane & ((1 << (S_)) - 1)) == 0)   \
+            l.sums[(1 << lev_) - 1 + (tid >> (S_))] = v;                                    \
+    } while (0)
+    PYR_STORE(0); v += row_shl_u64<1>(v);
+    PYR_STORE(1); v += row_shl_u64<2>(v);
+    PYR_STORE(2); v += row_shl_u64<4>(v);
+    PYR_STORE(3); v += row_shl_u64<8>(v);
+    PYR_STORE(4); v += __shfl_down(v, 16, WAVE);
+    PYR_STORE(5); v += __shfl_down(v, 32, WAVE);
+    PYR_STORE(6);
+#undef PYR_STORE
+    if (lane == 0) l.wtot[e.wv] = v;                 // level LT-6 node
+    __syncthreads();
+    STAMP(4);
+    STAMP(5);
+    {
+        // one thread per (level, partition) node.  Levels above the waves
+        // (LT-7 .. 0) are summed here from the per-wave totals.
+        constexpr int NW = T / WAVE;
+        const int first = (1 << pmin) - 1, last = (2 << pmax) - 2;
+        for (int q = first + tid; q <= last; q += T) {
+            const int p = ilog2_dev((uint32_t)(q + 1));
+            const int jn = q + 1 - (1 << p);
+            const int cnt = (n >> p) - (jn == 0 ? order : 0);
+            unsigned long long sum;
+            if (p <= LT - 7) {
+                const int span = NW >> p;              // waves per node
+                sum = 0;
+                for (int w = 0; w < span; w++) sum += l.wtot[jn * span + w];
+            } else {
+                sum = l.sums[q];
+            }
+            uint32_t b;
+            const int k = rice_k_fast(sum, cnt, &b);
+            l.kpar[q] = k;
+            atomicAdd(&l.lvl_bits[p], b);
+            if (k > 14) atomicOr(&l.lvl_meth[0], 1u << p);      // one flag word: bit p = level p needs RICE2
+        }
+    }
+    __syncthreads();
+    STAMP(6);
+    // rice.c:127-138, evaluated redundantly by every wave (no broadcast
+    // barrier).  The inputs are workgroup-uniform: readfirstlane moves them to
+    // SGPRs so that the comparison chain runs on the scalar unit.
+    uint32_t lb[9];
+#pragma unroll
+    for (int p = 0; p < 9; p++) lb[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.lvl_bits[p]);
+    const uint32_t lmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.lvl_meth[0]);
+    int bp = pmin;
+    uint32_t best = 0, method = 0;
+#pragma unroll
+    for (int p = 0; p < 9; p++) {
+        const uint32_t b = lb[p] + 4u * (1u << p);
+        if (p >= pmin && p <= pmax && (p == pmin || b <= best)) { best = b; bp = p; method = (lmask >> p) & 1u; }
+    }
+    // rice.c:157-171
+    uint32_t bits = (uint32_t)(order * e.obits + 2);
+    if (lpc) bits += (uint32_t)(4 + 5 + order * e.precision);
+    bits += best;
+    bits += method + 4u;
+    *porder_out = bp;
+    *method_out = (int)method;
+    STAMP(7);
+    return bits;
+}
+
+// optimize.c:170-181 for the fixed predictors: the size estimates of all orders
+// min_order..max_order (<= 4) from ONE pass over the samples.  The residual of order
+// k+1 is the first difference of the residual of order k (optimize.c:34-68 written
+// out), so a thread forms all five from its run and four samples of history, folds
+// them (rice.c:122) and keeps five sums; one in-wave pyramid, one node pass and one
+// level selection then serve all orders (five separate searches cost five times the
+// barriers and LDS traffic).  Returns the order the reference picks (first strict
+// minimum from min_order upward) together with its Rice result: the caller only has
+// to form that order's residuals once more.  Needs pmax_req <= 5 (64 heap nodes per
+// order).  LDS use: l.sums[k * 64 + node], wave totals l.sums[320 + k * 16 + wave],
+// level bits l.kpar[k * 9 + p], RICE2 flags l.kpar[48 + k], parameters of every
+// node l.kpar[64 + k * 64 + node] (the winner's move to l.kpar[node] at the end).
+template <int C, int T>
+__device__ __forceinline__ int fixed_search5(const FastCtx<C, T> &e, int min_order, int max_order,
+                                             uint32_t *bits_out, int *porder_out, int *method_out)
+{
+    using Img = SmpImg<C, T>;
+    constexpr int LT = clog2(T);
+    constexpr int NW = T / WAVE;
+    const FastLds &l = e.l;
+    const int n = e.n, tid = e.tid, lane = e.lane;
+    const int32_t *mine = l.smp + tid * Img::CS;
+
+    uint32_t xs[C], h[4];
+    if constexpr (Img::V4) {
+        const int4 p = *reinterpret_cast<const int4 *>(mine + Img::off(-4));      // samples -4 .. -1
+        h[0] = (uint32_t)p.w; h[1] = (uint32_t)p.z; h[2] = (uint32_t)p.y; h[3] = (uint32_t)p.x;
+#pragma unroll
+        for (int o = 0; o < C; o += 4) {
+            const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(o));
+            xs[o] = (uint32_t)v.x; xs[o + 1] = (uint32_t)v.y; xs[o + 2] = (uint32_t)v.z; xs[o + 3] = (uint32_t)v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) h[k] = (uint32_t)mine[Img::off(-1 - k)];
+#pragma unroll
+        for (int o = 0; o < C; o++) xs[o] = (uint32_t)mine[Img::off(o)];
+    }
+    // differences of orders 1..3 at the sample in front of the run
+    uint32_t p1 = h[0] - h[1];
+    uint32_t p2 = h[0] - 2u * h[1] + h[2];
+    uint32_t p3 = h[0] - 3u * h[1] + 3u * h[2] - h[3];
+    uint32_t p0 = h[0];
+
+    // folded sums per order; a folded value is below 2^(obits+4)
+    const bool sum32 = e.obits + 4 + clog2(C) <= 32;
+    unsigned long long v[5];
+    uint32_t a32[5] = {0, 0, 0, 0, 0};
+    unsigned long long a64[5] = {0, 0, 0, 0, 0};
+    const bool head = e.i0 < 4;                      // this run holds warm-up samples of some order
+#pragma unroll
+    for (int o = 0; o < C; o++) {
+        const uint32_t d0 = xs[o];
+        const uint32_t d1 = d0 - p0;
+        const uint32_t d2 = d1 - p1;
+        const uint32_t d3 = d2 - p2;
+        const uint32_t d4 = d3 - p3;
+        p0 = d0; p1 = d1; p2 = d2; p3 = d3;
+        uint32_t z[5] = {zigzag32((int32_t)d0), zigzag32((int32_t)d1), zigzag32((int32_t)d2),
+                         zigzag32((int32_t)d3), zigzag32((int32_t)d4)};
+        if (head) {
+#pragma unroll
+            for (int k = 1; k < 5; k++)
+                if (e.i0 + o < k) z[k] = 0u;         // rice.c:85-94: partition 0 starts at `order`
+        }
+        if (sum32) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) a32[k] += z[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; k++) a64[k] += z[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = sum32 ? (unsigned long long)a32[k] : a64[k];
+
+    // partition-order window over all orders: order 0 has the loosest clamp, the
+    // highest order the tightest (rice.c:148-155)
+    const int pmin_lo = clamp_porder(e.pmin_req, n, max_order);
+    const int pmax_hi = clamp_porder(e.pmax_req, n, min_order);
+
+    if (tid < 64) l.kpar[tid] = 0;                   // level bits and RICE2 flags
+#define PYR5_STORE(S_)                                                                      \
+    do {                                                                                    \
+        const int lev_ = LT - (S_);                                                         \
+        if (lev_ <= pmax_hi && lev_ >= pmin_lo && (lane & ((1 << (S_)) - 1)) == 0) {        \
+            _Pragma("unroll") for (int k = 0; k < 5; k++)                                   \
+                l.sums[k * 64 + (1 << lev_) - 1 + (tid >> (S_))] = v[k];                    \
+        }                                                                                   \
+    } while (0)
+    // a wave's total is below 2^(obits + 4 + log2(64 C)): in 32 bits one DPP add per step
+    const bool wave32 = e.obits + 4 + clog2(C) + 6 <= 32;
+    if (wave32) {
+        uint32_t w[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) w[k] = (uint32_t)v[k];
+#define PYR5_STEP32(S_, CTRL_)                                                              \
+    do {                                                                                    \
+        PYR5_STORE(S_);                                                                     \
+        _Pragma("unroll") for (int k = 0; k < 5; k++) { w[k] += dpp_u32<CTRL_>(w[k]); v[k] = w[k]; } \
+    } while (0)
+        PYR5_STEP32(0, 0x101);
+        PYR5_STEP32(1, 0x102);
+        PYR5_STEP32(2, 0x104);
+        PYR5_STEP32(3, 0x108);
+#undef PYR5_STEP32
+        PYR5_STORE(4);
+#pragma unroll
+        for (int k = 0; k < 5; k++) { w[k] += (uint32_t)__shfl_down((int)w[k], 16, WAVE); v[k] = w[k]; }
+        PYR5_STORE(5);
+#pragma unroll
+        for (int k = 0; k < 5; k++) { w[k] += (uint32_t)__shfl_down((int)w[k], 32, WAVE); v[k] = w[k]; }
+        PYR5_STORE(6);
+    } else {
+        PYR5_STORE(0);
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] += row_shl_u64<1>(v[k]);
+        PYR5_STORE(1);
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] += row_shl_u64<2>(v[k]);
+        PYR5_STORE(2);
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] += row_shl_u64<4>(v[k]);
+        PYR5_STORE(3);
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] += row_shl_u64<8>(v[k]);
+        PYR5_STORE(4);
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] += __shfl_down(v[k], 16, WAVE);
+        PYR5_STORE(5);
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] += __shfl_down(v[k], 32, WAVE);
+        PYR5_STORE(6);
+    }
+#undef PYR5_STORE
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) l.sums[320 + k * 16 + e.wv] = v[k];
+    }
+    __syncthreads();
+
+    {
+        // one thread per (order, level, partition) node
+        const int first = (1 << pmin_lo) - 1, last = (2 << pmax_hi) - 2;
+        const int nn = last - first + 1;
+        for (int it = tid; it < 5 * nn; it += T) {
+            const int k = it / nn;
+            const int q = first + (it - k * nn);
+            const int p = ilog2_dev((uint32_t)(q + 1));
+            const int jn = q + 1 - (1 << p);
+            const int cnt = (n >> p) - (jn == 0 ? k : 0);
+            unsigned long long sum;
+            if (p <= LT - 7) {
+                const int span = NW >> p;              // waves per node
+                sum = 0;
+                for (int w = 0; w < span; w++) sum += l.sums[320 + k * 16 + jn * span + w];
+            } else {
+                sum = l.sums[k * 64 + q];
+            }
+            uint32_t b;
+            const int kk = rice_k_fast(sum, cnt, &b);
+            l.kpar[64 + k * 64 + q] = kk;
+            atomicAdd(reinterpret_cast<uint32_t *>(&l.kpar[k * 9 + p]), b);
+            if (kk > 14) atomicOr(reinterpret_cast<uint32_t *>(&l.kpar[48 + k]), 1u << p);
+        }
+    }
+    __syncthreads();
+
+    // rice.c:127-138 and :157-171 per order, optimize.c:171-180 across them;
+    // evaluated by every thread from workgroup-uniform LDS words
+    int best = min_order, best_p = 0, best_m = 0;
+    uint32_t best_bits = 0;
+    for (int k = min_order; k <= max_order; k++) {
+        const int pmin = clamp_porder(e.pmin_req, n, k);
+        const int pmax = clamp_porder(e.pmax_req, n, k);
+        const uint32_t lmask = (uint32_t)__builtin_amdgcn_readfirstlane(l.kpar[48 + k]);
+        uint32_t lb = 0, method = 0;
+        int bp = pmin;
+        for (int p = pmin; p <= pmax; p++) {
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(l.kpar[k * 9 + p]) + 4u * (1u << p);
+            if (p == pmin || b <= lb) { lb = b; bp = p; method = (lmask >> p) & 1u; }
+        }
+        const uint32_t bits = (uint32_t)(k * e.obits + 2) + lb + method + 4u;
+        if (k == min_order || bits < best_bits) { best_bits = bits; best = k; best_p = bp; best_m = (int)method; }
+    }
+    // the winner's parameters to where the emit and the info record read them
+    __syncthreads();                                 // level words (l.kpar[0..52]) fully read
+    if (tid < 64) l.kpar[tid] = l.kpar[64 + best * 64 + tid];
+    __syncthreads();
+    *bits_out = best_bits;
+    *porder_out = best_p;
+    *method_out = best_m;
+    return best;
+}
+
+// OR `len` (<= 31) bits of val into the MSB-first bit string at bit `pos` of a
+// zeroed LDS window, 32-bit arithmetic only; words outside [0, nw) are skipped.
+__device__ __forceinline__ void put_bits32(uint32_t *win, int nw, long long pos, int len, uint32_t val)
+{
+    const long long wi = pos >> 5;
+    const int off = (int)(pos & 31);
+    const int room = 32 - off;
+    if (len <= room) {
+        if (wi >= 0 && wi < nw) atomicOr(&win[wi], val << (room - len));
+    } else {
+        const int spill = len - room;
+        if (wi >= 0 && wi < nw) atomicOr(&win[wi], val >> spill);
+        if (wi + 1 >= 0 && wi + 1 < nw) atomicOr(&win[wi + 1], val << (32 - spill));
+    }
+}
+
+// MODE 0: the MAX / EST order methods (one quantised row, known before the kernel
+// starts) -- the lean instance the headline workload runs; MODE 1: fixed predictors
+// only (prediction_type FIXED: no LPC code, no fp64); MODE 2: everything --
+// FIXED / NONE prediction and the order-search methods.
+template <int C, int T, int MODE>
+// At least 4 waves per SIMD (<= 128 VGPRs).  The kernel is bound by vector-ALU
+// issue (PMC: ~910 VALU instructions per wave, > 80 % of the issue slots), so what
+// pays is fewer instructions, not more waves: MODE 0 needs 96 VGPRs and runs five
+// workgroups per CU (-3 %); forcing MODE 2 to 96 spills and is slower.
+// Geometry for n = 4096, measured: (C,T) = (16,256) 94 us, (8,512) 137, (4,1024)
+// 256, (32,128) 115 (206 VGPRs): cross-wave phases grow with T, serial ones with C.
+__global__ __launch_bounds__(T, (MODE == 2 || C >= 16) ? 4 : 5)   // VGPR cap per waves/SIMD: 4 -> 128, 5 -> 96
+void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ smp_all,
+                   const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
+                   const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,
+                   fhip_subframe_info *__restrict__ info,
+                   int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
+                   int narrow_ok)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    size_t off[12];
+    fast_lds_layout(n, SmpImg<C, T>::SIZE, off);
+    FastCtx<C, T> e;
+    e.l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
+    e.l.coefd = reinterpret_cast<double *>(lds_raw + off[1]);
+    e.l.wtot = reinterpret_cast<unsigned long long *>(lds_raw + off[2]);
+    e.l.smp = reinterpret_cast<int32_t *>(lds_raw + off[3]);
+    e.l.kpar = reinterpret_cast<int32_t *>(lds_raw + off[4]);
+    e.l.lvl_bits = reinterpret_cast<uint32_t *>(lds_raw + off[5]);
+    e.l.lvl_meth = reinterpret_cast<uint32_t *>(lds_raw + off[6]);
+    e.l.coef = reinterpret_cast<int32_t *>(lds_raw + off[7]);
+    e.l.misc = reinterpret_cast<int32_t *>(lds_raw + off[8]);
+    e.l.trial = reinterpret_cast<uint32_t *>(lds_raw + off[9]);
+    e.l.bits = reinterpret_cast<uint32_t *>(lds_raw + off[10]);
+    const FastLds &l = e.l;
+
+    // fp64 rounding toward -inf for the whole kernel (MODE[3:2] = 2): every fp64
+    // operation in here is exact except the one fma in fir_lpc that wants a floor.
+    // As inline asm: after the builtin the compiler re-asserts the default mode in
+    // front of the next fp64 instruction.
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2" ::: "memory");
+
+    const int tid = threadIdx.x;
+    e.n = n; e.tid = tid; e.lane = tid & 63; e.wv = tid >> 6;
+    e.i0 = tid * C;
+    e.precision = P.lpc_precision;
+    e.pmin_req = P.min_partition_order;
+    e.pmax_req = P.max_partition_order;
+
+    // MAX / EST: the one row the reference quantises is known before the
+    // search starts and comes compact from K2
+    constexpr bool MULTI = MODE != 0;
+    constexpr bool HAS_LPC = MODE != 1;
+    constexpr bool pre_row = !MULTI;     // launcher: prediction_type == 2, n > max order, order method <= 1
+
+    // One workgroup per subframe (a persistent variant that prefetched the next
+    // subframe into registers measured slower: the hardware's own dispatch of a
+    // fresh workgroup per subframe balances better and costs no VGPRs).
+    const int s = blockIdx.x;
+    int32_t xn[C];
+    int32_t first_n, obits_n, fcoef_n = 0, fshift_n = 0, forder_n = 0, fcabs_n = 0, magbits_n = -1;
+    {
+        const int32_t *srcp = smp_all + (size_t)s * n;
+        // K0 may have stored this row as int16 (info.reserved, honoured only when the
+        // launcher says the flag is K0's): half the loads, one sign extension per sample
+        const int nflag = (C % 8 == 0 && narrow_ok) ? info[s].reserved : 0;     // 0, or 1 + bit length of max |x|
+        const bool narrow = nflag != 0;
+        magbits_n = nflag - 1;
+        if (C % 8 == 0 && narrow) {
+            const int4 *src4 = reinterpret_cast<const int4 *>(reinterpret_cast<const int16_t *>(srcp) + e.i0);
+#pragma unroll
+            for (int q = 0; q < C / 8; q++) {
+                const int4 t4 = src4[q];
+                xn[8 * q] = (int32_t)(int16_t)t4.x;     xn[8 * q + 1] = t4.x >> 16;
+                xn[8 * q + 2] = (int32_t)(int16_t)t4.y; xn[8 * q + 3] = t4.y >> 16;
+                xn[8 * q + 4] = (int32_t)(int16_t)t4.z; xn[8 * q + 5] = t4.z >> 16;
+                xn[8 * q + 6] = (int32_t)(int16_t)t4.w; xn[8 * q + 7] = t4.w >> 16;
+            }
+            first_n = (int32_t)*reinterpret_cast<const int16_t *>(srcp);
+        } else if (C % 4 == 0) {
+            // 16-byte lane accesses of the thread's own run
+            const int4 *src4 = reinterpret_cast<const int4 *>(srcp + e.i0);
+#pragma unroll
+            for (int q = 0; q < C / 4; q++) {
+                const int4 t4 = src4[q];
+                xn[4 * q] = t4.x; xn[4 * q + 1] = t4.y; xn[4 * q + 2] = t4.z; xn[4 * q + 3] = t4.w;
+            }
+        } else {
+            // runs of 3 or 9 samples: coalesced dword loads, element tid + T*q
+#pragma unroll
+            for (int q = 0; q < C; q++) xn[q] = srcp[tid + T * q];
+        }
+        if (!narrow) first_n = srcp[0];
+        obits_n = info[s].obits;
+        if (pre_row) {
+            const int32_t *f = fin_all + (size_t)s * FIN_STRIDE;
+            fcoef_n = f[tid & 31];
+            fshift_n = f[32];
+            forder_n = f[33];
+            fcabs_n = f[34];
+        }
+    }
+  {
+    fhip_subframe_info *out = &info[s];
+    e.obits = obits_n;
+    const int fshift = fshift_n, forder = forder_n;
+
+    STAMP(0);
+    // ---- stage this subframe in LDS ------------------------------------------
+    // "all samples equal the first" (CONSTANT, optimize.c:143-151) is max == min
+    // == first: running max / min cost one three-input instruction per two samples
+    int differs = 0;
+    {
+        const int32_t first = first_n;
+        int32_t mx = first, mn = first;
+#pragma unroll
+        for (int o = 0; o < C; o++) {
+            const int32_t v = xn[o];
+            // own-run mapping: sample i0 + o; coalesced mapping: sample tid + T*o
+            if (C % 4 != 0)       // coalesced mapping: this register holds sample tid + T*o of the block
+                l.smp[SmpImg<C, T>::at((tid + T * o) / C + SmpImg<C, T>::COL0, (tid + T * o) % C)] = v;
+            mx = max(mx, v);
+            mn = min(mn, v);
+        }
+        differs = (mx != mn);
+        if constexpr (C % 4 == 0) {
+            // own-run mapping: the registers are samples i0 .. i0+C-1: 16-byte stores
+#pragma unroll
+            for (int g4 = 0; g4 < C; g4 += 4)
+                *reinterpret_cast<int4 *>(l.smp + tid * 4 + SmpImg<C, T>::off(g4)) =
+                    make_int4(xn[g4], xn[g4 + 1], xn[g4 + 2], xn[g4 + 3]);
+        }
+    }
+    // zeros in front: columns 0 .. COL0-1 of every row
+    if (tid < SmpImg<C, T>::COL0 * C) l.smp[SmpImg<C, T>::at(tid / C, tid % C)] = 0;
+    // the first emit window is cleared here, under the shadow of the loads above
+    const int wwords = fast_window_words(n);
+    if (bits_out) for (int q = tid; q < wwords / 4; q += T) reinterpret_cast<uint4 *>(l.bits)[q] = make_uint4(0, 0, 0, 0);
+    if (tid < 16) l.coefd[32 + tid] = 0.0;
+    if (pre_row && tid < FHIP_MAX_ORDER) {
+        l.coef[tid] = fcoef_n;
+        l.coefd[tid] = (double)fcoef_n;
+    }
+    const bool constant = (__syncthreads_or(differs) == 0);
+    STAMP(1);
+
+    int32_t r[C];                        // residuals of the current candidate
+    uint32_t u[C];                       // ... folded (rice.c:122), warm-up zeroed: what the emit reads
+    int type, type_code, order = 0, shift = 0;
+    uint32_t est_bits = 0;
+    bool has_rice = false;
+    const int32_t *crow_base = coefs_all + (size_t)s * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
+    const int32_t *srow = shift_all + (size_t)s * FHIP_MAX_ORDER;
+
+    // decision tree of encode_residual() (optimize.c:124-276): same candidate
+    // loop as k_encode, every variable workgroup-uniform
+    enum { T_CONST, T_VERB, T_FIXED, T_LPC } tree;
+    if (constant) tree = T_CONST;
+    else if (!MULTI) tree = T_LPC;
+    else if (MODE == 1) tree = T_FIXED;                     // launcher: prediction_type == 1, n >= 5
+    else if (n < 5 || P.prediction_type == 0) tree = T_VERB;
+    else if (P.prediction_type == 1 || n <= P.max_prediction_order) tree = T_FIXED;
+    else tree = T_LPC;
+
+    const int omethod = MULTI ? P.order_method : 0;
+    const int min_order = P.min_prediction_order;
+    const int max_order = (tree == T_FIXED) ? min(P.max_prediction_order, 4) : P.max_prediction_order;
+
+    int it = 0, best = 0;
+    uint32_t best_bits = 0, last_bits = 0;
+    bool have_best = false;
+    int lg_step = 16, lg_last = 0, lg_pos = 3;
+    bool final_pass = false;             // MAX / EST: the one row is the result
+    int porder = 0, method = 0;          // of the most recent Rice search
+    // (Keeping the winner's Rice result instead of searching it again after the
+    // order search -- optimize.c:183-187, :265-274 -- was measured: the extra live
+    // state costs a wave of occupancy and the kernel ends up 15 % slower.)
+
+    if (tree == T_FIXED) { it = min_order; best = min_order; }
+    bool five_wide = false;
+    if constexpr (MODE == 1) {
+        // all fixed orders from one pass; the winner is then encoded like a single candidate
+        if (tree == T_FIXED && max_order > min_order && max_order <= 4 && min_order >= 0 &&
+            P.max_partition_order <= 5) {
+            five_wide = true;
+        }
+    }
+    if (HAS_LPC && tree == T_LPC) {
+        if (omethod <= 1) { best = forder - 1; final_pass = true; }     // MAX: max_order, EST: est
+        else if (omethod <= 4) { it = (1 << ((omethod - 1) & 7)) - 1; best = max_order - 1; }
+        else if (omethod == 5) { it = 0; best = 0; }
+        else {
+            best = min_order - 1 + (max_order - min_order) / 3;
+            if (tid < FHIP_MAX_ORDER) l.trial[tid] = 0xFFFFFFFFu;
+            __syncthreads();
+            lg_step = 32;
+        }
+    }
+
+    if (tree == T_CONST || tree == T_VERB) {
+        type = type_code = (tree == T_CONST) ? FHIP_SUB_CONSTANT : FHIP_SUB_VERBATIM;
+        est_bits = (uint32_t)(tree == T_CONST ? e.obits : e.obits * n);
+    } else {
+        if constexpr (MODE == 1) {
+            if (five_wide) {
+                best = fixed_search5<C, T>(e, min_order, max_order, &est_bits, &porder, &method);
+                fir_fixed<C, T>(e, r, best);
+                fold_residuals<C, T>(e, r, u, best);
+            }
+        }
+        if (!five_wide) for (;;) {
+            int cand = -1;
+            if (!final_pass) {
+                if (tree == T_FIXED) {
+                    if (it <= max_order) cand = it;
+                } else if (omethod <= 4) {
+                    if (it >= 0) {
+                        const int levels = 1 << ((omethod - 1) & 7);
+                        cand = min_order + (((max_order - min_order + 1) * (it + 1)) / levels) - 2;
+                        if (cand < 0) cand = 0;
+                    }
+                } else if (omethod == 5) {
+                    if (it < max_order) cand = it;
+                } else {
+                    for (;;) {
+                        if (lg_pos == 3) {
+                            lg_step >>= 1;
+                            if (lg_step == 0) break;
+                            lg_last = best;
+                            lg_pos = 0;
+                        }
+                        const int i = lg_last + (lg_pos - 1) * lg_step;
+                        lg_pos++;
+                        if (i < min_order - 1 || i >= max_order || l.trial[i] < 0xFFFFFFFFu) continue;
+                        cand = i;
+                        break;
+                    }
+                }
+                if (cand < 0) {
+                    if (tree == T_FIXED && best == max_order) { est_bits = last_bits; break; }
+                    final_pass = true;
+                }
+            }
+            if (final_pass) cand = best;
+
+            uint32_t b = 0;
+            if (MULTI && (!HAS_LPC || tree == T_FIXED)) {
+                fir_fixed<C, T>(e, r, cand);
+                __syncthreads();                      // previous search fully read
+                b = rice_search_fast<C, T>(e, r, u, cand, false, &porder, &method);
+            } else if constexpr (HAS_LPC) {
+                const int ord = cand + 1;
+                int cshift;
+                if (pre_row) {
+                    cshift = fshift;                  // coef/coefd were staged with the samples
+                } else {
+                    __syncthreads();                  // readers of coef/coefd/lvl_* are done
+                    if (tid < FHIP_MAX_ORDER) {
+                        const int32_t cv = (tid < ord) ? crow_base[cand * FHIP_MAX_ORDER + tid] : 0;
+                        l.coef[tid] = cv;
+                        l.coefd[tid] = (double)cv;
+                    }
+                    cshift = srow[cand];
+                    __syncthreads();
+                }
+                STAMP(2);
+                bool done = false;
+                if constexpr (C % 8 == 0) {
+                    // 16-bit samples and a prediction that cannot leave int32: packed dot products
+                    if (pre_row && ord <= 8 && magbits_n >= 0 &&
+                        ((unsigned long long)(uint32_t)fcabs_n << magbits_n) < (1ull << 31)) {
+                        fir_lpc_dot8<C, T>(e, r, ord, cshift, fin_all + (size_t)s * FIN_STRIDE + FIN_PAIRS);
+                        done = true;
+                    }
+                }
+                if (done) {
+                } else if (pre_row && ord <= 8)
+                    fir_lpc_o8<C, T>(e, r, ord, cshift,
+                                     reinterpret_cast<const double *>(fin_all + (size_t)s * FIN_STRIDE + FIN_DBL));
+                else
+                    fir_lpc<C, T>(e, r, ord, cshift);
+                STAMP(3);
+                b = rice_search_fast<C, T>(e, r, u, ord, true, &porder, &method);
+                STAMP(8);
+            }
+            if (final_pass) { est_bits = b; break; }
+
+            last_bits = b;
+            if (tree == T_FIXED) {
+                if (!have_best || b < best_bits) { best_bits = b; best = cand; }
+                it++;
+            } else if (omethod <= 4) {
+                if (!have_best) best_bits = b;
+                else if (b < best_bits) { best_bits = b; best = cand; }
+                it--;
+            } else if (omethod == 5) {
+                if (!have_best || b < best_bits) { best_bits = b; best = cand; }
+                it++;
+            } else {
+                if (tid == 0) l.trial[cand] = b;
+                __syncthreads();
+                if (b < l.trial[best]) best = cand;
+            }
+            have_best = true;
+
+        }
+        if (tree == T_FIXED) {
+            order = best;
+            type = FHIP_SUB_FIXED;
+            type_code = FHIP_SUB_FIXED | order;
+        } else {
+            order = best + 1;
+            shift = pre_row ? fshift : srow[best];
+            type = FHIP_SUB_LPC;
+            type_code = FHIP_SUB_LPC | (order - 1);
+        }
+        has_rice = true;
+    }
+
+    if (!has_rice) { porder = 0; method = 0; }
+
+    STAMP(9);
+    if (res_out) {
+        // FlacSubframe.residual: the samples themselves for CONSTANT / VERBATIM and
+        // for warm-up positions, else the fold undone (a bijection on 32 bits)
+        const int32_t *mine_s = l.smp + tid * SmpImg<C, T>::CS;
+#pragma unroll
+        for (int o = 0; o < C; o++) {
+            const int32_t back = (int32_t)((u[o] >> 1) ^ (0u - (u[o] & 1u)));
+            r[o] = (!has_rice || e.i0 + o < order) ? mine_s[SmpImg<C, T>::off(o)] : back;
+        }
+        if (C % 4 == 0) {
+            int4 *dst4 = reinterpret_cast<int4 *>(res_out + (size_t)s * n + e.i0);
+#pragma unroll
+            for (int q = 0; q < C / 4; q++)
+                dst4[q] = make_int4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+        } else {
+            int32_t *dst = res_out + (size_t)s * n + e.i0;
+#pragma unroll
+            for (int o = 0; o < C; o++) dst[o] = r[o];
+        }
+    }
+
+    // ---- encode.c:766-798 output_residual -----------------------------------
+    long long total_bits = 0;
+    if (has_rice) {
+        constexpr int LT = clog2(T);
+        const int pbits = 4 + method;
+        const int heap0 = (1 << porder) - 1;
+        const int tpp = LT - porder;                       // log2(threads per partition)
+        const int part = tid >> tpp;
+        const int k = l.kpar[heap0 + part];
+        const int k1 = k + 1;
+        const bool part_head = (part > 0) && ((tid & ((1 << tpp) - 1)) == 0);
+        // warm-up samples at the front of this thread's run (first threads only)
+        const int nwarm = min(max(order - e.i0, 0), C);
+        // the emit-side fold (bitio.h:128) differs from rice.c's for |x| >= 2^30
+        if (e.obits > 30) {
+#pragma unroll
+            for (int o = 0; o < C; o++)
+                u[o] = emit_fold32((int32_t)((u[o] >> 1) ^ (0u - (u[o] & 1u)))) & ((e.i0 + o < order) ? 0u : ~0u);
+        }
+        // codeword lengths of the run; in 32 bits unless a quotient is huge.
+        // A zeroed warm-up entry counts k+1 bits here, taken off again below.
+        uint32_t umax = 0;
+#pragma unroll
+        for (int o = 0; o < C; o++) umax = max(umax, u[o]);
+        const uint32_t longest = umax >> k;
+        // every codeword of the wave at most 32 bits: one flush test per codeword
+        const bool short_codes = !__any(longest + (uint32_t)k1 > 32u);
+        const bool tiny_codes = (C % 2 == 0) && !__any(longest + (uint32_t)k1 > 16u);
+        unsigned long long mine = (part_head ? pbits : 0) + (unsigned long long)((C - nwarm) * k1);
+        if (short_codes) {
+            uint32_t m32 = 0;
+#pragma unroll
+            for (int o = 0; o < C; o++) m32 += u[o] >> k;
+            mine += m32;
+        } else {
+#pragma unroll
+            for (int o = 0; o < C; o++) mine += (unsigned long long)(u[o] >> k);
+        }
+        // in-wave offsets: DPP scan in 32 bits unless some lane of the wave
+        // holds an absurdly long run (then the exact 64-bit shuffle scan)
+        unsigned long long incl;
+        if (__any(mine >> 24)) incl = wave_incl_scan_u64(mine, e.lane);
+        else incl = wave_incl_scan_u32_dpp((uint32_t)mine);
+        if (e.lane == 63) l.wtot[e.wv] = incl;
+        __syncthreads();
+        unsigned long long base = 6 + pbits;
+        unsigned long long tot = 6 + pbits;
+#pragma unroll
+        for (int w = 0; w < T / WAVE; w++) {
+            const unsigned long long wt = l.wtot[w];
+            if (w < e.wv) base += wt;
+            tot += wt;
+        }
+        const unsigned long long my_off = base + incl - mine;
+        total_bits = (tot > 0x7FFFFFFFull) ? 0x7FFFFFFFll : (long long)tot;
+        STAMP(10);
+
+        if (bits_out) {
+            if (tot > (unsigned long long)slot_bytes * 8ull) {
+                total_bits = -1;
+            } else {
+                uint32_t *dst32 = reinterpret_cast<uint32_t *>(bits_out + (size_t)s * slot_bytes);
+                const int nwords = (int)((tot + 31) >> 5);
+                // Every thread writes all C codewords, unconditionally.  A zeroed
+                // warm-up entry is the k+1-bit code of 0; the run of a thread that
+                // has some starts that many bits early, so those land in front of
+                // the thread's first real codeword -- i.e. in bits [.., 6+pbits) of
+                // the section (only threads at the start of partition 0 have warm-up
+                // samples), which thread 0 overwrites with the section header after
+                // the barrier.
+                const long long start = (long long)my_off - (long long)(nwarm * k1);
+                for (int wlo = 0; wlo < nwords; wlo += wwords) {
+                    const int nw = min(wwords, nwords - wlo);
+                    if (wlo > 0) {
+                        // later windows reuse the buffer (the first was cleared at the top)
+                        __syncthreads();
+                        for (int q = tid; q < (nw + 3) / 4; q += T) reinterpret_cast<uint4 *>(l.bits)[q] = make_uint4(0, 0, 0, 0);
+                        __syncthreads();
+                    }
+                    const long long rel = start - (long long)wlo * 32;
+                    // The thread's codewords form one contiguous bit run.  It is
+                    // assembled MSB-first in a 32-bit register and leaves a word at
+                    // a time by LDS OR (the run's first and last word are shared
+                    // with the neighbours; OR-ing the interior ones too costs the
+                    // same LDS issue slot as a store and needs no bookkeeping).
+                    uint32_t hi = 0;
+                    int nacc = (int)(rel & 31);
+                    int w = (int)(rel >> 5);
+                    // append a field of len <= 32 bits (val < 2^len; len 0 => val 0);
+                    // at most one word leaves
+                    auto field = [&](int len, uint32_t val) {
+                        const uint32_t a = val << ((32 - len) & 31);        // left-aligned
+                        const uint32_t head = a >> nacc;
+                        // a << (32 - nacc), and 0 for nacc == 0
+                        const uint32_t tail = __builtin_amdgcn_alignbit(a, 0u, (uint32_t)nacc);
+                        const int t = nacc + len;
+                        const uint32_t word = hi | head;
+                        const bool full = t >= 32;
+                        if (full && (unsigned)w < (unsigned)nw) atomicOr(&l.bits[w], word);
+                        hi = full ? tail : word;
+                        w += full ? 1 : 0;
+                        nacc = t & 31;
+                    };
+                    if (part_head) field(pbits, (uint32_t)k);
+                    const uint32_t kmask = (1u << k) - 1u, kbit = 1u << k;
+                    bool packed = false;
+                    if constexpr (C % 2 == 0) { if (tiny_codes) {
+                        packed = true;
+                        // every codeword of the wave <= 16 bits: two codewords are
+                        // one field of <= 32 bits (half the append/flush work)
+#pragma unroll
+                        for (int o = 0; o < C; o += 2) {
+                            const int l1 = (int)(u[o + 1] >> k) + k1;
+                            const uint32_t v0 = (u[o] & kmask) | kbit, v1 = (u[o + 1] & kmask) | kbit;
+                            field((int)(u[o] >> k) + k1 + l1, (v0 << l1) | v1);
+                        }
+                    } }
+                    if (packed) {
+                    } else if (short_codes) {
+                        // bitio.h:120-141: q zeros, a one, k low bits -- as one field
+                        // of q+k+1 <= 32 bits
+#pragma unroll
+                        for (int o = 0; o < C; o++)
+                            field((int)(u[o] >> k) + k1, (u[o] & kmask) | kbit);
+                    } else {
+#pragma unroll 2
+                        for (int o = 0; o < C; o++) {
+                            const uint32_t q = u[o] >> k;
+                            if (q >= 32u) {
+                                // long unary run: the pending word leaves, whole zero
+                                // words are skipped (the window is zero-filled)
+                                const long long adv = (long long)nacc + q;
+                                if (hi && (unsigned)w < (unsigned)nw) atomicOr(&l.bits[w], hi);
+                                hi = 0;
+                                w += (int)(adv >> 5);
+                                nacc = (int)(adv & 31);
+                            } else {
+                                field((int)q, 0u);
+                            }
+                            field(k1, (u[o] & kmask) | kbit);
+                        }
+                    }
+                    if (nacc > 0 && hi && (unsigned)w < (unsigned)nw) atomicOr(&l.bits[w], hi);
+                    __syncthreads();
+                    if (tid == 0 && wlo == 0) {
+                        // section header (encode.c:771-776): method, partition order,
+                        // first parameter; replaces whatever warm-up filler landed there
+                        const int hb = 6 + pbits;
+                        const uint32_t hdr = ((uint32_t)method << (4 + pbits)) | ((uint32_t)porder << pbits) |
+                                             (uint32_t)l.kpar[heap0];
+                        l.bits[0] = (l.bits[0] & (0xFFFFFFFFu >> hb)) | (hdr << (32 - hb));
+                    }
+                    STAMP(11);
+                    // 16 bytes per lane where whole quads of words are left (the LDS window
+                    // is 16-byte aligned; a slot need only be dword aligned, which is all a
+                    // global dwordx4 store asks for), single words for the last 1..3
+                    const int nq = nw >> 2;
+                    for (int q = tid; q < nq; q += T) {
+                        const uint4 v = reinterpret_cast<const uint4 *>(l.bits)[q];
+                        reinterpret_cast<uint4 *>(dst32 + wlo)[q] =
+                            make_uint4(__builtin_bswap32(v.x), __builtin_bswap32(v.y),
+                                       __builtin_bswap32(v.z), __builtin_bswap32(v.w));
+                    }
+                    if (tid < (nw & 3)) dst32[wlo + 4 * nq + tid] = __builtin_bswap32(l.bits[4 * nq + tid]);
+                }
+            }
+        }
+    }
+    STAMP(12);
+
+    if (tid == 0) {
+        out->type = type;
+        out->type_code = type_code;
+        out->order = order;
+        out->shift = shift;
+        out->rice_method = method;
+        out->porder = porder;
+        out->est_bits = est_bits;
+        out->rice_nbits = (int32_t)total_bits;
+        out->reserved = 0;
+    }
+    if (tid < FHIP_MAX_ORDER) {
+        out->coefs[tid] = (type == FHIP_SUB_LPC && tid < order) ? l.coef[tid] : 0;
+        const int nw = (type == FHIP_SUB_CONSTANT) ? 1 : order;
+        out->warmup[tid] = (tid < nw) ? l.smp[SmpImg<C, T>::at(tid / C + SmpImg<C, T>::COL0, tid % C)] : 0;
+    }
+    {
+        const int np = has_rice ? (1 << porder) : 0;
+        for (int q = tid; q < FHIP_MAX_PARTS; q += T) out->rparams[q] = (q < np) ? l.kpar[np - 1 + q] : 0;
+    }
+  }
+}
+
+
+}  // namespace
+
+size_t encode_lds_bytes(int n)
+{
+    if (n < 1 || n > FHIP_MAX_BLOCK) return 0;
+    size_t off[10];
+    return enc_lds_layout(n, off);
+}
+
+// Fast-path geometry for a block size: C samples per thread, T threads,
+// n = C*T, T a power of two >= 64.
+bool fast_geometry(const fhip_params &p, int n, int *C, int *T)
+{
+    if (n < 192 || n > FHIP_MAX_BLOCK) return false;
+    int odd = n, lg = 0;
+    while ((odd & 1) == 0) { odd >>= 1; lg++; }
+    int c, t;
+    if (odd == 1) {                       // 256 .. 16384
+        if (n >= 4096) { c = 16; t = n / 16; }
+        else if (n >= 2048) { c = 8; t = 256; }
+        else if (n >= 1024) { c = 4; t = 256; }
+        else if (n == 512) { c = 8; t = 64; }
+        else if (n == 256) { c = 4; t = 64; }
+        else return false;
+    } else if (odd == 9) {                // 576, 1152, 2304, 4608, 9216
+        // 256 threads where the block allows (measured at 4608: (18,256) 84 us, (9,512) 100)
+        c = 9; t = 1 << lg;
+        if (t >= 512) { c = 18; t >>= 1; }
+    } else if (odd == 3) {                // 192, 384, 768, 1536, ...
+        c = 3; t = 1 << lg;
+        if (t > 1024) { c = 0; }
+    } else {
+        return false;
+    }
+    if (const char *g = getenv("FHIP_K3_GEOM")) {     // measurements only: "C,T" of an instantiated pair
+        int gc = 0, gt = 0;
+        if (sscanf(g, "%d,%d", &gc, &gt) == 2 && gc * gt == n) { c = gc; t = gt; }
+    }
+    if (c == 0 || t < 64 || t > 1024) return false;
+    // every partition at least one thread wide at the finest level that can occur
+    if ((n >> p.max_partition_order) < c && odd == 1) return false;
+    *C = c; *T = t;
+    return true;
+}
+
+// True when every kernel of the pipeline that touches the sample rows understands
+// 16-bit rows for such a batch: the register K0 for stereo, the wave-typed K1 (or
+// no K1 at all) and a K3 fast-path geometry with runs of 8 or 16 samples.
+bool narrow_rows_ok(const fhip_params &p, int nsub, int n, bool lpc_path)
+{
+    static const bool off = getenv("FHIP_NO_NARROW") != nullptr;        // measurements only
+    if (off || p.channels != 2 || (n & 3) != 0 || n > 8192) return false;
+    int fc = 0, ft = 0;
+    if (!fast_geometry(p, n, &fc, &ft) || (fc % 8) != 0) return false;
+    if (lpc_path && !autocorr_is_wave_typed(nsub, n, p.max_prediction_order)) return false;
+    return true;
+}
+
+hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *smp,
+                         int nsub, int n, const int32_t *coefs, const int32_t *shift,
+                         const int32_t *opt_order, const int32_t *fin,
+                         fhip_subframe_info *info,
+                         int32_t *residual, uint8_t *bits, int64_t slot_bytes,
+                         int raw_order, int raw_lpc, bool narrow_ok)
+{
+    if (nsub == 0) return hipSuccess;
+    int fc = 0, ft = 0;
+    static const bool force_generic = getenv("FHIP_K3_GENERIC") != nullptr;    // measurements only
+    if (raw_order < 0 && !force_generic && fast_geometry(p, n, &fc, &ft)) {
+        size_t off[12];
+        size_t lds = 0;
+#define LAUNCH_FAST2(CC, TT, MM)                                                             \
+    do {                                                                                     \
+        lds = fast_lds_layout(n, (size_t)SmpImg<CC, TT>::SIZE, off);                         \
+        hipError_t er = hipFuncSetAttribute(                                                 \
+            reinterpret_cast<const void *>(&k_encode_pow2<CC, TT, MM>),                      \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        if (er != hipSuccess) return er;                                                     \
+        hipLaunchKernelGGL((k_encode_pow2<CC, TT, MM>), dim3(nsub), dim3(TT), lds, st, p, n, \
+                           nsub, smp, coefs, shift, opt_order, fin, info, residual, bits,    \
+                           (long long)slot_bytes, narrow_ok ? 1 : 0);                        \
+    } while (0)
+        // one quantised row known up front (MAX / EST): the lean instance
+        const bool single_row = (p.prediction_type == 2) && (n > p.max_prediction_order) && (p.order_method <= 1);
+        const bool fixed_only = (p.prediction_type == 1) && n >= 5;
+#define LAUNCH_FAST(CC, TT)                                                                  \
+    do {                                                                                     \
+        if (single_row) LAUNCH_FAST2(CC, TT, 0);                                             \
+        else if (fixed_only) LAUNCH_FAST2(CC, TT, 1);                                        \
+        else LAUNCH_FAST2(CC, TT, 2);                                                        \
+    } while (0)
+        const int key = fc * 10000 + ft;
+        switch (key) {
+        case 160256: LAUNCH_FAST(16, 256); break;
+        case 160512: LAUNCH_FAST(16, 512); break;
+        case 161024: LAUNCH_FAST(16, 1024); break;
+        case 80256: LAUNCH_FAST(8, 256); break;
+        case 40256: LAUNCH_FAST(4, 256); break;
+        case 80064: LAUNCH_FAST(8, 64); break;
+        case 40064: LAUNCH_FAST(4, 64); break;
+        case 90064: LAUNCH_FAST(9, 64); break;
+        case 180256: LAUNCH_FAST(18, 256); break;
+        case 180512: LAUNCH_FAST(18, 512); break;
+        case 90128: LAUNCH_FAST(9, 128); break;
+        case 90256: LAUNCH_FAST(9, 256); break;
+        case 30064: LAUNCH_FAST(3, 64); break;
+        case 30128: LAUNCH_FAST(3, 128); break;
+        case 30256: LAUNCH_FAST(3, 256); break;
+        case 30512: LAUNCH_FAST(3, 512); break;
+        case 31024: LAUNCH_FAST(3, 1024); break;
+        default: return hipErrorInvalidValue;
+        }
+#undef LAUNCH_FAST
+#undef LAUNCH_FAST2
+        return hipGetLastError();
+    }
+    const size_t lds = encode_lds_bytes(n);
+    if (lds == 0) return hipErrorInvalidValue;
+    const int chunk = (n + NT - 1) / NT;
+#define LAUNCH_ENC(CC)                                                                       \
+    do {                                                                                     \
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode<CC>),   \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                            (int)lds);                                       \
+        if (er != hipSuccess) return er;                                                     \
+        hipLaunchKernelGGL(k_encode<CC>, dim3(nsub), dim3(NT), lds, st, p, n, smp, coefs,    \
+                           shift, opt_order, info, residual, bits, (long long)slot_bytes,    \
+                           raw_order, raw_lpc);                                              \
+    } while (0)
+    if (chunk <= 16) LAUNCH_ENC(16);
+    else if (chunk <= 32) LAUNCH_ENC(32);
+    else LAUNCH_ENC(64);
+#undef LAUNCH_ENC
+    return hipGetLastError();
+}
+
+}  // namespace fhip

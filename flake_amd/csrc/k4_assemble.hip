@@ -1,0 +1,415 @@
+// k4_assemble.hip -- K4: whole FLAC frames on the device (encode.c:718-764, :800-917,
+// :949-964) and the VBS splitter (vbs.c:36-83).
+#include "device_util.h"
+
+namespace fhip {
+namespace {
+
+// ---------------------------------------------------------------------------
+// K4  k_assemble -- whole FLAC frames on the device
+// ---------------------------------------------------------------------------
+// One workgroup per frame turns the side information of K0..K3 and the packed
+// residual sections into the finished frame: frame header + CRC-8
+// (encode.c:718-764), subframe headers, warm-up samples, LPC header
+// (encode.c:800-905), the residual sections appended bit for bit, byte
+// alignment, CRC-16 (encode.c:907-917), and the verbatim fallback of
+// encode.c:949-964 when the frame would exceed its verbatim size or a section
+// did not fit its slot.
+//
+// The frame is a concatenation of a few bit strings ("segments"): the frame
+// header and one small prefix per subframe are built serially in LDS by one
+// thread each; the bodies are the residual slots in HBM (or, for VERBATIM
+// subframes, the samples themselves).  Every output dword is then produced by
+// exactly one thread from the segments that overlap it, so stores are plain and
+// coalesced.  CRC-16 is linear: each thread takes the CRC of a contiguous byte
+// chunk and the partial CRCs are merged in a log-step tree with the constants
+// x^(8*chunk*2^j) mod P.
+constexpr int ASM_MAX_SEG = 2 * FHIP_MAX_CH + 2;
+constexpr int ASM_PREFIX_BYTES = 224;     // 8+33 header bits, 32 warm-ups of <= 32 bits, 9 + 32*15 coef bits
+
+struct AsmSeg { int kind; int ch; long long nbits; long long dst; };   // kind: 0 LDS bytes, 1 rice slot, 2 verbatim samples
+
+struct MiniSink {                          // MSB-first writer into LDS bytes (serial, one thread)
+    uint8_t *buf; int nbits;
+    __device__ void put(int nb, uint32_t v)
+    {
+        for (int b = nb - 1; b >= 0; b--) {
+            const int pos = nbits++;
+            const uint32_t bit = (b < 32) ? ((v >> b) & 1u) : 0u;   // fields wider than 32 bits are zero-extended
+            if ((pos & 7) == 0) buf[pos >> 3] = 0;
+            buf[pos >> 3] |= (uint8_t)(bit << (7 - (pos & 7)));
+        }
+    }
+};
+
+__device__ __forceinline__ uint16_t crc16_mulmod(uint16_t a, uint16_t b)
+{
+    // a * b mod x^16 + x^15 + x^2 + 1 over GF(2)
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 15; i >= 0; i--) {
+        r <<= 1;
+        if (r & 0x10000u) r ^= 0x18005u;
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return (uint16_t)r;
+}
+
+__device__ __forceinline__ int32_t asm_sample(const int32_t *pcm_frame, int nch, int ch, int t,
+                                             int ch_mode, int wasted)
+{
+    // FlacSubframe.samples recomputed (encode.c:648-694, :558-593)
+    int32_t v;
+    if (nch == 2 && ch_mode != FHIP_CH_LEFT_RIGHT) {
+        const int32_t l = pcm_frame[2 * t], r = pcm_frame[2 * t + 1];
+        const int32_t side = (int32_t)((uint32_t)l - (uint32_t)r);
+        if (ch_mode == FHIP_CH_MID_SIDE) v = ch ? side : ((int32_t)((uint32_t)l + (uint32_t)r) >> 1);
+        else if (ch_mode == FHIP_CH_LEFT_SIDE) v = ch ? side : l;
+        else v = ch ? r : side;
+    } else {
+        v = pcm_frame[(size_t)t * nch + ch];
+    }
+    return v >> wasted;
+}
+
+__global__ __launch_bounds__(NT)
+void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
+                const fhip_subframe_info *__restrict__ info, const uint8_t *__restrict__ rice,
+                long long slot_bytes, uint8_t *__restrict__ frames, long long frame_stride,
+                int32_t *__restrict__ frame_bytes, uint32_t number_base, uint32_t number_step,
+                const uint32_t *__restrict__ numbers,
+                int sr_code0, int sr_code1, int bps_code, int verbatim_size)
+{
+    __shared__ uint8_t s_hdr[32];
+    __shared__ uint8_t s_prefix[FHIP_MAX_CH][ASM_PREFIX_BYTES];
+    __shared__ AsmSeg s_seg[ASM_MAX_SEG];
+    __shared__ int s_nseg, s_verbatim, s_hdr_bits;
+    __shared__ long long s_total_bits;
+    __shared__ uint16_t s_crc_tab[256];
+    __shared__ uint16_t s_part[NT];
+    __shared__ int s_info[FHIP_MAX_CH][8];       // type, type_code, order, shift, obits, wasted, rice_nbits, ch_mode
+
+    const int tid = threadIdx.x;
+    const int f = blockIdx.x;
+    const int nch = P.channels;
+    const fhip_subframe_info *fi = info + (size_t)f * nch;
+    const int32_t *pcm_frame = pcm + (size_t)f * n * nch;
+    uint8_t *out = frames + (size_t)f * frame_stride;
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+
+    // CRC-16 table (crc.c:24-44), one entry per thread
+    {
+        uint16_t c = (uint16_t)(tid << 8);
+#pragma unroll
+        for (int b = 0; b < 8; b++) c = (uint16_t)((c & 0x8000) ? ((c << 1) ^ 0x8005) : (c << 1));
+        s_crc_tab[tid] = c;
+    }
+    if (tid < nch) {
+        const fhip_subframe_info *i = &fi[tid];
+        s_info[tid][0] = i->type; s_info[tid][1] = i->type_code; s_info[tid][2] = i->order;
+        s_info[tid][3] = i->shift; s_info[tid][4] = i->obits; s_info[tid][5] = i->wasted;
+        s_info[tid][6] = i->rice_nbits; s_info[tid][7] = i->ch_mode;
+    }
+    __syncthreads();
+
+    // ---- does the frame take the verbatim fallback? (encode.c:949) -----------
+    if (tid == 0) {
+        // frame header (encode.c:718-764) + CRC-8
+        MiniSink hs{s_hdr, 0};
+        int bs0 = -1, bs1 = -1;
+        const int bs_tab[15] = {0, 192, 576, 1152, 2304, 4608, 0, 0, 256, 512, 1024, 2048, 4096, 8192, 16384};
+        for (int q = 0; q < 15; q++) if (n == bs_tab[q]) { bs0 = q; break; }
+        if (bs0 < 0) { bs0 = (n <= 256) ? 6 : 7; bs1 = n - 1; }
+        const int ch_mode = s_info[0][7];
+        const uint32_t number = numbers ? numbers[f] : number_base + (uint32_t)f * number_step;
+        hs.put(15, 0x7FFC);
+        hs.put(1, (uint32_t)P.allow_vbs);
+        hs.put(4, (uint32_t)bs0);
+        hs.put(4, (uint32_t)sr_code0);
+        hs.put(4, (uint32_t)(ch_mode == FHIP_CH_NOT_STEREO ? nch - 1 : ch_mode));
+        hs.put(3, (uint32_t)bps_code);
+        hs.put(1, 0);
+        if (number < 0x80) {
+            hs.put(8, number);
+        } else {
+            const int bytes = (ilog2_dev(number) + 4) / 5;          // encode.c:696-716
+            int sh = (bytes - 1) * 6;
+            hs.put(8, ((256u - (256u >> bytes)) | (number >> sh)) & 0xFFu);
+            while (sh >= 6) { sh -= 6; hs.put(8, 0x80u | ((number >> sh) & 0x3Fu)); }
+        }
+        if (bs1 >= 0) hs.put(bs1 < 256 ? 8 : 16, (uint32_t)bs1);
+        if (sr_code1 > 0) hs.put(sr_code1 < 256 ? 8 : 16, (uint32_t)sr_code1);
+        uint8_t c8 = 0;
+        for (int q = 0; q < (hs.nbits >> 3); q++) {
+            c8 ^= s_hdr[q];
+            for (int b = 0; b < 8; b++) c8 = (uint8_t)((c8 & 0x80) ? ((c8 << 1) ^ 0x07) : (c8 << 1));
+        }
+        hs.put(8, c8);
+        s_hdr_bits = hs.nbits;
+
+        long long bits = hs.nbits;
+        int verb = 0;
+        for (int c = 0; c < nch; c++) {
+            const int type = s_info[c][0], order = s_info[c][2], obits = s_info[c][4];
+            const int wasted = s_info[c][5], rn = s_info[c][6];
+            bits += 8 + (wasted ? wasted : 0);
+            if (type == FHIP_SUB_CONSTANT) bits += obits;
+            else if (type == FHIP_SUB_VERBATIM) bits += (long long)n * obits;
+            else {
+                if (rn < 0) verb = 1;
+                bits += (long long)order * obits + rn;
+                if (type == FHIP_SUB_LPC) bits += 9 + order * P.lpc_precision;
+            }
+        }
+        const long long bytes = ((bits + 7) >> 3) + 2;
+        if (bytes > verbatim_size) verb = 1;
+        s_verbatim = verb;
+    }
+    __syncthreads();
+    const int verbatim = s_verbatim;
+
+    // ---- per-subframe prefixes (encode.c:871-905, 800-869), one thread each --
+    if (tid < nch) {
+        const fhip_subframe_info *i = &fi[tid];
+        const int type = verbatim ? FHIP_SUB_VERBATIM : s_info[tid][0];
+        const int order = s_info[tid][2], obits = s_info[tid][4], wasted = s_info[tid][5];
+        MiniSink ps{s_prefix[tid], 0};
+        ps.put(1, 0);
+        ps.put(6, (uint32_t)(verbatim ? FHIP_SUB_VERBATIM : s_info[tid][1]));
+        if (wasted) { ps.put(1, 1); ps.put(wasted - 1, 0); ps.put(1, 1); }
+        else ps.put(1, 0);
+        const uint32_t omask = (obits >= 32) ? 0xFFFFFFFFu : ((1u << obits) - 1u);
+        if (type == FHIP_SUB_CONSTANT) {
+            ps.put(obits, (uint32_t)i->warmup[0] & omask);
+        } else if (type == FHIP_SUB_FIXED || type == FHIP_SUB_LPC) {
+            for (int t = 0; t < order; t++) ps.put(obits, (uint32_t)i->warmup[t] & omask);
+            if (type == FHIP_SUB_LPC) {
+                ps.put(4, (uint32_t)(P.lpc_precision - 1));
+                ps.put(5, (uint32_t)s_info[tid][3] & 31u);
+                const uint32_t cmask = (1u << P.lpc_precision) - 1u;
+                for (int t = 0; t < order; t++) ps.put(P.lpc_precision, (uint32_t)i->coefs[t] & cmask);
+            }
+        }
+        s_info[tid][0] = type;
+        s_info[tid][3] = ps.nbits;              // reuse: prefix length
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int ns = 0;
+        long long pos = 0;
+        s_seg[ns++] = AsmSeg{0, -1, s_hdr_bits, pos}; pos += s_hdr_bits;
+        for (int c = 0; c < nch; c++) {
+            s_seg[ns++] = AsmSeg{0, c, s_info[c][3], pos}; pos += s_info[c][3];
+            const int type = s_info[c][0];
+            if (type == FHIP_SUB_VERBATIM) {
+                const long long nb = (long long)n * s_info[c][4];
+                s_seg[ns++] = AsmSeg{2, c, nb, pos}; pos += nb;
+            } else if (type == FHIP_SUB_FIXED || type == FHIP_SUB_LPC) {
+                s_seg[ns++] = AsmSeg{1, c, s_info[c][6], pos}; pos += s_info[c][6];
+            }
+        }
+        s_nseg = ns;
+        s_total_bits = pos;
+    }
+    __syncthreads();
+
+    const long long total_bits = s_total_bits;
+    const int body_bytes = (int)((total_bits + 7) >> 3);          // before the CRC-16
+    const int nwords = (body_bytes + 3) >> 2;
+    const int nseg = s_nseg;
+
+    // ---- every output dword from the segments that overlap it ----------------
+    for (int w = tid; w < nwords; w += NT) {
+        const long long w0 = (long long)w * 32, w1 = w0 + 32;
+        uint32_t word = 0;
+        for (int q = 0; q < nseg; q++) {
+            const AsmSeg sg = s_seg[q];
+            const long long a = max(sg.dst, w0), b = min(sg.dst + sg.nbits, w1);
+            if (a >= b) continue;
+            const int cnt = (int)(b - a);
+            const long long sp = a - sg.dst;                      // bit offset inside the segment
+            uint32_t bitsv;                                       // cnt bits, right aligned
+            if (sg.kind == 2) {
+                const int c = sg.ch, obits = s_info[c][4], wasted = s_info[c][5], cm = s_info[c][7];
+                const uint32_t omask = (obits >= 32) ? 0xFFFFFFFFu : ((1u << obits) - 1u);
+                int i = (int)(sp / obits), offb = (int)(sp % obits), got = 0;
+                unsigned long long acc = 0;
+                while (got < cnt) {
+                    const uint32_t v = (uint32_t)asm_sample(pcm_frame, nch, c, i, cm, wasted) & omask;
+                    const int take = min(obits - offb, cnt - got);
+                    const uint32_t piece = (take >= 32) ? v : ((v >> (obits - offb - take)) & ((1u << take) - 1u));
+                    acc = (acc << take) | piece;
+                    got += take; offb = 0; i++;
+                }
+                bitsv = (uint32_t)acc;
+            } else {
+                // 64 source bits that start at the dword holding bit sp
+                const long long sw = sp >> 5;
+                uint32_t hi, lo;
+                if (sg.kind == 0) {
+                    const uint8_t *src = (sg.ch < 0) ? s_hdr : s_prefix[sg.ch];
+                    const int lim = (sg.ch < 0) ? 32 : ASM_PREFIX_BYTES;
+                    uint32_t bv[8];
+#pragma unroll
+                    for (int z = 0; z < 8; z++) {
+                        const long long bi = sw * 4 + z;
+                        bv[z] = (bi < lim) ? src[bi] : 0u;
+                    }
+                    hi = (bv[0] << 24) | (bv[1] << 16) | (bv[2] << 8) | bv[3];
+                    lo = (bv[4] << 24) | (bv[5] << 16) | (bv[6] << 8) | bv[7];
+                } else {
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(
+                        rice + ((size_t)f * nch + sg.ch) * (size_t)slot_bytes);
+                    hi = __builtin_bswap32(src[sw]);
+                    lo = ((sw + 1) * 4 < slot_bytes) ? __builtin_bswap32(src[sw + 1]) : 0u;
+                }
+                const unsigned long long x = ((unsigned long long)hi << 32) | lo;
+                const int sh = (int)(sp & 31);
+                bitsv = (uint32_t)((x << sh) >> (64 - cnt));
+            }
+            word |= bitsv << (32 - (int)(a - w0) - cnt);
+        }
+        out32[w] = __builtin_bswap32(word);
+    }
+    __syncthreads();                       // the frame body is in memory (same CU)
+
+    // ---- CRC-16 (crc.c:59-94) in parallel -------------------------------------
+    // chunk c covers message bytes [c*L - pad, (c+1)*L - pad): the message is
+    // thought of as left-padded with zero bytes, which leaves a CRC with initial
+    // value 0 unchanged.
+    const int L = (body_bytes + NT - 1) / NT;
+    const int pad = L * NT - body_bytes;
+    {
+        uint16_t c = 0;
+        const int b0 = tid * L - pad;
+        for (int q = 0; q < L; q++) {
+            const int bi = b0 + q;
+            if (bi >= 0) {
+                // the bytes were stored by other lanes of this workgroup: read past L1
+                const uint32_t wv = __hip_atomic_load(&out32[bi >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t byte = (wv >> (8 * (bi & 3))) & 0xFFu;
+                c = (uint16_t)((c << 8) ^ s_crc_tab[((c >> 8) ^ byte) & 0xFFu]);
+            }
+        }
+        s_part[tid] = c;
+    }
+    // m = x^(8L) mod P by square-and-multiply on x^8
+    uint16_t m;
+    {
+        uint16_t base = 0x100, r = 1;
+        int ex = L;
+        while (ex) { if (ex & 1) r = crc16_mulmod(r, base); base = crc16_mulmod(base, base); ex >>= 1; }
+        m = r;
+    }
+    __syncthreads();
+    for (int step = 1; step < NT; step <<= 1) {
+        // left node (tid) absorbs its right neighbour: crc(A||B) = crc(A)*x^(8|B|) + crc(B)
+        uint16_t v = 0;
+        const bool act = (tid % (2 * step)) == 0;
+        if (act) v = (uint16_t)(crc16_mulmod(s_part[tid], m) ^ s_part[tid + step]);
+        __syncthreads();
+        if (act) s_part[tid] = v;
+        __syncthreads();
+        m = crc16_mulmod(m, m);
+    }
+    if (tid == 0) {
+        const uint16_t crc = s_part[0];
+        out[body_bytes] = (uint8_t)(crc >> 8);
+        out[body_bytes + 1] = (uint8_t)crc;
+        frame_bytes[f] = body_bytes + 2;
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// K-vbs  k_vbs_split -- vbs.c:36-83 split_frame_v1
+// ---------------------------------------------------------------------------
+// One workgroup per block: eight sections of n/8 sample-frames, for each the
+// sum over channels of |x[j] - 2x[j-1] + x[j-2]| on the raw interleaved input
+// (int32 wrap, then abs), divided by the channel count, plus one; neighbours
+// are merged unless the score changes by more than 25 % -- evaluated with the
+// reference's int abs() and 32-bit multiply.
+__global__ __launch_bounds__(NT)
+void k_vbs_split(const int32_t *__restrict__ pcm, int nblocks, int block_size, int nch,
+                 int32_t *__restrict__ nframes_out, int32_t *__restrict__ sizes_out)
+{
+    __shared__ long long s_score[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.x;
+    const int n = block_size / 8;
+    const int32_t *base = pcm + (size_t)b * block_size * nch;
+    for (int sec = wv; sec < 8; sec += 4) {
+        const int32_t *sp = base + (size_t)sec * n * nch;
+        long long acc = 0;
+        // element e of the section = (j, ch) interleaved; rows j >= 2 only
+        const int total = (n - 2) * nch;
+        for (int e = lane; e < total; e += WAVE) {
+            const int idx = e + 2 * nch;
+            const uint32_t x0 = (uint32_t)sp[idx], x1 = (uint32_t)sp[idx - nch], x2 = (uint32_t)sp[idx - 2 * nch];
+            const int32_t d = (int32_t)(x0 - 2u * x1 + x2);
+            acc += (long long)wrap_abs(d);
+        }
+        acc = (long long)wave_sum_u64((unsigned long long)acc);
+        if (lane == 0) s_score[sec] = acc / nch + 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int sizes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int nf = 0;
+        for (int p = 0; p < 8; p++) {
+            bool cut = (p == 0);
+            if (p > 0) {
+                int32_t diff = (int32_t)(uint32_t)(unsigned long long)(s_score[p - 1] - s_score[p]);
+                diff = wrap_abs(diff);
+                const int32_t scaled = (int32_t)((uint32_t)diff * 200u);
+                cut = ((long long)scaled / s_score[p - 1]) > 50;
+            }
+            if (cut) nf++;
+            sizes[nf - 1] += n;
+        }
+        nframes_out[b] = nf;
+        for (int p = 0; p < 8; p++) sizes_out[(size_t)b * 8 + p] = sizes[p];
+    }
+}
+
+}  // namespace
+
+hipError_t launch_vbs_split(hipStream_t st, const int32_t *pcm, int nblocks, int block_size,
+                            int nch, int32_t *nframes_out, int32_t *sizes_out)
+{
+    if (nblocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_vbs_split, dim3(nblocks), dim3(NT), 0, st, pcm, nblocks, block_size, nch,
+                       nframes_out, sizes_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble(hipStream_t st, const fhip_params &p, const int32_t *pcm, int nframes,
+                           int n, const fhip_subframe_info *info, const uint8_t *rice,
+                           int64_t slot_bytes, uint8_t *frames, int64_t frame_stride,
+                           int32_t *frame_bytes, uint32_t number_base, uint32_t number_step,
+                           const uint32_t *numbers)
+{
+    if (nframes == 0) return hipSuccess;
+    // sample-rate / bit-depth codes of flake_encode_init() (encode.c:400-438)
+    static const int sr_table[16] = {0, 0, 0, 0, 8000, 16000, 22050, 24000, 32000, 44100, 48000,
+                                     96000, 0, 0, 0, 0};
+    static const int bd_table[8] = {0, 8, 12, 0, 16, 20, 24, 0};
+    int sr0 = 0, sr1 = 0, bpsc = 0;
+    for (int i = 4; i < 12; i++) if (p.sample_rate == sr_table[i]) { sr0 = i; break; }
+    if (!sr0) {
+        const int sr = p.sample_rate;
+        if (sr % 1000 == 0 && sr <= 255000) { sr0 = 12; sr1 = sr / 1000; }
+        else if (sr % 10 == 0 && sr <= 655350) { sr0 = 14; sr1 = sr / 10; }
+        else if (sr < 65535) { sr0 = 13; sr1 = sr; }
+    }
+    for (int i = 1; i < 8; i++) if (p.bits_per_sample == bd_table[i]) { bpsc = i; break; }
+    const int bps = p.bits_per_sample;
+    const int vsize = (p.channels == 2) ? 16 + ((n * (bps + bps + 1) + 7) >> 3)
+                                        : 16 + ((n * p.channels * bps + 7) >> 3);
+    hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(NT), 0, st, p, n, pcm, info, rice,
+                       (long long)slot_bytes, frames, (long long)frame_stride, frame_bytes,
+                       number_base, number_step, numbers, sr0, sr1, bpsc, vsize);
+    return hipGetLastError();
+}
+
+}  // namespace fhip

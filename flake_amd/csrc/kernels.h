@@ -1,5 +1,5 @@
 // kernels.h -- launch interface between the C ABI (api.hip) and the gfx950
-// kernels (kernels.hip).  Internal to libflakehip.so.
+// kernels (k0_prepare.hip ... k4_assemble.hip).  Internal to libflakehip.so.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -41,6 +41,8 @@ bool autocorr_fuses_prepare(const fhip_params &p, int nsub, int n);
 // subframes and launch_lpc is not needed.
 struct autocorr_lpc_out { int precision, omethod; int32_t *coefs, *shift, *opt_order, *fin; };
 bool autocorr_does_lpc(int nsub, int n, int max_order);
+// True when the wave-typed K1 (k_autocorr_wt) serves such a batch.
+bool autocorr_is_wave_typed(int nsub, int n, int max_order);
 hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                            int max_order, double *autoc, const int32_t *pcm_fused = nullptr,
                            int32_t *smp_out = nullptr, const fhip_subframe_info *info = nullptr,
@@ -81,5 +83,8 @@ hipError_t launch_vbs_split(hipStream_t st, const int32_t *pcm, int nblocks, int
 
 // Dynamic-LDS need of K3 for a block size (0 if unsupported).
 size_t encode_lds_bytes(int n);
+
+// Fast-path geometry of K3 for a block size: C samples per thread, T threads, n = C*T.
+bool fast_geometry(const fhip_params &p, int n, int *C, int *T);
 
 }  // namespace fhip

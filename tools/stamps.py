@@ -1,5 +1,5 @@
 """Diagnostic (not part of the product): phase stamps of k_encode_pow2, workgroup 0.
-Build: hipcc ... -DFHIP_STAMPS -o flake_amd/lib/libflakehip_dbg.so ; run on the GPU box."""
+Build: python -c "from flake_amd.build import build_hip; build_hip(True, ['-DFHIP_STAMPS'], 'libflakehip_dbg.so')"; run on the GPU box."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, flake_amd

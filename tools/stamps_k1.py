@@ -1,7 +1,6 @@
-"""Diagnostic (not part of the product): where the first wave pair of k_autocorr_pc
-spends its cycles.  Needs the -DFHIP_STAMPS build:
-  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared -std=c++17 -DFHIP_STAMPS \
-        -I include -I flake_amd/csrc flake_amd/csrc/kernels.hip flake_amd/csrc/api.hip -o flake_amd/lib/libflakehip_dbg.so
+"""Diagnostic (not part of the product): where the first wave pair of k_autocorr_wt
+spends its cycles.  Needs the stamped build:
+  python -c "from flake_amd.build import build_hip; build_hip(True, ['-DFHIP_STAMPS'], 'libflakehip_dbg.so')"
   FHIP_LIB=flake_amd/lib/libflakehip_dbg.so python tools/stamps_k1.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -23,6 +23,8 @@ def patched():
         fa._lib = None
     return fa_load()
 p = fa.level_params(5, order_method=fa.OM_MAX)
+if len(sys.argv) > 1 and sys.argv[1] == "level7":
+    p = fa.level_params(7)
 if len(sys.argv) > 1 and sys.argv[1] == "search":
     p = fa.level_params(5, bits_per_sample=24, order_method=fa.OM_SEARCH, max_prediction_order=32, max_partition_order=8)
 pcm = fa.synth_pcm(2048, 4096, 2, p.bits_per_sample)

@@ -200,21 +200,30 @@ void k_prepare_multi(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
 // APPLY = false is the decision pass of the fused pipeline: it writes only
 // obits / wasted / ch_mode; the K1 producers then apply them to the PCM they
 // load anyway and write smp (k_autocorr_wt<NCH, true>).
-template <int M, bool APPLY>
+// WPF = waves per frame (1, 2 or 4): short blocks put 4 / WPF frames in a workgroup so
+// that its 256 threads have quads to work on (n = 256: one wave per frame; at four
+// waves per frame three quarters of the threads idled and K0 took 5.7x its time per
+// sample).  Thread t of a frame owns quads t + 64 WPF m.
+template <int M, int WPF, bool APPLY>
 __global__ __launch_bounds__(NT)
 // allow_narrow: a channel whose samples (after the shift) all fit 16 bits is stored
 // as int16[n] at the start of its row (info.reserved = 1 tells K1's producers and
 // K3's staging; K3 resets the field) -- half the bytes written here and read there.
 void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
                       fhip_subframe_info *__restrict__ info, int n, int bps, int estimate,
-                      int allow_narrow)
+                      int allow_narrow, int nframes)
 {
     __shared__ unsigned long long s_sum[4][4];
     __shared__ uint32_t s_or[4][4];
     __shared__ int s_mode;
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int f = blockIdx.x;
+    constexpr int TF = WAVE * WPF;                       // threads per frame
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wb = (wv / WPF) * WPF;                     // first wave of this thread's frame
+    const int tid = threadIdx.x - wb * WAVE;             // thread index inside the frame
+    const int fq = blockIdx.x * (4 / WPF) + wv / WPF;
+    const bool fvalid = fq < nframes;                    // a partial last workgroup computes a copy of the last frame
+    const int f = min(fq, nframes - 1);
     const int4 *src = reinterpret_cast<const int4 *>(pcm + (size_t)f * n * 2);
     const int nquads = n >> 2;
 
@@ -222,7 +231,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
     int4 prev[M];
 #pragma unroll
     for (int m = 0; m < M; m++) {
-        const int g = tid + NT * m;
+        const int g = tid + TF * m;
         const int gc = min(g, nquads - 1);                 // clamped: loads stay unconditional
         const int4 a = src[2 * gc], b = src[2 * gc + 1];   // (l0 r0 l1 r1) (l2 r2 l3 r3)
         prev[m] = src[max(2 * gc - 1, 0)];                 // (l-2 r-2 l-1 r-1)
@@ -240,7 +249,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
             uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const int g = tid + NT * m;
+                const int g = tid + TF * m;
                 if (g < nquads) {
                     int32_t l2 = prev[m].x, r2 = prev[m].y, l1 = prev[m].z, r1 = prev[m].w;
 #pragma unroll
@@ -263,7 +272,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
         } else {
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            const int g = tid + NT * m;
+            const int g = tid + TF * m;
             uint32_t l2 = (uint32_t)prev[m].x, r2 = (uint32_t)prev[m].y;
             uint32_t l1 = (uint32_t)prev[m].z, r1 = (uint32_t)prev[m].w;
 #pragma unroll
@@ -287,14 +296,16 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
         if (lane == 0) { s_sum[wv][0] = a0; s_sum[wv][1] = a1; s_sum[wv][2] = a2; s_sum[wv][3] = a3; }
         __syncthreads();
         if (tid < 4) {
-            const unsigned long long sm = s_sum[0][tid] + s_sum[1][tid] + s_sum[2][tid] + s_sum[3][tid];
+            unsigned long long sm = 0;
+#pragma unroll
+            for (int w = 0; w < WPF; w++) sm += s_sum[wb + w][tid];
             uint32_t dummy;
             const int k = rice_best_k(2 * sm, n, &dummy);
-            s_sum[0][tid] = rice_count64(2 * sm, n, k);       // no 32-bit truncation (encode.c:620)
+            s_sum[wb][tid] = rice_count64(2 * sm, n, k);      // no 32-bit truncation (encode.c:620)
         }
         __syncthreads();
         {
-            const unsigned long long c0 = s_sum[0][0], c1 = s_sum[0][1], c2 = s_sum[0][2], c3 = s_sum[0][3];
+            const unsigned long long c0 = s_sum[wb][0], c1 = s_sum[wb][1], c2 = s_sum[wb][2], c3 = s_sum[wb][3];
             const unsigned long long sc[4] = {c0 + c1, c0 + c3, c1 + c3, c2 + c3};
             int best = 0;
 #pragma unroll
@@ -309,7 +320,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
     uint32_t mg0 = 0, mg1 = 0;            // OR of x ^ (x >> 31): the magnitude bits in use
 #pragma unroll
     for (int m = 0; m < M; m++) {
-        const bool on = (tid + NT * m) < nquads;
+        const bool on = (tid + TF * m) < nquads;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             int32_t a = L[m][q], b = R[m][q];
@@ -338,7 +349,9 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         // encode.c:558-593
-        const uint32_t o = s_or[0][c] | s_or[1][c] | s_or[2][c] | s_or[3][c];
+        uint32_t o = 0;
+#pragma unroll
+        for (int w = 0; w < WPF; w++) o |= s_or[wb + w][c];
         int w = o ? min(__ffs((int)o) - 1, bps - 1) : bps - 1;
         if (w == bps - 1) w = 0;
         wasted[c] = w;
@@ -351,7 +364,10 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         // (x >> w) ^ sign == (x ^ sign) >> w: every shifted sample within int16
-        const uint32_t mg = (s_or[0][2 + c] | s_or[1][2 + c] | s_or[2][2 + c] | s_or[3][2 + c]) >> wasted[c];
+        uint32_t mgo = 0;
+#pragma unroll
+        for (int w = 0; w < WPF; w++) mgo |= s_or[wb + w][2 + c];
+        const uint32_t mg = mgo >> wasted[c];
         narrow[c] = allow_narrow && (mg < 32768u);
         magbits[c] = 32 - __clz((int)mg);
     }
@@ -360,8 +376,8 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
     int4 *dr = reinterpret_cast<int4 *>(smp + (size_t)f * 2 * n + n);
 #pragma unroll
     for (int m = 0; m < M; m++) {
-        const int g = tid + NT * m;
-        if (APPLY && g < nquads) {
+        const int g = tid + TF * m;
+        if (APPLY && g < nquads && fvalid) {
             const int4 vl = make_int4(L[m][0] >> wasted[0], L[m][1] >> wasted[0], L[m][2] >> wasted[0], L[m][3] >> wasted[0]);
             const int4 vr = make_int4(R[m][0] >> wasted[1], R[m][1] >> wasted[1], R[m][2] >> wasted[1], R[m][3] >> wasted[1]);
             if (narrow[0]) reinterpret_cast<int2 *>(dl)[g] = make_int2((vl.x & 0xFFFF) | (vl.y << 16), (vl.z & 0xFFFF) | (vl.w << 16));
@@ -370,7 +386,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
             else dr[g] = vr;
         }
     }
-    if (tid < 2) {
+    if (tid < 2 && fvalid) {
         fhip_subframe_info *o = &info[(size_t)f * 2 + tid];
         o->obits = obits[tid];
         o->wasted = wasted[tid];
@@ -395,15 +411,21 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
         const int est = p.stereo_method == 1 ? 1 : 0;
         const int quads = n >> 2;
         const int nar = (allow_narrow && !decide_only) ? 1 : 0;
-#define LAUNCH_PS(M_, A_) hipLaunchKernelGGL((k_prepare_stereo<M_, A_>), dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est, nar)
+#define LAUNCH_PS(M_, W_, A_) hipLaunchKernelGGL((k_prepare_stereo<M_, W_, A_>), dim3((nframes + 4 / W_ - 1) / (4 / W_)), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est, nar, nframes)
         if (decide_only) {
-            if (quads <= NT) LAUNCH_PS(1, false); else if (quads <= 2 * NT) LAUNCH_PS(2, false); else LAUNCH_PS(4, false);
+            if (quads <= NT) LAUNCH_PS(1, 4, false); else if (quads <= 2 * NT) LAUNCH_PS(2, 4, false); else LAUNCH_PS(4, 4, false);
         } else {
-            if (quads <= NT) LAUNCH_PS(1, true);
-            else if (quads <= 2 * NT) LAUNCH_PS(2, true);
-            else if (quads <= 4 * NT) LAUNCH_PS(4, true);
-            else if (quads <= 5 * NT) LAUNCH_PS(5, true);       // 4608
-            else LAUNCH_PS(8, true);                            // 8192
+            // quads per thread M and waves per frame: the fullest threads win for short blocks
+            if (quads <= 64) LAUNCH_PS(1, 1, true);              // n <= 256: one wave per frame
+            else if (quads <= 128) LAUNCH_PS(1, 2, true);        // 512
+            else if (quads <= 192) LAUNCH_PS(3, 1, true);        // 576, 768
+            else if (quads <= NT) LAUNCH_PS(1, 4, true);         // 1024
+            else if (quads <= 320) LAUNCH_PS(5, 1, true);        // 1152
+            else if (quads <= 2 * NT) LAUNCH_PS(2, 4, true);
+            else if (quads <= 3 * NT) LAUNCH_PS(3, 4, true);     // 2304, 3072
+            else if (quads <= 4 * NT) LAUNCH_PS(4, 4, true);
+            else if (quads <= 5 * NT) LAUNCH_PS(5, 4, true);     // 4608
+            else LAUNCH_PS(8, 4, true);                          // 8192
         }
 #undef LAUNCH_PS
         return hipGetLastError();

@@ -1379,7 +1379,14 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
         l.coef[tid] = fcoef_n;
         l.coefd[tid] = (double)fcoef_n;
     }
-    const bool constant = (__syncthreads_or(differs) == 0);
+    // one barrier (the library's __syncthreads_or is three): per-wave flags, then everyone ORs them
+    const int wave_differs = (__ballot(differs) != 0ull) ? 1 : 0;       // all lanes vote
+    if (e.lane == 0) l.misc[e.wv] = wave_differs;
+    __syncthreads();
+    int any_differs = 0;
+#pragma unroll
+    for (int w = 0; w < T / WAVE; w++) any_differs |= l.misc[w];
+    const bool constant = (__builtin_amdgcn_readfirstlane(any_differs) == 0);
     STAMP(1);
 
     int32_t r[C];                        // residuals of the current candidate

@@ -300,7 +300,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
 #pragma unroll
             for (int w = 0; w < WPF; w++) sm += s_sum[wb + w][tid];
             uint32_t dummy;
-            const int k = rice_best_k(2 * sm, n, &dummy);
+            const int k = rice_k_fast(2 * sm, n, &dummy);     // closed form of the 31-step scan: the workgroup waits here
             s_sum[wb][tid] = rice_count64(2 * sm, n, k);      // no 32-bit truncation (encode.c:620)
         }
         __syncthreads();

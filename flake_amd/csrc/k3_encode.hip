@@ -592,34 +592,6 @@ struct SmpImg {
     }
 };
 
-// rice.c:30-45 find_optimal_rice_param without the scan.  With
-// S = sum - (n>>1):  f(k) = n(k+1) + (S>>k).
-//  * sum < n>>1: S wraps; f(k) = n(k+1) - ceil(d/2^k) (mod 2^32) with
-//    d = (n>>1)-sum <= n/2 is increasing, so k = 0.
-//  * no wrap and f < 2^32 for all k: f is convex in k (its increment
-//    n - ceil((S>>k)/2) never decreases), so the first minimum is the smallest
-//    k with (S>>k) <= 2n, capped at 30.
-//  * otherwise (sums near 2^32): the reference scan.
-__device__ __forceinline__ int rice_k_fast(uint64_t sum, int n, uint32_t *bits_out)
-{
-    const uint64_t half = (uint64_t)(n >> 1);
-    if (sum < half) {
-        *bits_out = (uint32_t)n - (uint32_t)(half - sum);
-        return 0;
-    }
-    const uint64_t S = sum - half;
-    if (n <= 0 || S >= 0xFFE00000ull) return rice_best_k(sum, n, bits_out);
-    const uint32_t two = 2u * (uint32_t)n;
-    int k = 0;
-    if (S > two) {
-        k = (64 - __clzll((long long)S)) - (32 - __clz((int)two));
-        if ((S >> k) > two) k++;
-        if (k > 30) k = 30;
-    }
-    *bits_out = (uint32_t)(n * (k + 1)) + (uint32_t)(S >> k);
-    return k;
-}
-
 struct FastLds {
     int32_t *smp;                        // SmpImg<C,T>: samples, HIST zeros in front
     unsigned long long *sums;            // [511] heap order

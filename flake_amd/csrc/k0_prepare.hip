@@ -295,17 +295,22 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
         a2 = wave_sum_u64(a2); a3 = wave_sum_u64(a3);
         if (lane == 0) { s_sum[wv][0] = a0; s_sum[wv][1] = a1; s_sum[wv][2] = a2; s_sum[wv][3] = a3; }
         __syncthreads();
-        if (tid < 4) {
+        // every wave prices the four sums itself (lane & 3 picks the sum, four lanes hold the
+        // results): no second barrier, no four threads the workgroup waits for
+        unsigned long long c0, c1, c2, c3;
+        {
             unsigned long long sm = 0;
 #pragma unroll
-            for (int w = 0; w < WPF; w++) sm += s_sum[wb + w][tid];
+            for (int w = 0; w < WPF; w++) sm += s_sum[wb + w][lane & 3];
             uint32_t dummy;
-            const int k = rice_k_fast(2 * sm, n, &dummy);     // closed form of the 31-step scan: the workgroup waits here
-            s_sum[wb][tid] = rice_count64(2 * sm, n, k);      // no 32-bit truncation (encode.c:620)
+            const int k = rice_k_fast(2 * sm, n, &dummy);     // closed form of the 31-step scan
+            const unsigned long long cnt = rice_count64(2 * sm, n, k);      // no 32-bit truncation (encode.c:620)
+            const int lo = (int)(uint32_t)cnt, hi = (int)(uint32_t)(cnt >> 32);
+#define LANE64(q_) (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(hi, q_) << 32) | (uint32_t)__builtin_amdgcn_readlane(lo, q_))
+            c0 = LANE64(0); c1 = LANE64(1); c2 = LANE64(2); c3 = LANE64(3);
+#undef LANE64
         }
-        __syncthreads();
         {
-            const unsigned long long c0 = s_sum[wb][0], c1 = s_sum[wb][1], c2 = s_sum[wb][2], c3 = s_sum[wb][3];
             const unsigned long long sc[4] = {c0 + c1, c0 + c3, c1 + c3, c2 + c3};
             int best = 0;
 #pragma unroll

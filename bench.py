@@ -212,6 +212,10 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": {k: round(v, 4) for k, v in per.items()},
+                # each event pair also times its own packets and the dispatch; in the timed
+                # region the kernels run back to back, so that share is (sum - step) / launches
+                "kernel_ms_net": {k: round(v - (sum(per.values()) - dt / args.steps * 1e3) / len(per), 4)
+                                  for k, v in per.items()},
                 "pipeline_achieved": round(alg_bytes / (sum(per.values()) * 1e-3) / 1e9, 1),
             }
         if world == 1 and not args.no_cpu_baseline:

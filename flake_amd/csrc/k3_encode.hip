@@ -633,7 +633,8 @@ __host__ __device__ inline size_t fast_lds_layout(int n, size_t img_doubles, siz
     return o;
 }
 
-constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }
+constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }          // floor(log2 v)
+constexpr int clog2_up(int v) { return clog2(v) + ((v & (v - 1)) ? 1 : 0); }    // ceil(log2 v): runs of 3, 9, 18
 
 template <int C, int T>
 struct FastCtx {
@@ -899,7 +900,7 @@ __device__ __forceinline__ void fold_residuals(const FastCtx<C, T> &e, const int
 template <int C, int T>
 __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, const int32_t (&r)[C],
                                                      uint32_t (&u)[C], int order, bool lpc,
-                                                     int *porder_out, int *method_out)
+                                                     int *porder_out, int *method_out, uint32_t *umax_out)
 {
     constexpr int LT = clog2(T);                      // the thread level
     const FastLds &l = e.l;
@@ -908,9 +909,16 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
     const int pmax = clamp_porder(e.pmax_req, n, order);
 
     fold_residuals<C, T>(e, r, u, order);
-    // thread-level sum
+    // thread-level sum.  The residuals are not bounded by the sample width (a fixed
+    // predictor of order 4 gains four bits, an LPC row with shift 0 more, and the
+    // reference wraps at 32), so the narrow sum is chosen by the data: the largest
+    // folded value of the run -- which the emit needs anyway -- decides per wave.
+    uint32_t umax = 0;
+#pragma unroll
+    for (int o = 0; o < C; o++) umax = max(umax, u[o]);
+    *umax_out = umax;
     unsigned long long v;
-    if (e.obits <= 31 - clog2(C)) {
+    if (!__any((umax >> (32 - clog2_up(C))) != 0u)) {
         // C folded values below 2^(32 - log2 C) each: the thread's sum fits 32 bits
         uint32_t v32 = 0;
 #pragma unroll
@@ -1042,7 +1050,7 @@ __device__ __forceinline__ int fixed_search5(const FastCtx<C, T> &e, int min_ord
     uint32_t p0 = h[0];
 
     // folded sums per order; a folded value is below 2^(obits+4)
-    const bool sum32 = e.obits + 4 + clog2(C) <= 32;
+    const bool sum32 = e.obits + 4 + clog2_up(C) <= 32;
     unsigned long long v[5];
     uint32_t a32[5] = {0, 0, 0, 0, 0};
     unsigned long long a64[5] = {0, 0, 0, 0, 0};
@@ -1088,7 +1096,7 @@ __device__ __forceinline__ int fixed_search5(const FastCtx<C, T> &e, int min_ord
         }                                                                                   \
     } while (0)
     // a wave's total is below 2^(obits + 4 + log2(64 C)): in 32 bits one DPP add per step
-    const bool wave32 = e.obits + 4 + clog2(C) + 6 <= 32;
+    const bool wave32 = e.obits + 4 + clog2_up(C) + 6 <= 32;
     if (wave32) {
         uint32_t w[5];
 #pragma unroll
@@ -1389,6 +1397,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     int lg_step = 16, lg_last = 0, lg_pos = 3;
     bool final_pass = false;             // MAX / EST: the one row is the result
     int porder = 0, method = 0;          // of the most recent Rice search
+    uint32_t umax_run = 0;               // largest folded value of this thread's run in that search
     // (Keeping the winner's Rice result instead of searching it again after the
     // order search -- optimize.c:183-187, :265-274 -- was measured: the extra live
     // state costs a wave of occupancy and the kernel ends up 15 % slower.)
@@ -1423,6 +1432,9 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                 best = fixed_search5<C, T>(e, min_order, max_order, &est_bits, &porder, &method);
                 fir_fixed<C, T>(e, r, best);
                 fold_residuals<C, T>(e, r, u, best);
+                umax_run = 0;
+#pragma unroll
+                for (int o = 0; o < C; o++) umax_run = max(umax_run, u[o]);
             }
         }
         if (!five_wide) for (;;) {
@@ -1464,7 +1476,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
             if (MULTI && (!HAS_LPC || tree == T_FIXED)) {
                 fir_fixed<C, T>(e, r, cand);
                 __syncthreads();                      // previous search fully read
-                b = rice_search_fast<C, T>(e, r, u, cand, false, &porder, &method);
+                b = rice_search_fast<C, T>(e, r, u, cand, false, &porder, &method, &umax_run);
             } else if constexpr (HAS_LPC) {
                 const int ord = cand + 1;
                 int cshift;
@@ -1497,7 +1509,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                 else
                     fir_lpc<C, T>(e, r, ord, cshift);
                 STAMP(3);
-                b = rice_search_fast<C, T>(e, r, u, ord, true, &porder, &method);
+                b = rice_search_fast<C, T>(e, r, u, ord, true, &porder, &method, &umax_run);
                 STAMP(8);
             }
             if (final_pass) { est_bits = b; break; }
@@ -1571,17 +1583,19 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
         const bool part_head = (part > 0) && ((tid & ((1 << tpp) - 1)) == 0);
         // warm-up samples at the front of this thread's run (first threads only)
         const int nwarm = min(max(order - e.i0, 0), C);
-        // the emit-side fold (bitio.h:128) differs from rice.c's for |x| >= 2^30
-        if (e.obits > 30) {
+        // the emit-side fold (bitio.h:128) differs from rice.c's for |x| >= 2^30, i.e. for
+        // folded values from 2^31 (any sample width: it is the residual that counts)
+        uint32_t umax = umax_run;
+        if (__any((umax >> 31) != 0u)) {
+            umax = 0;
 #pragma unroll
-            for (int o = 0; o < C; o++)
+            for (int o = 0; o < C; o++) {
                 u[o] = emit_fold32((int32_t)((u[o] >> 1) ^ (0u - (u[o] & 1u)))) & ((e.i0 + o < order) ? 0u : ~0u);
+                umax = max(umax, u[o]);
+            }
         }
         // codeword lengths of the run; in 32 bits unless a quotient is huge.
         // A zeroed warm-up entry counts k+1 bits here, taken off again below.
-        uint32_t umax = 0;
-#pragma unroll
-        for (int o = 0; o < C; o++) umax = max(umax, u[o]);
         const uint32_t longest = umax >> k;
         // every codeword of the wave at most 32 bits: one flush test per codeword
         const bool short_codes = !__any(longest + (uint32_t)k1 > 32u);

@@ -2,6 +2,8 @@
 channel counts, bit depths, every order method, ragged partition / prediction
 order ranges and signal kinds -- the HIP path through the C ABI against the
 oracle, bit for bit.  Small batches, so the whole sweep takes well under a minute."""
+import os
+
 import numpy as np
 import pytest
 
@@ -61,7 +63,17 @@ def _params(r, n, ch, bps):
                                   stereo_method=int(r.randint(0, 2)))
 
 
-@pytest.mark.parametrize("seed", range(384))
+# FLAKE_FUZZ_FIRST / FLAKE_FUZZ_SEEDS widen the sweep for a campaign (default: seeds 0..383)
+_FIRST = int(os.environ.get("FLAKE_FUZZ_FIRST", "0"))
+_COUNT = int(os.environ.get("FLAKE_FUZZ_SEEDS", "384"))
+
+
+# found by a wider campaign (8000 seeds): residuals wider than the sample width -- 32-bit
+# noise under a fixed predictor -- overflowed a 32-bit thread sum chosen by `obits`
+_REGRESSIONS = [484, 3185] if "FLAKE_FUZZ_FIRST" not in os.environ else []
+
+
+@pytest.mark.parametrize("seed", list(range(_FIRST, _FIRST + _COUNT)) + _REGRESSIONS)
 def test_random_configuration(oracle, seed):
     r = np.random.RandomState(1000 + seed)
     n = int(BLOCKS[r.randint(0, len(BLOCKS))])

@@ -66,6 +66,7 @@ def _params(r, n, ch, bps):
 # FLAKE_FUZZ_FIRST / FLAKE_FUZZ_SEEDS widen the sweep for a campaign (default: seeds 0..383)
 _FIRST = int(os.environ.get("FLAKE_FUZZ_FIRST", "0"))
 _COUNT = int(os.environ.get("FLAKE_FUZZ_SEEDS", "384"))
+_MORE_FRAMES = os.environ.get("FLAKE_FUZZ_FRAMES", "") != ""      # campaign: 17..69 frames per case
 
 
 # found by a wider campaign (8000 seeds): residuals wider than the sample width -- 32-bit
@@ -81,6 +82,8 @@ def test_random_configuration(oracle, seed):
     bps = int(r.choice([8, 12, 16, 16, 16, 20, 24, 24, 32]))
     p = _params(r, n, ch, bps)
     nfr = 2 if n * ch > 20000 else int(r.randint(2, 6))
+    if _MORE_FRAMES and n * ch <= 20000:
+        nfr = int(r.randint(17, 70))                 # several K1 workgroups, mixed row widths
     pcm = _signal(r, int(r.randint(0, 5)), nfr, n, ch, bps)
     what = f"seed {seed}: n={n} ch={ch} bps={bps} pred={p.prediction_type} om={p.order_method} " \
            f"order {p.min_prediction_order}..{p.max_prediction_order} porder {p.min_partition_order}..{p.max_partition_order}"
@@ -90,3 +93,36 @@ def test_random_configuration(oracle, seed):
     assert_info_equal(got["info"], exp["info"], what)
     assert_residual_equal(got["residual"], exp["residual"], exp["info"], what)
     assert_bits_equal(got["rice_bits"], exp["rice_bits"], exp["info"], what)
+
+
+_FRAME_COUNT = int(os.environ.get("FLAKE_FUZZ_FRAME_SEEDS", "96"))
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + _FRAME_COUNT))
+def test_random_frames(oracle, decoder, seed):
+    """The same sweep one level up: whole frames assembled on the device (K4: headers,
+    UTF-8 frame numbers, warm-up samples, residual sections, CRC-8 / CRC-16, verbatim
+    fallback) against the oracle's encode_frame(), byte for byte, and decoded back."""
+    r = np.random.RandomState(5000 + seed)
+    n = int(BLOCKS[r.randint(0, len(BLOCKS))])
+    ch = int(r.choice([1, 2, 2, 2, 3, 6, 8]))
+    bps = int(r.choice([8, 12, 16, 16, 16, 20, 24, 24]))
+    p = _params(r, n, ch, bps)
+    nfr = 2 if n * ch > 20000 else int(r.randint(2, 5))
+    pcm = _signal(r, int(r.randint(0, 5)), nfr, n, ch, bps)
+    first = int(r.choice([0, 120, 127, 2047, 65530, 2 ** 21 - 2, 2 ** 26 - 1]))
+    what = f"frames seed {seed}: n={n} ch={ch} bps={bps} pred={p.prediction_type} om={p.order_method} first={first}"
+    with flake_amd.Encoder(p, max_frames=nfr) as enc:
+        got = enc.encode_subframes(pcm, n, want_residual=False, want_frames=True, first_frame_number=first)
+    step = n if p.allow_vbs else 1
+    stream = []
+    for f in range(nfr):
+        rc, exp, _, _, _ = oracle.encode_frame(p, first + f * step, pcm[f], n)
+        nb = int(got["frame_bytes"][f])
+        assert nb == rc, (what, f, nb, rc)
+        frame = got["frames"][f, :nb]
+        bad = np.nonzero(frame != exp)[0]
+        assert bad.size == 0, (what, f, "first differing byte", int(bad[0]) if bad.size else -1)
+        stream.append(frame)
+    out, _ = decoder.decode(np.concatenate(stream), ch, bps, nfr * n)
+    assert (out.reshape(nfr, n, ch) == pcm.reshape(nfr, n, ch)).all(), what

@@ -233,3 +233,46 @@ def test_lookahead_queue_is_transparent(tmp_path, level, nblocks, look):
         assert r.returncode == 0, r.stderr + r.stdout
         outs.append(np.fromfile(out, dtype=np.uint8))
     assert outs[0].size > 1000 and outs[0].tobytes() == outs[1].tobytes()
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("FLAKE_FUZZ_HOST_SEEDS", "48"))))
+def test_random_streams(oracle, decoder, seed):
+    """Seeded sweep through the host layer: level, channel count, bit depth, block
+    size, variable block size on or off, a random number of blocks and a random short
+    tail -- the byte stream against the oracle's block loop, the decoder and the MD5."""
+    r = np.random.RandomState(9000 + seed)
+    level = int(r.choice([0, 1, 2, 3, 5, 5, 6, 7, 8, 9, 10, 12]))
+    ch = int(r.choice([1, 2, 2, 2, 3, 6]))
+    bps = int(r.choice([8, 16, 16, 20, 24]))
+    over = {}
+    if r.rand() < 0.5:
+        over["block_size"] = int(r.choice([256, 512, 1024, 1152, 2048, 4096, 4608]))
+    if r.rand() < 0.3:
+        over["variable_block_size"] = int(r.randint(0, 2))
+        if over["variable_block_size"]:
+            over["allow_vbs"] = 1                        # encode.c:363: the splitter needs it
+    with flake_amd.HostEncoder(level, channels=ch, bits_per_sample=bps, **over) as enc:
+        p = enc.params()
+        n = p.block_size
+        nblocks = int(r.randint(1, 7)) if n * ch <= 16384 else int(r.randint(1, 4))
+        tail = int(r.choice([0, 0, 1, 7, n // 3, n - 1]))
+        kind = int(r.randint(0, 3))
+        total = nblocks * n + tail
+        if kind == 0:
+            pcm = flake_amd.synth_pcm(1, total, ch, bps, first_frame=seed)[0]
+        elif kind == 1:
+            full = 1 << (bps - 1)
+            pcm = r.randint(-full, full, (total, ch)).astype(np.int32)
+        else:
+            t = np.arange(total)[:, None]
+            full = 1 << (bps - 1)
+            pcm = (0.6 * full * np.sin(t * r.uniform(0.002, 0.2)) + r.randint(-4, 5, (total, ch))).astype(np.int32)
+            pcm[total // 2:] //= 64                      # a level change for the VBS splitter
+        what = f"stream seed {seed}: level {level} ch {ch} bps {bps} n {n} blocks {nblocks} tail {tail} vbs {p.variable_block_size}"
+        data, sizes = enc.encode_frames(pcm, n, tail)
+        exp, esizes = oracle_stream(oracle, p, pcm, n, tail)
+        assert (sizes == esizes).all(), what
+        assert data.tobytes() == exp.tobytes(), what
+        out, _ = decoder.decode(data, ch, bps, total)
+        assert (out == pcm).all(), what
+        assert bytes(enc.streaminfo().md5sum) == pcm_md5(pcm, bps), what

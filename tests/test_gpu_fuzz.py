@@ -31,6 +31,21 @@ def _signal(r, kind, nfr, n, ch, bps):
         a = (0.7 * full * np.sin(t * r.uniform(0.001, 0.3))).astype(np.int64)
         x = a + r.randint(-8, 9, (nfr, n, ch))
         return np.clip(x, -full, full - 1).astype(np.int32)
+    if kind == 5:                                    # +-full scale alternating, phase flips
+        sgn = np.where((np.arange(n) + (np.arange(n) // max(int(r.randint(3, 50)), 1))) % 2 == 0, 1, -1)
+        x = (sgn[None, :, None] * (full - 1) - (sgn[None, :, None] < 0)).astype(np.int64)
+        return np.broadcast_to(x, (nfr, n, ch)).astype(np.int32).copy()
+    if kind == 6:                                    # exact polynomial: a fixed predictor leaves zeros
+        t = np.arange(n, dtype=np.int64)[None, :, None]
+        a, b, c = int(r.randint(-3, 4)), int(r.randint(-200, 200)), int(r.randint(-full // 4, full // 4))
+        x = np.clip(a * t * t // 64 + b * t // 8 + c, -full, full - 1)
+        return np.broadcast_to(x, (nfr, n, ch)).astype(np.int32).copy()
+    if kind == 7:                                    # silence, then a burst of noise, then quiet
+        x = np.zeros((nfr, n, ch), dtype=np.int64)
+        lo, hi = sorted(int(v) for v in r.randint(0, n + 1, 2))
+        x[:, lo:hi, :] = r.randint(-full, full, (nfr, hi - lo, ch))
+        x[:, hi:, :] = r.randint(-2, 3, (nfr, n - hi, ch))
+        return x.astype(np.int32)
     x = np.zeros((nfr, n, ch), dtype=np.int32)       # constant blocks, one full-scale click
     x[:, :, :] = int(r.randint(-full, full))
     if n > 8:
@@ -66,6 +81,7 @@ def _params(r, n, ch, bps):
 # FLAKE_FUZZ_FIRST / FLAKE_FUZZ_SEEDS widen the sweep for a campaign (default: seeds 0..383)
 _FIRST = int(os.environ.get("FLAKE_FUZZ_FIRST", "0"))
 _COUNT = int(os.environ.get("FLAKE_FUZZ_SEEDS", "384"))
+_MORE_KINDS = os.environ.get("FLAKE_FUZZ_KINDS", "") != ""         # campaign: three more signal kinds
 _MORE_FRAMES = os.environ.get("FLAKE_FUZZ_FRAMES", "") != ""      # campaign: 17..69 frames per case
 
 
@@ -84,7 +100,10 @@ def test_random_configuration(oracle, seed):
     nfr = 2 if n * ch > 20000 else int(r.randint(2, 6))
     if _MORE_FRAMES and n * ch <= 20000:
         nfr = int(r.randint(17, 70))                 # several K1 workgroups, mixed row widths
-    pcm = _signal(r, int(r.randint(0, 5)), nfr, n, ch, bps)
+    kind = int(r.randint(0, 5))
+    if _MORE_KINDS:
+        kind = int(r.randint(0, 8))                  # campaign only: the suite's seeds keep their cases
+    pcm = _signal(r, kind, nfr, n, ch, bps)
     what = f"seed {seed}: n={n} ch={ch} bps={bps} pred={p.prediction_type} om={p.order_method} " \
            f"order {p.min_prediction_order}..{p.max_prediction_order} porder {p.min_partition_order}..{p.max_partition_order}"
     with flake_amd.Encoder(p, max_frames=nfr) as enc:

@@ -128,7 +128,10 @@ def test_random_frames(oracle, decoder, seed):
     bps = int(r.choice([8, 12, 16, 16, 16, 20, 24, 24]))
     p = _params(r, n, ch, bps)
     nfr = 2 if n * ch > 20000 else int(r.randint(2, 5))
-    pcm = _signal(r, int(r.randint(0, 5)), nfr, n, ch, bps)
+    kind = int(r.randint(0, 5))
+    if _MORE_KINDS:
+        kind = int(r.randint(0, 8))
+    pcm = _signal(r, kind, nfr, n, ch, bps)
     first = int(r.choice([0, 120, 127, 2047, 65530, 2 ** 21 - 2, 2 ** 26 - 1]))
     what = f"frames seed {seed}: n={n} ch={ch} bps={bps} pred={p.prediction_type} om={p.order_method} first={first}"
     with flake_amd.Encoder(p, max_frames=nfr) as enc:

@@ -22,7 +22,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 MAX_ORDER = 32
 MAX_PARTS = 256
 MAX_LAGS = 33
-MAX_BLOCK = 16384
+MAX_BLOCK = 65535
 
 OK, E_GENERIC, E_HIP, E_UNSUPPORTED, E_INVALID, E_NOMEM = 0, -1, -2, -3, -4, -5
 

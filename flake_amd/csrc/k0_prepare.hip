@@ -11,6 +11,10 @@ namespace {
 // Stereo frames that do not qualify for the register path (n > 8192 or n % 4):
 // one workgroup per frame, both channels resident in LDS (int32[2n]).  Other
 // channel counts go to k_prepare_multi.
+// RESIDENT = false: frames too long for LDS (n > 20 k, up to FLAC's 65535) are
+// streamed from global memory in each of the three passes instead (L2 serves the
+// re-reads: a frame is 512 KB at most).
+template <bool RESIDENT>
 __global__ __launch_bounds__(NT)
 void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
                fhip_subframe_info *__restrict__ info, int n, int nch, int bps, int estimate)
@@ -27,20 +31,36 @@ void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
         const int32_t *src = pcm + (size_t)f * n * 2;
         int32_t *L = lds_i32, *R = lds_i32 + n;
         const int2 *src2 = reinterpret_cast<const int2 *>(src);
-        for (int i = tid; i < n; i += NT) {
-            int2 v = src2[i];
-            L[i] = v.x;
-            R[i] = v.y;
+        if (RESIDENT) {
+            for (int i = tid; i < n; i += NT) {
+                int2 v = src2[i];
+                L[i] = v.x;
+                R[i] = v.y;
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        auto left = [&](int i) { return RESIDENT ? L[i] : src2[i].x; };
+        auto right = [&](int i) { return RESIDENT ? R[i] : src2[i].y; };
+        // encode.c:668-693 for one sample-frame of the input
+        auto decorrelate = [&](int32_t &a, int32_t &b, int md) {
+            if (md == FHIP_CH_MID_SIDE) {
+                const int32_t mid = (int32_t)((uint32_t)a + (uint32_t)b) >> 1;
+                const int32_t sd = (int32_t)((uint32_t)a - (uint32_t)b);
+                a = mid; b = sd;
+            } else if (md == FHIP_CH_LEFT_SIDE) {
+                b = (int32_t)((uint32_t)a - (uint32_t)b);
+            } else if (md == FHIP_CH_RIGHT_SIDE) {
+                a = (int32_t)((uint32_t)a - (uint32_t)b);
+            }
+        };
 
         int mode = FHIP_CH_LEFT_RIGHT;
         if (estimate && n > 32) {
             // encode.c:598-643 calc_decorr_scores
             unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             for (int i = tid + 2; i < n; i += NT) {
-                int32_t lt = (int32_t)((uint32_t)L[i] - 2u * (uint32_t)L[i - 1] + (uint32_t)L[i - 2]);
-                int32_t rt = (int32_t)((uint32_t)R[i] - 2u * (uint32_t)R[i - 1] + (uint32_t)R[i - 2]);
+                int32_t lt = (int32_t)((uint32_t)left(i) - 2u * (uint32_t)left(i - 1) + (uint32_t)left(i - 2));
+                int32_t rt = (int32_t)((uint32_t)right(i) - 2u * (uint32_t)right(i - 1) + (uint32_t)right(i - 2));
                 int32_t m = (int32_t)((uint32_t)lt + (uint32_t)rt) >> 1;
                 int32_t s = (int32_t)((uint32_t)lt - (uint32_t)rt);
                 a0 += (unsigned long long)(long long)wrap_abs(lt);
@@ -75,17 +95,9 @@ void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
         // encode.c:668-693 apply, then OR of every sample per channel
         uint32_t or0 = 0, or1 = 0;
         for (int i = tid; i < n; i += NT) {
-            int32_t a = L[i], b = R[i];
-            if (mode == FHIP_CH_MID_SIDE) {
-                int32_t mid = (int32_t)((uint32_t)a + (uint32_t)b) >> 1;
-                int32_t sd = (int32_t)((uint32_t)a - (uint32_t)b);
-                a = mid; b = sd;
-            } else if (mode == FHIP_CH_LEFT_SIDE) {
-                b = (int32_t)((uint32_t)a - (uint32_t)b);
-            } else if (mode == FHIP_CH_RIGHT_SIDE) {
-                a = (int32_t)((uint32_t)a - (uint32_t)b);
-            }
-            L[i] = a; R[i] = b;
+            int32_t a = left(i), b = right(i);
+            decorrelate(a, b, mode);
+            if (RESIDENT) { L[i] = a; R[i] = b; }
             or0 |= (uint32_t)a; or1 |= (uint32_t)b;
         }
         or0 = wave_or_u32(or0); or1 = wave_or_u32(or1);
@@ -107,8 +119,10 @@ void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
 
         int32_t *dst = smp + (size_t)f * 2 * n;
         for (int i = tid; i < n; i += NT) {
-            dst[i] = L[i] >> wasted[0];
-            dst[n + i] = R[i] >> wasted[1];
+            int32_t a = left(i), b = right(i);
+            if (!RESIDENT) decorrelate(a, b, mode);          // resident rows were decorrelated in place
+            dst[i] = a >> wasted[0];
+            dst[n + i] = b >> wasted[1];
         }
         if (tid < 2) {
             fhip_subframe_info *o = &info[(size_t)f * 2 + tid];
@@ -444,11 +458,16 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
     const int blocks = nframes;
     const size_t lds = sizeof(int32_t) * (size_t)n * (nch == 2 ? 2 : 1);
     if (blocks == 0) return hipSuccess;
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prepare),
+    if (lds > 150 * 1024) {
+        // frames of more than ~19 k sample-frames: streamed from global memory
+        hipLaunchKernelGGL(k_prepare<false>, dim3(blocks), dim3(NT), 0, st, pcm, smp, info, n, nch,
+                           p.bits_per_sample, p.stereo_method == 1 ? 1 : 0);
+        return hipGetLastError();
+    }
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prepare<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (er != hipSuccess) return er;
-    hipLaunchKernelGGL(k_prepare, dim3(blocks), dim3(NT), lds, st, pcm, smp, info, n, nch,
+    hipLaunchKernelGGL(k_prepare<true>, dim3(blocks), dim3(NT), lds, st, pcm, smp, info, n, nch,
                        p.bits_per_sample, p.stereo_method == 1 ? 1 : 0);
     return hipGetLastError();
 }

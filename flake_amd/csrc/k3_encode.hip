@@ -83,38 +83,60 @@ __device__ __forceinline__ int clamp_porder(int porder, int n, int order)
 // Rice search over the residuals held in r[] (rice.c:105-187).  Leaves the
 // per-node parameters in l.kpar, the chosen order/method in l.misc and
 // returns the subframe bit estimate.  All threads must call it.
+// The search in three steps, so that a run too long for the registers can be fed
+// piece by piece (k_encode_big): clear, add the finest-level sums of a piece, finish.
+__device__ __forceinline__ void rice_zero(const EncCtx &e)
+{
+    const EncLds &l = e.l;
+    for (int q = e.tid; q < 511; q += NT) l.sums[q] = 0;
+    if (e.tid < 9) { l.lvl_bits[e.tid] = 0; l.lvl_meth[e.tid] = 0; }
+    __syncthreads();
+}
+
+// rice.c:76-94 finest-level sums of the samples i0 .. i0+cnt-1 held in r[]: partition 0
+// starts at `order`
+template <int C>
+__device__ __forceinline__ void rice_accumulate(const EncCtx &e, const int32_t (&r)[C], int order,
+                                                int i0, int cnt)
+{
+    const EncLds &l = e.l;
+    const int n = e.n;
+    const int pmax = clamp_porder(e.pmax_req, n, order);
+    const int psize = n >> pmax;
+    const int heap0 = (1 << pmax) - 1;
+    unsigned long long run = 0;
+    int part = -1, bound = 0;
+#pragma unroll
+    for (int o = 0; o < C; o++) {
+        const int i = i0 + o;
+        if (o < cnt && i < n && i >= order) {
+            if (part < 0) { part = i / psize; bound = (part + 1) * psize; }
+            if (i == bound) {
+                atomicAdd(&l.sums[heap0 + part], run);
+                run = 0; part++; bound += psize;
+            }
+            run += zigzag32(r[o]);
+        }
+    }
+    if (part >= 0) atomicAdd(&l.sums[heap0 + part], run);
+}
+
+__device__ __forceinline__ uint32_t rice_finish(const EncCtx &e, int order, bool lpc);
+
 template <int C>
 __device__ __forceinline__ uint32_t rice_search(const EncCtx &e, const int32_t (&r)[C], int order, bool lpc)
+{
+    rice_zero(e);
+    rice_accumulate<C>(e, r, order, e.i0, e.chunk);
+    return rice_finish(e, order, lpc);
+}
+
+__device__ __forceinline__ uint32_t rice_finish(const EncCtx &e, int order, bool lpc)
 {
     const EncLds &l = e.l;
     const int n = e.n, tid = e.tid;
     const int pmin = clamp_porder(e.pmin_req, n, order);
     const int pmax = clamp_porder(e.pmax_req, n, order);
-    const int psize = n >> pmax;
-
-    for (int q = tid; q < 511; q += NT) l.sums[q] = 0;
-    if (tid < 9) { l.lvl_bits[tid] = 0; l.lvl_meth[tid] = 0; }
-    __syncthreads();
-
-    // rice.c:76-94 finest-level sums: partition 0 starts at `order`
-    {
-        const int heap0 = (1 << pmax) - 1;
-        unsigned long long run = 0;
-        int part = -1, bound = 0;
-#pragma unroll
-        for (int o = 0; o < C; o++) {
-            const int i = e.i0 + o;
-            if (o < e.chunk && i < n && i >= order) {
-                if (part < 0) { part = i / psize; bound = (part + 1) * psize; }
-                if (i == bound) {
-                    atomicAdd(&l.sums[heap0 + part], run);
-                    run = 0; part++; bound += psize;
-                }
-                run += zigzag32(r[o]);
-            }
-        }
-        if (part >= 0) atomicAdd(&l.sums[heap0 + part], run);
-    }
     __syncthreads();
     // rice.c:96-102 pyramid
     for (int p = pmax - 1; p >= pmin; p--) {
@@ -541,6 +563,368 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// K3 for long blocks  k_encode_big -- 16384 < n <= 65535
+// ---------------------------------------------------------------------------
+// Same contract and the same decision tree as k_encode, for blocks whose samples fit
+// neither LDS nor a thread's registers: a thread's run (up to 256 samples) is walked
+// in pieces of BIG_C, the samples are read from global memory (the subframe is at
+// most 256 KB: L2), and residuals are formed again wherever they are needed -- once
+// per candidate for the partition sums, once for the code lengths, once per emit
+// window that the piece's bits touch.  Correctness first: this path serves block
+// sizes outside FLAC's subset that the reference accepts (encode.c:288 ff.).
+constexpr int BIG_C = 64;
+
+// residuals of samples i0 .. i0+cnt-1 (optimize.c:34-122); LPC coefficients in l.coef
+__device__ __forceinline__ void residual_big(const EncCtx &e, const int32_t *__restrict__ x,
+                                             int32_t (&r)[BIG_C], int i0, int cnt, bool lpc, int order, int shift)
+{
+    const EncLds &l = e.l;
+#pragma unroll 4
+    for (int o = 0; o < BIG_C; o++) {
+        const int i = i0 + o;
+        int32_t v = 0;
+        if (o < cnt && i < e.n) {
+            const long long x0 = x[i];
+            if (i < order || order == 0) {
+                v = (int32_t)x0;
+            } else if (lpc) {
+                long long pred = 0;
+                for (int j = order; j >= 1; j--) pred += (long long)l.coef[j - 1] * (long long)x[i - j];
+                v = (int32_t)(x0 - (pred >> shift));
+            } else {
+                const long long x1 = x[i - 1];
+                long long acc = x0 - x1;
+                if (order >= 2) {
+                    const long long x2 = x[i - 2];
+                    acc = x0 - 2 * x1 + x2;
+                    if (order >= 3) {
+                        const long long x3 = x[i - 3];
+                        acc = x0 - 3 * x1 + 3 * x2 - x3;
+                        if (order >= 4) acc = x0 - 4 * x1 + 6 * x2 - 4 * x3 + (long long)x[i - 4];
+                    }
+                }
+                v = (int32_t)acc;
+            }
+        }
+        r[o] = v;
+    }
+}
+
+__global__ __launch_bounds__(NT)
+void k_encode_big(fhip_params P, int n, const int32_t *__restrict__ smp_all,
+                  const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
+                  const int32_t *__restrict__ opt_all, fhip_subframe_info *__restrict__ info,
+                  int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
+                  int raw_order, int raw_lpc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    size_t off[10];
+    enc_lds_layout(0, off);                              // no sample image
+    EncCtx e;
+    e.l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
+    e.l.scan = reinterpret_cast<unsigned long long *>(lds_raw + off[1]);
+    e.l.smp = nullptr;
+    e.l.kpar = reinterpret_cast<int32_t *>(lds_raw + off[3]);
+    e.l.lvl_bits = reinterpret_cast<uint32_t *>(lds_raw + off[4]);
+    e.l.lvl_meth = reinterpret_cast<uint32_t *>(lds_raw + off[5]);
+    e.l.coef = reinterpret_cast<int32_t *>(lds_raw + off[6]);
+    e.l.misc = reinterpret_cast<int32_t *>(lds_raw + off[7]);
+    e.l.bits = reinterpret_cast<uint32_t *>(lds_raw + off[8]);
+    e.l.trial = reinterpret_cast<uint32_t *>(lds_raw + off[9]);
+    const EncLds &l = e.l;
+
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    fhip_subframe_info *out = &info[s];
+    e.n = n;
+    e.tid = tid;
+    e.chunk = (n + NT - 1) / NT;                         // <= 256
+    e.i0 = tid * e.chunk;
+    e.obits = out->obits;
+    e.precision = P.lpc_precision;
+    e.pmin_req = P.min_partition_order;
+    e.pmax_req = P.max_partition_order;
+    const int npieces = (e.chunk + BIG_C - 1) / BIG_C;   // <= 4
+
+    const int32_t *src = smp_all + (size_t)s * n;
+    if (tid == 0) l.misc[M_FLAG] = 0;
+    __syncthreads();
+    {
+        const int32_t first = src[0];
+        int differs = 0;
+        for (int i = tid; i < n; i += NT) differs |= (src[i] != first);
+        if (differs) atomicOr(&l.misc[M_FLAG], 1);
+    }
+    __syncthreads();
+    const bool constant = (l.misc[M_FLAG] == 0);
+
+    int32_t r[BIG_C];
+    int type, type_code, order = 0, shift = 0;
+    uint32_t est_bits = 0;
+    bool has_rice = false, res_lpc = false;
+    int res_order = 0;                                   // predictor of the residual that is kept
+    const int32_t *crow_base = coefs_all + (size_t)s * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
+    const int32_t *srow = shift_all + (size_t)s * FHIP_MAX_ORDER;
+
+    // one candidate: its partition sums piece by piece, then the search (rice.c:105-187)
+    auto evaluate = [&](bool lpc, int pred_order, int rice_order, int sh) -> uint32_t {
+        if (lpc) {
+            __syncthreads();                             // previous readers of l.coef are done
+            if (tid < pred_order) l.coef[tid] = crow_base[(pred_order - 1) * FHIP_MAX_ORDER + tid];
+            __syncthreads();
+        }
+        rice_zero(e);
+        for (int pc = 0; pc < npieces; pc++) {
+            const int i0 = e.i0 + pc * BIG_C, cnt = min(BIG_C, e.chunk - pc * BIG_C);
+            residual_big(e, src, r, i0, cnt, lpc, pred_order, sh);
+            rice_accumulate<BIG_C>(e, r, rice_order, i0, cnt);
+        }
+        return rice_finish(e, rice_order, lpc);
+    };
+
+    enum { T_CONST, T_VERB, T_FIXED, T_LPC, T_RAW } tree;
+    if (raw_order >= 0) tree = T_RAW;
+    else if (constant) tree = T_CONST;                                   // optimize.c:143-151
+    else if (n < 5 || P.prediction_type == 0) tree = T_VERB;             // optimize.c:153-158
+    else if (P.prediction_type == 1 || n <= P.max_prediction_order) tree = T_FIXED;
+    else tree = T_LPC;
+
+    const int omethod = P.order_method;
+    const int min_order = P.min_prediction_order;
+    const int max_order = (tree == T_FIXED) ? min(P.max_prediction_order, 4) : P.max_prediction_order;
+
+    int it = 0, best = 0;
+    uint32_t best_bits = 0, last_bits = 0;
+    bool have_best = false;
+    int lg_step = 16, lg_last = 0, lg_pos = 3;
+    bool final_pass = false;
+
+    if (tree == T_FIXED) { it = min_order; best = min_order; }
+    if (tree == T_LPC) {
+        if (omethod == 0) { best = max_order - 1; final_pass = true; }
+        else if (omethod == 1) { best = opt_all[s] - 1; final_pass = true; }
+        else if (omethod <= 4) { it = (1 << (omethod - 1)) - 1; best = max_order - 1; }
+        else if (omethod == 5) { it = 0; best = 0; }
+        else {
+            best = min_order - 1 + (max_order - min_order) / 3;
+            if (tid < FHIP_MAX_ORDER) l.trial[tid] = 0xFFFFFFFFu;
+            __syncthreads();
+            lg_step = 32;
+        }
+    }
+
+    if (tree == T_RAW) {
+        // the input already is a residual: only calc_rice_params_* with that order
+        rice_zero(e);
+        for (int pc = 0; pc < npieces; pc++) {
+            const int i0 = e.i0 + pc * BIG_C, cnt = min(BIG_C, e.chunk - pc * BIG_C);
+            residual_big(e, src, r, i0, cnt, false, 0, 0);
+            rice_accumulate<BIG_C>(e, r, raw_order, i0, cnt);
+        }
+        est_bits = rice_finish(e, raw_order, raw_lpc != 0);
+        order = raw_order;
+        type = raw_lpc ? FHIP_SUB_LPC : FHIP_SUB_FIXED;
+        type_code = type;
+        has_rice = true;
+        res_order = 0; res_lpc = false;
+    } else if (tree == T_CONST || tree == T_VERB) {
+        type = type_code = (tree == T_CONST) ? FHIP_SUB_CONSTANT : FHIP_SUB_VERBATIM;
+        est_bits = (uint32_t)(tree == T_CONST ? e.obits : e.obits * n);
+    } else {
+        for (;;) {
+            int cand = -1;
+            if (!final_pass) {
+                if (tree == T_FIXED) {
+                    if (it <= max_order) cand = it;
+                } else if (omethod <= 4) {
+                    if (it >= 0) {
+                        const int levels = 1 << (omethod - 1);
+                        cand = min_order + (((max_order - min_order + 1) * (it + 1)) / levels) - 2;
+                        if (cand < 0) cand = 0;
+                    }
+                } else if (omethod == 5) {
+                    if (it < max_order) cand = it;
+                } else {
+                    for (;;) {
+                        if (lg_pos == 3) {
+                            lg_step >>= 1;
+                            if (lg_step == 0) break;
+                            lg_last = best;
+                            lg_pos = 0;
+                        }
+                        const int i = lg_last + (lg_pos - 1) * lg_step;
+                        lg_pos++;
+                        if (i < min_order - 1 || i >= max_order || l.trial[i] < 0xFFFFFFFFu) continue;
+                        cand = i;
+                        break;
+                    }
+                }
+                if (cand < 0) {
+                    if (tree == T_FIXED && best == max_order) { est_bits = last_bits; break; }
+                    final_pass = true;
+                }
+            }
+            if (final_pass) cand = best;
+
+            uint32_t b;
+            if (tree == T_FIXED) b = evaluate(false, cand, cand, 0);
+            else b = evaluate(true, cand + 1, cand + 1, srow[cand]);
+            if (final_pass) { est_bits = b; break; }
+
+            last_bits = b;
+            if (tree == T_FIXED) {
+                if (!have_best || b < best_bits) { best_bits = b; best = cand; }
+                it++;
+            } else if (omethod <= 4) {
+                if (!have_best) best_bits = b;
+                else if (b < best_bits) { best_bits = b; best = cand; }
+                it--;
+            } else if (omethod == 5) {
+                if (!have_best || b < best_bits) { best_bits = b; best = cand; }
+                it++;
+            } else {
+                if (tid == 0) l.trial[cand] = b;
+                __syncthreads();
+                if (b < l.trial[best]) best = cand;
+            }
+            have_best = true;
+        }
+        if (tree == T_FIXED) {
+            order = best;
+            type = FHIP_SUB_FIXED;
+            type_code = FHIP_SUB_FIXED | order;
+            res_order = order; res_lpc = false;
+        } else {
+            order = best + 1;
+            shift = srow[best];
+            type = FHIP_SUB_LPC;
+            type_code = FHIP_SUB_LPC | (order - 1);
+            res_order = order; res_lpc = true;           // l.coef holds this row (last one staged)
+        }
+        has_rice = true;
+    }
+
+    const int porder = has_rice ? l.misc[M_PORDER] : 0;
+    const int method = has_rice ? l.misc[M_METHOD] : 0;
+
+    // FlacSubframe.residual (the samples themselves for CONSTANT / VERBATIM)
+    if (res_out) {
+        int32_t *dst = res_out + (size_t)s * n;
+        for (int pc = 0; pc < npieces; pc++) {
+            const int i0 = e.i0 + pc * BIG_C, cnt = min(BIG_C, e.chunk - pc * BIG_C);
+            residual_big(e, src, r, i0, cnt, has_rice && res_lpc, has_rice ? res_order : 0, shift);
+            for (int o = 0; o < BIG_C; o++)
+                if (o < cnt && i0 + o < n) dst[i0 + o] = r[o];
+        }
+    }
+
+    // encode.c:766-798 output_residual
+    long long total_bits = 0;
+    if (has_rice) {
+        const int psz = n >> porder;
+        const int pbits = 4 + method;
+        const int heap0 = (1 << porder) - 1;
+        unsigned long long piece_off[5];                 // bits in front of each piece of this run
+        unsigned long long mine = 0;
+        for (int pc = 0; pc < 4; pc++) {
+            piece_off[pc] = mine;
+            if (pc < npieces) {
+                const int i0 = e.i0 + pc * BIG_C, cnt = min(BIG_C, e.chunk - pc * BIG_C);
+                residual_big(e, src, r, i0, cnt, res_lpc, res_order, shift);
+                for (int o = 0; o < BIG_C; o++) {
+                    const int i = i0 + o;
+                    if (o < cnt && i < n && i >= order) {
+                        const int part = i / psz;
+                        const int k = l.kpar[heap0 + part];
+                        if (part > 0 && i == part * psz) mine += pbits;
+                        mine += (unsigned long long)(emit_fold32(r[o]) >> k) + 1 + k;
+                    }
+                }
+            }
+        }
+        piece_off[4] = mine;
+        unsigned long long incl = wave_incl_scan_u64(mine, lane);
+        if (lane == 63) l.scan[wv] = incl;
+        __syncthreads();
+        unsigned long long base = 6 + pbits;
+        for (int w = 0; w < wv; w++) base += l.scan[w];
+        const unsigned long long tot = 6 + pbits + l.scan[0] + l.scan[1] + l.scan[2] + l.scan[3];
+        const unsigned long long my_off = base + incl - mine;
+        total_bits = (tot > 0x7FFFFFFFull) ? 0x7FFFFFFFll : (long long)tot;
+
+        if (bits_out) {
+            if (tot > (unsigned long long)slot_bytes * 8ull) {
+                total_bits = -1;
+            } else {
+                uint32_t *dst32 = reinterpret_cast<uint32_t *>(bits_out + (size_t)s * slot_bytes);
+                const long long nwords = (long long)((tot + 31) >> 5);
+                for (long long wlo = 0; wlo < nwords; wlo += ENC_WWORDS) {
+                    __syncthreads();
+                    for (int q = tid; q < ENC_WWORDS; q += NT) l.bits[q] = 0;
+                    __syncthreads();
+                    if (tid == 0) {
+                        put_bits(l.bits, wlo, 0, 2, (uint32_t)method);
+                        put_bits(l.bits, wlo, 2, 4, (uint32_t)porder);
+                        put_bits(l.bits, wlo, 6, pbits, (uint32_t)l.kpar[heap0]);
+                    }
+                    const long long win_lo = wlo * 32, win_hi = (wlo + ENC_WWORDS) * 32;
+                    for (int pc = 0; pc < npieces; pc++) {
+                        // only the pieces whose bits reach into this window are formed again
+                        const long long p_lo = (long long)(my_off + piece_off[pc]);
+                        const long long p_hi = (long long)(my_off + piece_off[pc + 1]);
+                        if (p_hi <= win_lo - 64 || p_lo >= win_hi) continue;
+                        const int i0 = e.i0 + pc * BIG_C, cnt = min(BIG_C, e.chunk - pc * BIG_C);
+                        residual_big(e, src, r, i0, cnt, res_lpc, res_order, shift);
+                        long long pos = p_lo;
+                        for (int o = 0; o < BIG_C; o++) {
+                            const int i = i0 + o;
+                            if (o < cnt && i < n && i >= order) {
+                                const int part = i / psz;
+                                const int k = l.kpar[heap0 + part];
+                                if (part > 0 && i == part * psz) {
+                                    put_bits(l.bits, wlo, pos, pbits, (uint32_t)k);
+                                    pos += pbits;
+                                }
+                                const uint32_t u = emit_fold32(r[o]);
+                                const uint32_t q = u >> k;
+                                put_bits(l.bits, wlo, pos + q, k + 1, (1u << k) | (u & ((1u << k) - 1u)));
+                                pos += (long long)q + 1 + k;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    const long long cnt = (nwords - wlo < ENC_WWORDS) ? (nwords - wlo) : (long long)ENC_WWORDS;
+                    for (int q = tid; q < cnt; q += NT)
+                        dst32[wlo + q] = __builtin_bswap32(l.bits[q]);
+                }
+            }
+        }
+    }
+
+    if (tid == 0) {
+        out->type = type;
+        out->type_code = type_code;
+        out->order = order;
+        out->shift = shift;
+        out->rice_method = method;
+        out->porder = porder;
+        out->est_bits = est_bits;
+        out->rice_nbits = (int32_t)total_bits;
+        out->reserved = 0;
+    }
+    if (tid < FHIP_MAX_ORDER)
+        out->coefs[tid] = (type == FHIP_SUB_LPC && tid < order && raw_order < 0) ? l.coef[tid] : 0;
+    {
+        const int np = has_rice ? (1 << porder) : 0;
+        out->rparams[tid] = (tid < np) ? l.kpar[np - 1 + tid] : 0;
+    }
+    if (tid < FHIP_MAX_ORDER) {
+        const int nw = (type == FHIP_SUB_CONSTANT) ? 1 : order;
+        out->warmup[tid] = (tid < nw && tid < n) ? src[tid] : 0;
+    }
+}
 
 // ---------------------------------------------------------------------------
 // K3 fast path  k_encode_pow2<C, T>
@@ -1772,7 +2156,7 @@ size_t encode_lds_bytes(int n)
 {
     if (n < 1 || n > FHIP_MAX_BLOCK) return 0;
     size_t off[10];
-    return enc_lds_layout(n, off);
+    return enc_lds_layout(n > FHIP_MAX_RESIDENT_BLOCK ? 0 : n, off);      // long blocks: no sample image (k_encode_big)
 }
 
 // Fast-path geometry for a block size: C samples per thread, T threads,
@@ -1884,6 +2268,11 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
     }
     const size_t lds = encode_lds_bytes(n);
     if (lds == 0) return hipErrorInvalidValue;
+    if (n > FHIP_MAX_RESIDENT_BLOCK) {
+        hipLaunchKernelGGL(k_encode_big, dim3(nsub), dim3(NT), lds, st, p, n, smp, coefs, shift,
+                           opt_order, info, residual, bits, (long long)slot_bytes, raw_order, raw_lpc);
+        return hipGetLastError();
+    }
     const int chunk = (n + NT - 1) / NT;
 #define LAUNCH_ENC(CC)                                                                       \
     do {                                                                                     \

@@ -9,6 +9,10 @@
 
 namespace fhip {
 
+// Blocks up to this size keep a subframe's samples in LDS / registers (K3's k_encode and
+// k_encode_pow2); longer ones, up to FHIP_MAX_BLOCK, stream them (k_encode_big).
+constexpr int FHIP_MAX_RESIDENT_BLOCK = 16384;
+
 // Everything a launch needs that does not change within a batch.
 struct EncodeArgs {
     fhip_params p;

@@ -38,9 +38,9 @@ extern "C" {
 #define FHIP_MAX_CH      8      /* FLAC_MAX_CH, encode.h:33 */
 #define FHIP_MAX_LAGS    (FHIP_MAX_ORDER + 1)
 
-/* largest block the kernels keep resident in LDS; larger blocks return
- * FHIP_E_UNSUPPORTED (the reference allows up to 65535, encode.h:35) */
-#define FHIP_MAX_BLOCK   16384
+/* largest block (the reference's limit, encode.h:35); blocks above 16384 take
+ * streaming variants of K0 and K3 (correct, not tuned) */
+#define FHIP_MAX_BLOCK   65535    /* FLAC's and libflake's limit (encode.c:288) */
 
 enum {
     FHIP_OK            =  0,

@@ -76,3 +76,15 @@ def test_full_batch_crc_and_decode(decoder):
     stream = np.concatenate([got["frames"][f, :got["frame_bytes"][f]] for f in range(1024)])
     out, sizes = decoder.decode(stream, 2, 16, 1024 * 4096)
     assert len(sizes) == 1024 and (out.reshape(pcm.shape) == pcm).all()
+
+
+@pytest.mark.parametrize("n", [20000, 32768, 65535])
+def test_long_block_frames(oracle, decoder, n):
+    """Frames of blocks above 16384 (libflake allows 65535): 16-bit block-size field in the
+    header, long residual sections, CRC over up to 260 KB."""
+    p = flake_amd.level_params(5, block_size=n)
+    pcm = flake_amd.synth_pcm(3, n, 2, 16, first_frame=5)
+    check_frames(oracle, decoder, p, pcm, n, first=7, what=f"long n{n}")
+    p = flake_amd.level_params(2, channels=1, bits_per_sample=24, block_size=n)
+    pcm = flake_amd.synth_pcm(2, n, 1, 24, first_frame=9)
+    check_frames(oracle, decoder, p, pcm, n, first=0, what=f"long mono24 n{n}")

@@ -81,6 +81,7 @@ def _params(r, n, ch, bps):
 # FLAKE_FUZZ_FIRST / FLAKE_FUZZ_SEEDS widen the sweep for a campaign (default: seeds 0..383)
 _FIRST = int(os.environ.get("FLAKE_FUZZ_FIRST", "0"))
 _COUNT = int(os.environ.get("FLAKE_FUZZ_SEEDS", "384"))
+_LONG = os.environ.get("FLAKE_FUZZ_LONG", "") != ""                # campaign: blocks of 16385 .. 65535
 _MORE_KINDS = os.environ.get("FLAKE_FUZZ_KINDS", "") != ""         # campaign: three more signal kinds
 _MORE_FRAMES = os.environ.get("FLAKE_FUZZ_FRAMES", "") != ""      # campaign: 17..69 frames per case
 
@@ -94,6 +95,8 @@ _REGRESSIONS = [484, 3185] if "FLAKE_FUZZ_FIRST" not in os.environ else []
 def test_random_configuration(oracle, seed):
     r = np.random.RandomState(1000 + seed)
     n = int(BLOCKS[r.randint(0, len(BLOCKS))])
+    if _LONG:
+        n = int(r.choice([16385, 17000, 20480, 24576, 30000, 32768, 49152, 65535]))   # streaming K0 / K3
     ch = int(r.choice([1, 2, 2, 2, 3, 6, 8]))
     bps = int(r.choice([8, 12, 16, 16, 16, 20, 24, 24, 32]))
     p = _params(r, n, ch, bps)

@@ -455,3 +455,28 @@ def test_fixed_order_and_partition_ranges(oracle, n, orders):
         p = flake_amd.level_params(5, channels=2, bits_per_sample=24, block_size=n, **kw)
         pcm = flake_amd.synth_pcm(3, n, 2, 24, first_frame=7)
         check(oracle, p, pcm, n, f"fixed_stereo24_n{n}_{orders}_{pmin}-{pmax}")
+
+
+@pytest.mark.parametrize("n", [16385, 20000, 24576, 32768, 40000, 65535])
+def test_long_blocks(oracle, n):
+    """Blocks above 16384 (outside FLAC's subset, inside libflake's 65535 limit,
+    encode.h:35) take the streaming K0 and K3: stereo with every decorrelation mode in
+    reach, mono 24-bit through an order search, a fixed-order range, wasted bits, and a
+    constant subframe."""
+    r = np.random.RandomState(n)
+    t = np.arange(n)
+    base = (9000 * np.sin(t * 0.013) + 2000 * np.sin(t * 0.31)).astype(np.int64)
+    stereo = np.stack([
+        np.stack([base + r.randint(-40, 40, n), base + r.randint(-40, 40, n)], 1),           # mid/side wins
+        np.stack([base, r.randint(-3000, 3000, n)], 1),                                       # independent
+        np.stack([(base >> 3) << 3, np.full(n, 1234)], 1),                                    # wasted bits, constant
+    ]).astype(np.int32)
+    for kw in (dict(order_method=flake_amd.OM_MAX),
+               dict(order_method=flake_amd.OM_LOG, max_prediction_order=12, max_partition_order=8),
+               dict(prediction_type=flake_amd.PRED_FIXED, min_prediction_order=0, max_prediction_order=4)):
+        p = flake_amd.level_params(5, block_size=n, **kw)
+        check(oracle, p, stereo, n, f"long stereo n{n}")
+    mono = flake_amd.synth_pcm(2, n, 1, 24, first_frame=3)
+    p = flake_amd.level_params(5, channels=1, bits_per_sample=24, block_size=n,
+                               order_method=flake_amd.OM_4LEVEL, max_partition_order=8)
+    check(oracle, p, mono, n, f"long mono24 n{n}")

@@ -276,3 +276,17 @@ def test_random_streams(oracle, decoder, seed):
         out, _ = decoder.decode(data, ch, bps, total)
         assert (out == pcm).all(), what
         assert bytes(enc.streaminfo().md5sum) == pcm_md5(pcm, bps), what
+
+
+@pytest.mark.parametrize("n", [24000, 65535])
+def test_long_blocks_through_the_host_layer(oracle, decoder, n):
+    with flake_amd.HostEncoder(5, block_size=n) as enc:
+        p = enc.params()
+        pcm = flake_amd.synth_pcm(1, 3 * n + 1000, 2, 16, first_frame=2)[0]
+        data, sizes = enc.encode_frames(pcm, n, 1000)
+        exp, esizes = oracle_stream(oracle, p, pcm, n, 1000)
+        assert (sizes == esizes).all()
+        assert data.tobytes() == exp.tobytes()
+        out, _ = decoder.decode(data, 2, 16, pcm.shape[0])
+        assert (out == pcm).all()
+        assert bytes(enc.streaminfo().md5sum) == pcm_md5(pcm, 16)

@@ -1037,7 +1037,7 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
     const FastLds &l = e.l;
     const double inv = __builtin_ldexp(1.0, -shift);
     // outputs per register block: a divisor of C
-    constexpr int OB = (C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : 1;
+    constexpr int OB = (C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : (C % 5 == 0) ? 5 : (C % 7 == 0) ? 7 : 1;
     // taps per block: a multiple of C (going back C*k samples is going back k
     // columns of the image, so every block sees the same immediate offsets)
     constexpr int TB = (16 % C == 0) ? 16 : C * ((8 + C - 1) / C);
@@ -1123,7 +1123,7 @@ __device__ __forceinline__ void fir_lpc_o8(const FastCtx<C, T> &e, int32_t (&r)[
 {
     using Img = SmpImg<C, T>;
     const double inv = __builtin_ldexp(1.0, -shift);
-    constexpr int OB = (C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : 1;
+    constexpr int OB = (C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : (C % 5 == 0) ? 5 : (C % 7 == 0) ? 7 : 1;
     const int32_t *mine = e.l.smp + e.tid * Img::CS;
     double cf[8];
 #pragma unroll
@@ -1611,7 +1611,7 @@ template <int C, int T, int MODE>
 // workgroups per CU (-3 %); forcing MODE 2 to 96 spills and is slower.
 // Geometry for n = 4096, measured: (C,T) = (16,256) 94 us, (8,512) 137, (4,1024)
 // 256, (32,128) 115 (206 VGPRs): cross-wave phases grow with T, serial ones with C.
-__global__ __launch_bounds__(T, (MODE == 2 || C >= 16) ? 4 : 5)   // VGPR cap per waves/SIMD: 4 -> 128, 5 -> 96
+__global__ __launch_bounds__(T, (MODE == 2 || C >= 14) ? 4 : 5)   // VGPR cap per waves/SIMD: 4 -> 128, 5 -> 96
 void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ smp_all,
                    const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                    const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,
@@ -2181,6 +2181,10 @@ bool fast_geometry(const fhip_params &p, int n, int *C, int *T)
     } else if (odd == 3) {                // 192, 384, 768, 1536, ...
         c = 3; t = 1 << lg;
         if (t > 1024) { c = 0; }
+    } else if ((odd == 5 || odd == 7) && (lg == 9 || lg == 10)) {
+        // 2560, 3584, 5120, 7168: five or seven eighths of a 4096 / 8192 block, the pieces
+        // the VBS splitter (vbs.c:36-83) makes most often besides the plain power-of-two ones
+        c = 2 * odd; t = 1 << (lg - 1);
     } else {
         return false;
     }
@@ -2251,6 +2255,10 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
         case 80064: LAUNCH_FAST(8, 64); break;
         case 40064: LAUNCH_FAST(4, 64); break;
         case 90064: LAUNCH_FAST(9, 64); break;
+        case 100256: LAUNCH_FAST(10, 256); break;
+        case 100512: LAUNCH_FAST(10, 512); break;
+        case 140256: LAUNCH_FAST(14, 256); break;
+        case 140512: LAUNCH_FAST(14, 512); break;
         case 180256: LAUNCH_FAST(18, 256); break;
         case 180512: LAUNCH_FAST(18, 512); break;
         case 90128: LAUNCH_FAST(9, 128); break;

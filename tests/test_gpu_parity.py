@@ -346,8 +346,8 @@ def test_config4_full_size_properties(oracle, decoder):
     assert np.concatenate([a["info"], b["info"]]).tobytes() == got["info"].tobytes()
 
 
-@pytest.mark.parametrize("n", [192, 256, 384, 512, 576, 768, 1024, 1152, 1536, 2048, 2304, 3072,
-                               4608, 6144, 8192, 9216, 12288, 16384])
+@pytest.mark.parametrize("n", [192, 256, 384, 512, 576, 768, 1024, 1152, 1536, 2048, 2304, 2560, 3072,
+                               3584, 4608, 5120, 6144, 7168, 8192, 9216, 12288, 16384])
 @pytest.mark.parametrize("kw", [
     dict(order_method=flake_amd.OM_MAX),
     dict(order_method=flake_amd.OM_LOG, max_prediction_order=12, max_partition_order=8),

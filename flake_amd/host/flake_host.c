@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "flake_amd.h"
 #include "flakehip.h"
@@ -41,6 +42,7 @@ typedef struct host_ctx {
     int host_assembly;                    /* FLAKE_AMD_HOST_ASSEMBLY=1: build frames on the CPU */
     int host_vbs;                         /* FLAKE_AMD_HOST_VBS=1: split blocks on the CPU */
     int md5_off;                          /* FLAKE_AMD_MD5=0: STREAMINFO carries the all-zero "not computed" MD5 */
+    int trace;                            /* FLAKE_AMD_TRACE=1: phase times of every batch on stderr */
     /* FLAKE_AMD_LOOKAHEAD=N: flake_encode_frame() queues up to N whole blocks and
      * encodes them as one GPU batch (see flake_amd_encode_frame) */
     int lookahead;
@@ -364,6 +366,7 @@ FLAKE_AMD_API int flake_amd_encode_init(FlakeAmdContext *s)
     c->host_assembly = eh && eh[0] == '1';
     { const char *ev = getenv("FLAKE_AMD_HOST_VBS"); c->host_vbs = ev && ev[0] == '1'; }
     { const char *ev = getenv("FLAKE_AMD_MD5"); c->md5_off = ev && ev[0] == '0'; }
+    { const char *ev = getenv("FLAKE_AMD_TRACE"); c->trace = ev && ev[0] == '1'; }
     c->max_batch = eb ? atoi(eb) : 1024;
     if (c->max_batch < 1) c->max_batch = 1;
     if (c->lookahead > c->max_batch) c->max_batch = c->lookahead;
@@ -590,6 +593,13 @@ static int run_gpu(host_ctx *c, const int32_t *pcm, int nframes, int n, size_t f
     return rc;
 }
 
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 /* encode.c:1006 md5_accumulate over the batch's input, on a helper thread: the
  * hash is sequential over the whole stream (~0.5 GB/s) and would otherwise sit
  * behind every GPU batch. */
@@ -620,6 +630,8 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
     if (!c->md5_off) md5_running = pthread_create(&md5_thread, NULL, md5_worker, &job) == 0;
     int np = 0;
     int32_t *dev_nf = NULL, *dev_sizes = NULL;
+    double t_begin = now_ms(), t_split = 0, t_gather = 0, t_gpu = 0, t_out = 0;
+    int ngroups = 0;
     if (vbs && !c->host_vbs) {
         /* split_frame_v1 on the device (K-vbs) for the whole batch */
         dev_nf = (int32_t *)malloc(sizeof(int32_t) * (size_t)count);
@@ -653,6 +665,7 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
             np++;
         }
     }
+    t_split = now_ms() - t_begin;
     /* GPU: one launch per distinct frame length; pieces keep their order in info[] */
     long long total = -1;
     int *slot_of = (int *)malloc(sizeof(int) * (size_t)np);
@@ -678,6 +691,7 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
                 cnt++;
             }
             const int32_t *src = base;
+            const double tg0 = now_ms();
             if (!contiguous) {
                 int k = 0;
                 for (int j = i; j < np; j++) {
@@ -695,7 +709,9 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
                     k++;
                 }
             }
+            const double tg1 = now_ms();
             if (run_gpu(c, src, cnt, n, (size_t)next_slot * nch, (size_t)next_slot) != FHIP_OK) goto out;
+            t_gather += tg1 - tg0; t_gpu += now_ms() - tg1; ngroups++;
             int k = 0;
             for (int j = i; j < np; j++) {
                 if (done[j] || pieces[j].n != n) continue;
@@ -708,6 +724,7 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
     }
     /* host: frames in stream order */
     {
+        const double to0 = now_ms();
         size_t pos = 0;
         int cur_block = -1;
         for (int i = 0; i < np; i++) {
@@ -733,7 +750,12 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
             pos += (size_t)fs;
         }
         total = (long long)pos;
+        t_out = now_ms() - to0;
     }
+    if (c->trace)
+        fprintf(stderr, "flake_amd batch: %d blocks -> %d frames in %d size groups; split %.2f ms, gather %.2f, "
+                        "gpu (H2D + kernels + D2H) %.2f, copy-out %.2f\n", count, np, ngroups, t_split, t_gather,
+                t_gpu, t_out);
     if (!c->md5_off) {
         if (md5_running) { pthread_join(md5_thread, NULL); md5_running = 0; }
         else md5_worker(&job);                         /* no thread: hash here */

@@ -76,7 +76,8 @@ FLAKE_AMD_API int flake_amd_validate_params(const FlakeAmdContext *s);
  * queues and all queued frames at once when it flushes (see flake_host.c).
  * FLAKE_AMD_MD5=0 skips the stream MD5 (STREAMINFO then carries the all-zero
  * "not computed" signature); FLAKE_AMD_HOST_ASSEMBLY=1 / FLAKE_AMD_HOST_VBS=1 move
- * frame assembly / block splitting back to the CPU (for comparison). */
+ * frame assembly / block splitting back to the CPU (for comparison);
+ * FLAKE_AMD_TRACE=1 prints the phase times of every batch on stderr. */
 FLAKE_AMD_API int flake_amd_encode_init(FlakeAmdContext *s);
 /* flake_get_buffer(), encode.c:474-485: frame buffer of flake_amd_encode_frame */
 FLAKE_AMD_API void *flake_amd_get_buffer(const FlakeAmdContext *s);

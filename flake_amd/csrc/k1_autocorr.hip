@@ -847,9 +847,9 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
 namespace {
 // Which K1 kernel serves a batch: a measured time model in ns (MI355X; rounds =
 // workgroup waves over the chip, step = one walk step):
-//   wt : rounds x (n/2 x max(30, 6.2 NCH) + 3200)      32 subframes per workgroup, whole tiles only
+//   wt : rounds x (n/2 x max(23, 4.8 NCH) + 8000)      32 subframes per workgroup, whole tiles only, K2 included
 //   ps : rounds x (n/2 x 39 + 1000)                      Gp subframes per wave
-//   cur: rounds x (n x 20 + 1000)                        G subframes per wave
+//   cur: passes of 2048 waves x (n x 33..41 + 1000)      G subframes per wave
 struct ac_choice { int kernel; int G, nl2, Gp, lps, ge, ne, no; };   // kernel: 0 cur, 1 ps, 2 wt
 ac_choice pick_autocorr(int nsub, int n, int max_order)
 {
@@ -868,15 +868,22 @@ ac_choice pick_autocorr(int nsub, int n, int max_order)
     ch.lps = 2 * (ch.ge + go);
     ch.Gp = WAVE / ch.lps;
     if (ch.Gp > PS_GMAX) ch.Gp = PS_GMAX;
-    const double t_cur = (double)((waves_cur + simds - 1) / simds) * (n * 20.0 + 1000.0);
+    // k_autocorr keeps two waves per SIMD resident (LDS): 2048 walk at once, at 33 ns per
+    // position alone on a SIMD and 41 when two share it (measured at n = 1536 .. 3584)
+    const double t_cur = (double)((waves_cur + 2 * simds - 1) / (2 * simds)) *
+                         (n * (waves_cur > simds ? 41.0 : 33.0) + 1000.0);
     const double t_ps = (ch.Gp >= 1) ? (double)(((nsub + ch.Gp - 1) / ch.Gp + simds - 1) / simds) * (0.5 * n * 39.0 + 1000.0) : 1e30;
     double t_wt = 1e30;
     if ((n % AC_TILE) == 0) {
         const int e0 = (ch.ne + 1) / 2;
-        const double per_step = (6.2 * e0 > 30.0) ? 6.2 * e0 : 30.0;
-        t_wt = (double)(((nsub + WT_SUB - 1) / WT_SUB + 255) / 256) * (0.5 * n * per_step + 3200.0);
+        // re-measured after this round's changes: 23 ns per step up to three chains per
+        // group, 8 us per launch for barriers, head and the K2 tail (n = 2560 .. 7168)
+        const double per_step = (4.8 * e0 > 23.0) ? 4.8 * e0 : 23.0;
+        t_wt = (double)(((nsub + WT_SUB - 1) / WT_SUB + 255) / 256) * (0.5 * n * per_step + 8000.0);
     }
-    ch.kernel = (t_wt <= t_ps && t_wt <= t_cur) ? 2 : (t_ps < t_cur) ? 1 : 0;
+    // only the wave-typed kernel runs K2 as its tail; the others pay its launch (~9 us)
+    const double k2 = (max_order <= 12) ? 9000.0 : 0.0;
+    ch.kernel = (t_wt <= t_ps + k2 && t_wt <= t_cur + k2) ? 2 : (t_ps < t_cur) ? 1 : 0;
     if (const char *force = getenv("FHIP_AC_KERNEL")) {       // "cur" / "ps" / "wt": measurements only
         if (force[0] == 'c') ch.kernel = 0;
         if (force[0] == 'p' && ch.Gp >= 1) ch.kernel = 1;

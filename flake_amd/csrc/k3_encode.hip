@@ -1872,6 +1872,17 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                         const int32_t cv = (tid < ord) ? crow_base[cand * FHIP_MAX_ORDER + tid] : 0;
                         l.coef[tid] = cv;
                         l.coefd[tid] = (double)cv;
+                        if constexpr (C % 8 == 0) {
+                            // what the packed FIR wants of a candidate row (orders <= 8): the taps as
+                            // int16 pairs (lo: tap 2j+2, hi: tap 2j+1) and the sum of their magnitudes
+                            const int32_t nb = __shfl_xor(cv, 1, WAVE);            // the pair's other tap
+                            if (tid < 8 && (tid & 1) == 0) l.misc[tid >> 1] = (nb & 0xFFFF) | (cv << 16);
+                            int32_t sa = cv < 0 ? -cv : cv;
+                            sa += __shfl_xor(sa, 1, WAVE); sa += __shfl_xor(sa, 2, WAVE);
+                            sa += __shfl_xor(sa, 4, WAVE); sa += __shfl_xor(sa, 8, WAVE);
+                            sa += __shfl_xor(sa, 16, WAVE);
+                            if (tid == 0) l.misc[4] = sa;
+                        }
                     }
                     cshift = srow[cand];
                     __syncthreads();
@@ -1883,6 +1894,11 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                     if (pre_row && ord <= 8 && magbits_n >= 0 &&
                         ((unsigned long long)(uint32_t)fcabs_n << magbits_n) < (1ull << 31)) {
                         fir_lpc_dot8<C, T>(e, r, ord, cshift, fin_all + (size_t)s * FIN_STRIDE + FIN_PAIRS);
+                        done = true;
+                    }
+                    if (!pre_row && ord <= 8 && magbits_n >= 0 &&
+                        ((unsigned long long)(uint32_t)l.misc[4] << magbits_n) < (1ull << 31)) {
+                        fir_lpc_dot8<C, T>(e, r, ord, cshift, l.misc);
                         done = true;
                     }
                 }

@@ -1174,43 +1174,55 @@ __device__ __forceinline__ void fir_lpc_o8(const FastCtx<C, T> &e, int32_t (&r)[
     }
 }
 
+template <int C, int T, int NP>
+__device__ __forceinline__ void fir_lpc_dotn(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
+                                             const int32_t *__restrict__ cp);
+template <int C, int T>
+__device__ __forceinline__ void fir_lpc_dot8(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
+                                             const int32_t *__restrict__ cp)
+{
+    fir_lpc_dotn<C, T, 4>(e, r, order, shift, cp);
+}
+
 // Orders <= 8 on a channel whose samples fit 16 bits (K0's narrow rows), when the
 // prediction provably stays inside int32 (sum|coef| * 2^magbits < 2^31, checked by
 // the caller): v_dot2_i32_i16 does two taps per instruction on int16 pairs and
 // costs about what one fp64 FMA does, with no int -> fp64 conversions in front.
 // Sample pairs R(k) = (lo: x[k], hi: x[k+1]) are packed from the int32 window;
 // cp[j] = (lo: coef of tap 2j+2, hi: coef of tap 2j+1) comes from K2 (scalars).
-template <int C, int T>
-__device__ __forceinline__ void fir_lpc_dot8(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
+// NP = int16 pairs per output: 4 for orders <= 8, 8 for orders <= 16 (order searches).
+template <int C, int T, int NP>
+__device__ __forceinline__ void fir_lpc_dotn(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
                                              const int32_t *__restrict__ cp)
 {
     using Img = SmpImg<C, T>;
-    static_assert(Img::V4 && C % 8 == 0, "fir_lpc_dot8: runs of 8 or 16");
+    static_assert(Img::V4 && C % 8 == 0 && (NP == 4 || NP == 8), "fir_lpc_dotn: runs of 8 or 16");
     typedef short s2 __attribute__((ext_vector_type(2)));
+    constexpr int H = 2 * NP;                              // samples of history an output reaches back
     const int32_t *mine = e.l.smp + e.tid * Img::CS;
-    const s2 q0 = __builtin_bit_cast(s2, cp[0]), q1 = __builtin_bit_cast(s2, cp[1]);
-    const s2 q2 = __builtin_bit_cast(s2, cp[2]), q3 = __builtin_bit_cast(s2, cp[3]);
+    s2 q[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) q[j] = __builtin_bit_cast(s2, cp[j]);
 #pragma unroll
     for (int ob = 0; ob < C; ob += 8) {
         __builtin_amdgcn_sched_barrier(0);
-        int32_t W[16];                                     // samples ob-8 .. ob+7
+        int32_t W[H + 8];                                  // samples ob-H .. ob+7
 #pragma unroll
-        for (int m4 = 0; m4 < 16; m4 += 4) {
-            const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob - 8 + m4));
+        for (int m4 = 0; m4 < H + 8; m4 += 4) {
+            const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob - H + m4));
             W[m4] = v.x; W[m4 + 1] = v.y; W[m4 + 2] = v.z; W[m4 + 3] = v.w;
         }
-        s2 R[14];                                          // R[m] = (x[ob-8+m], x[ob-7+m])
+        s2 R[H + 6];                                       // R[m] = (x[ob-H+m], x[ob-H+1+m])
 #pragma unroll
-        for (int m = 0; m < 14; m++)
+        for (int m = 0; m < H + 6; m++)
             R[m] = __builtin_bit_cast(s2, (int32_t)__builtin_amdgcn_perm((uint32_t)W[m + 1], (uint32_t)W[m], 0x05040100u));
 #pragma unroll
         for (int o = 0; o < 8; o++) {
-            // taps (1,2) use x[o-2], x[o-1] = R at window index o+6; (3,4): o+4; (5,6): o+2; (7,8): o
-            int32_t acc = __builtin_amdgcn_sdot2(R[o + 6], q0, 0, false);
-            acc = __builtin_amdgcn_sdot2(R[o + 4], q1, acc, false);
-            acc = __builtin_amdgcn_sdot2(R[o + 2], q2, acc, false);
-            acc = __builtin_amdgcn_sdot2(R[o], q3, acc, false);
-            r[ob + o] = (int32_t)((uint32_t)W[8 + o] - (uint32_t)(acc >> shift));
+            // taps (2j+1, 2j+2) use x[o-2j-2], x[o-2j-1] = R at window index o + H - 2 - 2j
+            int32_t acc = 0;
+#pragma unroll
+            for (int j = 0; j < NP; j++) acc = __builtin_amdgcn_sdot2(R[o + H - 2 - 2 * j], q[j], acc, false);
+            r[ob + o] = (int32_t)((uint32_t)W[H + o] - (uint32_t)(acc >> shift));
         }
     }
     if (e.i0 < order) {
@@ -1873,15 +1885,15 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                         l.coef[tid] = cv;
                         l.coefd[tid] = (double)cv;
                         if constexpr (C % 8 == 0) {
-                            // what the packed FIR wants of a candidate row (orders <= 8): the taps as
+                            // what the packed FIR wants of a candidate row (orders <= 16): the taps as
                             // int16 pairs (lo: tap 2j+2, hi: tap 2j+1) and the sum of their magnitudes
                             const int32_t nb = __shfl_xor(cv, 1, WAVE);            // the pair's other tap
-                            if (tid < 8 && (tid & 1) == 0) l.misc[tid >> 1] = (nb & 0xFFFF) | (cv << 16);
+                            if (tid < 16 && (tid & 1) == 0) l.misc[tid >> 1] = (nb & 0xFFFF) | (cv << 16);
                             int32_t sa = cv < 0 ? -cv : cv;
                             sa += __shfl_xor(sa, 1, WAVE); sa += __shfl_xor(sa, 2, WAVE);
                             sa += __shfl_xor(sa, 4, WAVE); sa += __shfl_xor(sa, 8, WAVE);
                             sa += __shfl_xor(sa, 16, WAVE);
-                            if (tid == 0) l.misc[4] = sa;
+                            if (tid == 0) l.misc[8] = sa;
                         }
                     }
                     cshift = srow[cand];
@@ -1896,9 +1908,10 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                         fir_lpc_dot8<C, T>(e, r, ord, cshift, fin_all + (size_t)s * FIN_STRIDE + FIN_PAIRS);
                         done = true;
                     }
-                    if (!pre_row && ord <= 8 && magbits_n >= 0 &&
-                        ((unsigned long long)(uint32_t)l.misc[4] << magbits_n) < (1ull << 31)) {
-                        fir_lpc_dot8<C, T>(e, r, ord, cshift, l.misc);
+                    if (!pre_row && ord <= 16 && magbits_n >= 0 &&
+                        ((unsigned long long)(uint32_t)l.misc[8] << magbits_n) < (1ull << 31)) {
+                        if (ord <= 8) fir_lpc_dotn<C, T, 4>(e, r, ord, cshift, l.misc);
+                        else fir_lpc_dotn<C, T, 8>(e, r, ord, cshift, l.misc);
                         done = true;
                     }
                 }

@@ -1663,7 +1663,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
 
     // MAX / EST: the one row the reference quantises is known before the
     // search starts and comes compact from K2
-    constexpr bool MULTI = MODE != 0;
+    constexpr bool MULTI = MODE != 0 && MODE != 3;      // MODE 3: MODE 0 with the packed FIR for orders 9..16
     constexpr bool HAS_LPC = MODE != 1;
     constexpr bool pre_row = !MULTI;     // launcher: prediction_type == 2, n > max order, order method <= 1
 
@@ -1754,6 +1754,12 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     if (pre_row && tid < FHIP_MAX_ORDER) {
         l.coef[tid] = fcoef_n;
         l.coefd[tid] = (double)fcoef_n;
+    }
+    if constexpr (MODE == 3 && C % 8 == 0) {
+        // orders 9..16 on 16-bit rows: the taps as eight int16 pairs for the packed FIR (K2's
+        // compact row carries the first four; l.trial is idle in this instance)
+        const int32_t other = __shfl_xor(fcoef_n, 1, WAVE);
+        if (tid < 16 && (tid & 1) == 0) l.trial[tid >> 1] = (uint32_t)((other & 0xFFFF) | (fcoef_n << 16));
     }
     // one barrier (the library's __syncthreads_or is three): per-wave flags, then everyone ORs them
     const int wave_differs = (__ballot(differs) != 0ull) ? 1 : 0;       // all lanes vote
@@ -1907,6 +1913,13 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                         ((unsigned long long)(uint32_t)fcabs_n << magbits_n) < (1ull << 31)) {
                         fir_lpc_dot8<C, T>(e, r, ord, cshift, fin_all + (size_t)s * FIN_STRIDE + FIN_PAIRS);
                         done = true;
+                    }
+                    if constexpr (MODE == 3) {
+                        if (!done && ord <= 16 && magbits_n >= 0 &&
+                            ((unsigned long long)(uint32_t)fcabs_n << magbits_n) < (1ull << 31)) {
+                            fir_lpc_dotn<C, T, 8>(e, r, ord, cshift, reinterpret_cast<const int32_t *>(l.trial));
+                            done = true;
+                        }
                     }
                     if (!pre_row && ord <= 16 && magbits_n >= 0 &&
                         ((unsigned long long)(uint32_t)l.misc[8] << magbits_n) < (1ull << 31)) {
@@ -2268,9 +2281,13 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
         // one quantised row known up front (MAX / EST): the lean instance
         const bool single_row = (p.prediction_type == 2) && (n > p.max_prediction_order) && (p.order_method <= 1);
         const bool fixed_only = (p.prediction_type == 1) && n >= 5;
+        // orders 9..16 on 16-bit rows: their own instance, so that the lean one (orders <= 8,
+        // the default presets) does not carry the second packed FIR (it cost it 3 %)
+        const bool wide_rows = narrow_ok && p.max_prediction_order > 8 && (fc % 8) == 0;
 #define LAUNCH_FAST(CC, TT)                                                                  \
     do {                                                                                     \
-        if (single_row) LAUNCH_FAST2(CC, TT, 0);                                             \
+        if (single_row && wide_rows) LAUNCH_FAST2(CC, TT, 3);                                \
+        else if (single_row) LAUNCH_FAST2(CC, TT, 0);                                        \
         else if (fixed_only) LAUNCH_FAST2(CC, TT, 1);                                        \
         else LAUNCH_FAST2(CC, TT, 2);                                                        \
     } while (0)

@@ -480,3 +480,20 @@ def test_long_blocks(oracle, n):
     p = flake_amd.level_params(5, channels=1, bits_per_sample=24, block_size=n,
                                order_method=flake_amd.OM_4LEVEL, max_partition_order=8)
     check(oracle, p, mono, n, f"long mono24 n{n}")
+
+
+@pytest.mark.parametrize("n", [512, 2048, 4096, 8192])
+@pytest.mark.parametrize("order", [9, 12, 16])
+def test_orders_9_to_16_on_16bit_rows(oracle, n, order):
+    """MAX / EST with a maximum order of 9..16 on 16-bit stereo: K3's instance with the
+    eight-pair packed FIR (and its fall-back to the fp64 FIR when sum|coef| * 2^magbits
+    could leave int32: the full-scale square wave below)."""
+    r = np.random.RandomState(n + order)
+    t = np.arange(n)
+    loud = np.stack([30000 * np.sign(np.sin(t * 0.3)), 28000 * np.sign(np.sin(t * 0.31))], 1)
+    pcm = np.concatenate([flake_amd.synth_pcm(5, n, 2, 16, first_frame=order),
+                          loud[None].astype(np.int32),
+                          r.randint(-2000, 2000, (1, n, 2)).astype(np.int32)])
+    for om in (flake_amd.OM_MAX, flake_amd.OM_EST):
+        p = flake_amd.level_params(5, block_size=n, max_prediction_order=order, order_method=om)
+        check(oracle, p, pcm, n, f"order{order} n{n} om{om}")

@@ -1932,8 +1932,8 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                 } else if (pre_row && ord <= 8)
                     fir_lpc_o8<C, T>(e, r, ord, cshift,
                                      reinterpret_cast<const double *>(fin_all + (size_t)s * FIN_STRIDE + FIN_DBL));
-                else
-                    fir_lpc<C, T>(e, r, ord, cshift);
+                else if constexpr (MODE != 0)
+                    fir_lpc<C, T>(e, r, ord, cshift);     // (MODE 0 is launched for maximum orders <= 8 only)
                 STAMP(3);
                 b = rice_search_fast<C, T>(e, r, u, ord, true, &porder, &method, &umax_run);
                 STAMP(8);
@@ -2283,7 +2283,7 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
         const bool fixed_only = (p.prediction_type == 1) && n >= 5;
         // orders 9..16 on 16-bit rows: their own instance, so that the lean one (orders <= 8,
         // the default presets) does not carry the second packed FIR (it cost it 3 %)
-        const bool wide_rows = narrow_ok && p.max_prediction_order > 8 && (fc % 8) == 0;
+        const bool wide_rows = p.max_prediction_order > 8;
 #define LAUNCH_FAST(CC, TT)                                                                  \
     do {                                                                                     \
         if (single_row && wide_rows) LAUNCH_FAST2(CC, TT, 3);                                \

@@ -2101,6 +2101,12 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                         w += full ? 1 : 0;
                         nacc = t & 31;
                     };
+                    // a section longer than the window (dense or long blocks, wide samples) takes
+                    // several passes: a thread only walks its codewords in the passes its bits
+                    // fall into, not in every one
+                    const bool touches = (nwords <= wwords) ||
+                                         (rel + (long long)(nwarm * k1) + (long long)mine > 0 && rel < (long long)nw * 32);
+                    if (touches) {
                     if (part_head) field(pbits, (uint32_t)k);
                     const uint32_t kmask = (1u << k) - 1u, kbit = 1u << k;
                     bool packed = false;
@@ -2141,6 +2147,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                         }
                     }
                     if (nacc > 0 && hi && (unsigned)w < (unsigned)nw) atomicOr(&l.bits[w], hi);
+                    }
                     __syncthreads();
                     if (tid == 0 && wlo == 0) {
                         // section header (encode.c:771-776): method, partition order,

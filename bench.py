@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of the FLAC prediction/entropy hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 400 --warmup 150
+    python bench.py --gpus N --steps 400 --warmup 150          # any N: for N > 1 the
+        # parent (which never touches the GPU) starts N child ranks and relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -49,6 +50,10 @@ def parse_args():
                     help="rough budget of CPU work for the cpu_baseline leg")
     ap.add_argument("--profile-steps", type=int, default=200,
                     help="extra steps with per-kernel hipEvent timing for the roofline object")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short per-kernel timings of BASELINE configs[2], configs[3], "
+                         "level 8 and level 2 that rank 0 adds as \"other_configs\" at N = 1")
+    ap.add_argument("--other-steps", type=int, default=20)
     ap.add_argument("--with-residual", action="store_true",
                     help="also write the int32 residual (stage A of SURVEY 8d)")
     return ap.parse_args()
@@ -85,8 +90,102 @@ def cpu_baseline(params, n, budget_s):
     }
 
 
+def other_configs(dev_index, steps):
+    """Per-kernel timings (hipEvents on the launch stream) of the BASELINE configs the
+    headline is NOT quoted on, at their full sizes, plus two presets with an order
+    search: reported next to the headline, never as `value`."""
+    import torch
+    import flake_amd
+
+    P = flake_amd.level_params
+    cases = [
+        ("configs[2]: stereo 24-bit 96 kHz, n 4096, LPC order SEARCH 1-32, partition orders 0-8",
+         P(5, bits_per_sample=24, sample_rate=96000, order_method=flake_amd.OM_SEARCH,
+           max_prediction_order=32, max_partition_order=8), 4096),
+        ("configs[3]: 8-channel 24-bit 192 kHz, n 4096, LPC-12 (MAX), 32768 subframes",
+         P(5, channels=8, bits_per_sample=24, sample_rate=192000, order_method=flake_amd.OM_MAX,
+           max_prediction_order=12), 4096),
+        ("level 8: stereo 16-bit, n 4096, LPC <= 12 LOG search, partition orders 0-6", P(8), 4096),
+        ("level 2: stereo 16-bit, n 1152, fixed orders 0-4, partition orders 0-3", P(2),
+         4096 * 4096 // 1152),
+    ]
+    dev = torch.device("cuda", dev_index)
+    out = []
+    for tag, p, nframes in cases:
+        n = p.block_size
+        nsub = nframes * p.channels
+        slot = flake_amd.rice_slot_bytes(p, n)
+        pcm = torch.from_numpy(flake_amd.synth_pcm(nframes, n, p.channels, p.bits_per_sample)).to(dev)
+        info = torch.zeros(nsub * flake_amd.INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        bits = torch.zeros(nsub * slot, dtype=torch.uint8, device=dev)
+        enc = flake_amd.Encoder(p, max_frames=nframes, device=dev_index)
+        enc.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
+        def step():
+            enc.encode_subframes_dev(pcm, nframes, n, info, rice_bits=bits, slot_bytes=slot)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        enc.set_profiling(True)
+        enc.kernel_times(reset=True)
+        for _ in range(max(3, steps // 2)):
+            step()
+        enc.sync()
+        per = {k: tms / c for k, (tms, c) in enc.kernel_times(reset=True).items() if c}
+        enc.set_profiling(False)
+        info_np = np.frombuffer(info.cpu().numpy().tobytes(), dtype=flake_amd.INFO_DTYPE)
+        samples = nframes * n * p.channels
+        alg = samples * 4 + int(((info_np["rice_nbits"].clip(min=0) + 31) // 32 * 4).sum()) \
+            + nsub * flake_amd.INFO_DTYPE.itemsize
+        dom = max(per, key=per.get)
+        out.append({
+            "workload": tag, "frames": nframes, "samples_per_step": samples,
+            "ms_per_step": round(ms, 4), "Msamples_per_s": round(samples / ms / 1e3, 1),
+            "kernel_ms": {k: round(v, 4) for k, v in per.items()},
+            "dominant_kernel": dom,
+            "algorithmic_bytes": alg,
+            "hbm_frac_dominant": round(alg / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "hbm_frac_step": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "bits_per_sample_out": round(float(info_np["rice_nbits"].clip(min=0).sum()) / samples, 3),
+        })
+        enc.close()
+        del pcm, info, bits
+        torch.cuda.empty_cache()
+    return out
+
+
+def launch_ranks(ngpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD
+    processes (torch.distributed.run, one per GPU) and pass their output through;
+    rank 0 prints the JSON line.  This parent has only parsed arguments -- it has
+    not initialised the GPU and it never exec()s."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     import torch
     import flake_amd
 
@@ -94,8 +193,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     ndev = torch.cuda.device_count()
@@ -106,8 +204,9 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        # "nccl" is RCCL on ROCm; BENCH_DIST_BACKEND=gloo rehearses the N>1 path on one GPU
-        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        # "nccl" is RCCL on ROCm.  With fewer GPUs than ranks (a rehearsal of the N > 1
+        # path on a one-GPU box) ranks share a card, which RCCL refuses: gloo then.
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl" if ndev >= world else "gloo")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -133,7 +232,9 @@ def main():
     enc = flake_amd.Encoder(p, max_frames=nframes, device=dev_index)
     stream = torch.cuda.current_stream(dev)
     enc.set_stream(stream.cuda_stream)
-    stats = torch.zeros(2, dtype=torch.int64, device=dev)
+    # gloo reduces host tensors; RCCL device tensors
+    cdev = dev if (world == 1 or backend == "nccl") else torch.device("cpu")
+    stats = torch.zeros(3, dtype=torch.int64, device=cdev)
 
     def step():
         enc.encode_subframes_dev(pcm, nframes, n, info, residual=resid, rice_bits=bits,
@@ -143,7 +244,8 @@ def main():
         """The job's only exchange: {frames, residual bits} summed over ranks."""
         nb = info.view(torch.int32).view(nsub, info_bytes // 4)[:, 10]
         stats[0] = nframes * steps
-        stats[1] = nb.clamp(min=0).sum() * steps
+        stats[1] = int(nb.clamp(min=0).sum().item()) * steps
+        stats[2] = 1                                   # ranks_seen
         if world > 1:
             dist.all_reduce(stats)
 
@@ -170,9 +272,15 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        per_rank = [torch.zeros(2, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([rank, nframes * args.steps], dtype=torch.int64,
+                                               device=cdev))
+        rank_frames = {int(r[0]): int(r[1]) for r in per_rank}
+    else:
+        rank_frames = {0: nframes * args.steps}
 
     samples_per_step = nframes * n * p.channels * world
     value = samples_per_step * args.steps / dt / 1e6
@@ -180,6 +288,7 @@ def main():
     # ---- roofline of the dominant kernel (rank 0, hipEvents on the launch stream)
     roofline = None
     cpu = None
+    others = None
     if rank == 0:
         info_np = np.frombuffer(info.cpu().numpy().tobytes(), dtype=flake_amd.INFO_DTYPE)
         rice_bytes = int(((info_np["rice_nbits"].clip(min=0) + 31) // 32 * 4).sum())
@@ -220,6 +329,8 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(p, n, args.cpu_seconds)
+        if world == 1 and not args.no_other_configs:
+            others = other_configs(dev_index, args.other_steps)
 
     if world > 1:
         torch.cuda.synchronize(dev)
@@ -251,9 +362,13 @@ def main():
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "other_configs": others,
         }
         out["job_frames"] = int(stats[0].item())
         out["job_residual_bits"] = int(stats[1].item())
+        out["ranks_seen"] = int(stats[2].item())
+        out["rank_frames"] = [rank_frames.get(r, 0) for r in range(world)]
+        out["dist_backend"] = backend if world > 1 else None
         print(json.dumps(out), flush=True)
 
     enc.close()

@@ -1,0 +1,462 @@
+"""Replay of libflake's encode_residual() / feeders / frame emit in which every
+arithmetic step is COMPILED REFERENCE CODE or plain numpy integer arithmetic.
+
+TEST INFRASTRUCTURE ONLY (same standing as oracle/): imported by tests/ and by
+tests/golden/make_golden.py, never by flake_amd/.
+
+optimize.c, encode.c and vbs.c cannot be compiled here (encode.h:23 includes the
+CMake-generated config.h, and the rules forbid a stand-in), so the oracle's
+restatement of them (oracle/flake_oracle.c) is pinned from a second, independent
+side instead: this module re-states only their CONTROL FLOW, in Python, and takes
+
+* window / autocorrelation / Levinson / Schur / quantiser from the reference's
+  own lpc.c           (ref.lpc_calc_coefs            -> lpc.c:224-257)
+* zig-zag, partition sums, Rice parameter and partition-order search, the
+  subframe bit estimate from the reference's own rice.c
+                       (ref.calc_rice_params          -> rice.c:105-187)
+* the Rice estimator of the stereo decision from rice.c / rice.h
+                       (ref.find_optimal_rice_param, ref.rice_encode_count)
+* every emitted bit from the reference's own BitWriter (bitio.h) and the CRCs
+  from its crc.c       (ref.bitwriter_run, ref.emit_residual, ref.crc8/16)
+
+What remains restated here is integer arithmetic a line long (the FIR of
+optimize.c:70-122 as an int64 numpy convolution, fixed differences :34-68,
+mid/side, the wasted-bits shift, the 2nd-order score sums) and the selection
+rules (optimize.c:143-275, encode.c:630-635, vbs.c:66-82).  A disagreement between
+this replay and oracle/flake_oracle.c is a bug in one of two independent
+readings of ~40 lines of control flow.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+import flake_amd
+
+U32_MAX = 0xFFFFFFFF
+SUB_CONSTANT, SUB_VERBATIM, SUB_FIXED, SUB_LPC = 0, 1, 8, 32
+CH_NOT_STEREO, CH_LR, CH_LS, CH_RS, CH_MS = 0, 1, 8, 9, 10
+
+
+# ---------------------------------------------------------------------------
+# integer one-liners (numpy int64, wrapped to int32 exactly where C does)
+# ---------------------------------------------------------------------------
+def _i32(a):
+    """C's (int32_t) of a 64-bit integer: low 32 bits, two's complement."""
+    return np.asarray(a, np.int64).astype(np.uint64).astype(np.uint32).view(np.int32) \
+        if np.ndim(a) else np.int32(np.uint32(np.uint64(np.int64(a)) & np.uint64(U32_MAX)))
+
+
+def residual_lpc(smp, order, coefs, shift):
+    """optimize.c:70-122: pred = sum coefs[j-1]*smp[i-j] in int64, res = (int32)(smp - (pred >> shift))."""
+    smp = np.asarray(smp, np.int32)
+    n = smp.size
+    s = smp.astype(np.int64)
+    res = smp.copy()
+    if n > order:
+        pred = np.zeros(n - order, np.int64)
+        for j in range(1, order + 1):
+            pred += np.int64(coefs[j - 1]) * s[order - j:n - j]
+        res[order:] = _i32(s[order:] - (pred >> np.int64(shift)))
+    return res
+
+
+def residual_fixed(smp, order):
+    """optimize.c:34-68: finite differences with long long intermediates, stored to int32."""
+    smp = np.asarray(smp, np.int32)
+    s = smp.astype(np.int64)
+    res = smp.copy()
+    n = smp.size
+    if order == 0 or n <= order:
+        return res
+    binom = {1: (1, -1), 2: (1, -2, 1), 3: (1, -3, 3, -1), 4: (1, -4, 6, -4, 1)}[order]
+    acc = np.zeros(n - order, np.int64)
+    for j, c in enumerate(binom):
+        acc += np.int64(c) * s[order - j:n - j]
+    res[order:] = _i32(acc)
+    return res
+
+
+# ---------------------------------------------------------------------------
+# encode_residual()  optimize.c:124-276
+# ---------------------------------------------------------------------------
+def encode_residual(ref, p, smp, obits):
+    """Returns dict(type, type_code, order, shift, coefs[32], residual[n], method, porder,
+    rparams[256], est_bits) -- the fields of FlacSubframe the function writes, and its
+    return value."""
+    smp = np.ascontiguousarray(smp, np.int32)
+    n = smp.size
+    prec = p.lpc_precision
+    out = dict(type=0, type_code=0, order=0, shift=0, coefs=np.zeros(32, np.int32),
+               residual=smp.copy(), method=0, porder=0, rparams=np.zeros(256, np.int32), est_bits=0)
+
+    def rice(res, order, lpc):
+        bits, method, porder, params = ref.calc_rice_params(
+            lpc, p.min_partition_order, p.max_partition_order, res, order, obits, prec)
+        return bits, (method, porder, params)
+
+    def keep(rc):
+        out["method"], out["porder"] = rc[0], rc[1]
+        out["rparams"][:] = 0
+        out["rparams"][:1 << rc[1]] = rc[2][:1 << rc[1]]
+
+    # CONSTANT :143-151
+    if (smp == smp[0]).all():
+        out.update(type=SUB_CONSTANT, type_code=SUB_CONSTANT, est_bits=obits)
+        return out
+    # VERBATIM :153-158
+    if n < 5 or p.prediction_type == flake_amd.PRED_NONE:
+        out.update(type=SUB_VERBATIM, type_code=SUB_VERBATIM, est_bits=(obits * n) & U32_MAX)
+        return out
+
+    omethod = p.order_method
+    min_order, max_order = p.min_prediction_order, p.max_prediction_order
+
+    # FIXED :167-190
+    if p.prediction_type == flake_amd.PRED_FIXED or n <= max_order:
+        max_order = min(max_order, 4)
+        opt = min_order
+        bits = {opt: U32_MAX}
+        last_rc = None
+        res = smp.copy()
+        for i in range(min_order, max_order + 1):
+            res = residual_fixed(smp, i)
+            bits[i], last_rc = rice(res, i, False)
+            if bits[i] < bits[opt]:
+                opt = i
+        if opt != max_order:
+            res = residual_fixed(smp, opt)
+            est, last_rc = rice(res, opt, False)
+        else:
+            est = bits[opt]
+        out.update(type=SUB_FIXED, type_code=SUB_FIXED | opt, order=opt, residual=res, est_bits=est)
+        keep(last_rc)
+        return out
+
+    # LPC :192-275
+    coefs, shift, est_order = ref.lpc_calc_coefs(smp, max_order, prec, omethod)
+
+    def try_order(i):          # index i = order - 1
+        r = residual_lpc(smp, i + 1, coefs[i], int(shift[i]))
+        return rice(r, i + 1, True)[0]
+
+    if omethod == flake_amd.OM_MAX:
+        opt_order = max_order
+    elif omethod == flake_amd.OM_EST:
+        opt_order = est_order
+    elif omethod in (flake_amd.OM_2LEVEL, flake_amd.OM_4LEVEL, flake_amd.OM_8LEVEL):
+        levels = 1 << (omethod - 1)
+        opt_index = levels - 1
+        opt_order = max_order - 1
+        bits = {opt_index: U32_MAX}
+        for i in range(levels - 1, -1, -1):
+            order = min_order + (((max_order - min_order + 1) * (i + 1)) // levels) - 2
+            if order < 0:
+                order = 0
+            bits[i] = try_order(order)
+            if bits[i] < bits[opt_index]:
+                opt_index, opt_order = i, order
+        opt_order += 1
+    elif omethod == flake_amd.OM_SEARCH:
+        opt = 0
+        bits = {0: U32_MAX}
+        for i in range(max_order):
+            bits[i] = try_order(i)
+            if bits[i] < bits[opt]:
+                opt = i
+        opt_order = opt + 1
+    elif omethod == flake_amd.OM_LOG:
+        opt = min_order - 1 + (max_order - min_order) // 3
+        bits = [U32_MAX] * 32
+        step = 16
+        while step > 0:
+            last = opt
+            for i in range(last - step, last + step + 1, step):
+                if i < min_order - 1 or i >= max_order or bits[i] < U32_MAX:
+                    continue
+                bits[i] = try_order(i)
+                if bits[i] < bits[opt]:
+                    opt = i
+            step >>= 1
+        opt_order = opt + 1
+    else:
+        raise ValueError("order method")
+
+    sh = int(shift[opt_order - 1])
+    out["coefs"][:opt_order] = coefs[opt_order - 1][:opt_order]
+    res = residual_lpc(smp, opt_order, out["coefs"], sh)
+    est, rc = rice(res, opt_order, True)
+    out.update(type=SUB_LPC, type_code=SUB_LPC | (opt_order - 1), order=opt_order, shift=sh,
+               residual=res, est_bits=est)
+    keep(rc)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# feeders  encode.c:541-694
+# ---------------------------------------------------------------------------
+def calc_decorr_scores(ref, left, right):
+    """encode.c:598-643 with the estimator calls going to the compiled rice.c."""
+    l = np.asarray(left, np.int32).astype(np.int64)
+    r = np.asarray(right, np.int32).astype(np.int64)
+    n = l.size
+    lt = _i32(l[2:] - 2 * l[1:-1] + l[:-2]).astype(np.int64)     # int32 expressions in C
+    rt = _i32(r[2:] - 2 * r[1:-1] + r[:-2]).astype(np.int64)
+
+    def iabs(x):                                                 # abs(int): INT_MIN stays INT_MIN
+        return _i32(np.abs(_i32(x).astype(np.int64))).astype(np.int64)
+
+    sums = [iabs(lt), iabs(rt), iabs(_i32(lt + rt).astype(np.int64) >> 1), iabs(lt - rt)]
+    est = []
+    for s in sums:
+        # sum[] is uint64 and receives sign-extended ints
+        tot = int(s.astype(np.uint64).sum(dtype=np.uint64))
+        two = (2 * tot) & 0xFFFFFFFFFFFFFFFF
+        k = ref.find_optimal_rice_param(two, n)
+        est.append(ref.rice_encode_count(two, n, k))             # stored to uint64: no truncation
+    m = 0xFFFFFFFFFFFFFFFF
+    score = [(est[0] + est[1]) & m, (est[0] + est[3]) & m, (est[1] + est[3]) & m, (est[2] + est[3]) & m]
+    best = 0
+    for i in range(1, 4):
+        if score[i] < score[best]:
+            best = i
+    return (CH_LR, CH_LS, CH_RS, CH_MS)[best]
+
+
+def prepare_frame(ref, p, pcm, n):
+    """copy_samples + channel_decorrelation + remove_wasted_bits (encode.c:541-694, order of
+    :932-936).  Returns samples[ch][n], obits[ch], wasted[ch], ch_mode."""
+    ch = p.channels
+    bps = p.bits_per_sample
+    smp = np.ascontiguousarray(np.asarray(pcm, np.int32).reshape(n, ch).T).copy()
+    obits = [bps] * ch
+    if ch != 2:
+        mode = CH_NOT_STEREO
+    elif n <= 32 or p.stereo_method == flake_amd.STEREO_INDEPENDENT:
+        mode = CH_LR
+    else:
+        mode = calc_decorr_scores(ref, smp[0], smp[1])
+        l, r = smp[0].astype(np.int64), smp[1].astype(np.int64)
+        if mode == CH_MS:
+            smp[0] = _i32(_i32(l + r).astype(np.int64) >> 1)
+            smp[1] = _i32(l - r)
+            obits[1] += 1
+        elif mode == CH_LS:
+            smp[1] = _i32(l - r)
+            obits[1] += 1
+        elif mode == CH_RS:
+            smp[0] = _i32(l - r)
+            obits[0] += 1
+    wasted = [0] * ch
+    for c in range(ch):
+        w = bps - 1
+        nz = smp[c][smp[c] != 0].view(np.uint32)
+        if nz.size:
+            orall = int(np.bitwise_or.reduce(nz))
+            tz = (orall & -orall).bit_length() - 1                # min over samples of ctz
+            w = min(w, tz)
+        if w == bps - 1:
+            w = 0
+        elif w:
+            smp[c] = smp[c] >> w
+            obits[c] -= w
+        wasted[c] = w
+    return smp, obits, wasted, mode
+
+
+# ---------------------------------------------------------------------------
+# frame emit  encode.c:700-917 through the reference BitWriter + CRC tables
+# ---------------------------------------------------------------------------
+_SAMPLERATES = [0, 0, 0, 0, 8000, 16000, 22050, 24000, 32000, 44100, 48000, 96000, 0, 0, 0, 0]
+_BITDEPTHS = [0, 8, 12, 0, 16, 20, 24, 0]
+_BLOCKSIZES = [0, 192, 576, 1152, 2304, 4608, 0, 0, 256, 512, 1024, 2048, 4096, 8192, 16384]
+
+
+class _Ops:
+    """A list of bitwriter_writebits / _signed calls, replayed through bitio.h."""
+
+    def __init__(self):
+        self.nbits, self.vals, self.signed = [], [], []
+
+    def u(self, nbits, val):
+        self.nbits.append(nbits), self.vals.append(int(val) & U32_MAX), self.signed.append(0)
+
+    def s(self, nbits, val):
+        self.nbits.append(nbits), self.vals.append(int(val)), self.signed.append(1)
+
+    def run(self, ref, cap):
+        v = np.array(self.vals, np.int64).astype(np.uint64).astype(np.uint32).view(np.int32)
+        return ref.bitwriter_run(np.array(self.nbits, np.int32), v, np.array(self.signed, np.uint8), cap)
+
+
+def stream_codes(p):
+    """flake_encode_init's header codes (encode.c:395-440)."""
+    sr = p.sample_rate
+    sr_code = [0, 0]
+    for i in range(4, 12):
+        if sr == _SAMPLERATES[i]:
+            sr_code[0] = i
+            break
+    else:
+        if sr % 1000 == 0 and sr < 255000:
+            sr_code = [12, sr // 1000]
+        elif sr % 10 == 0 and sr < 655350:
+            sr_code = [14, sr // 10]
+        elif sr < 65535:
+            sr_code = [13, sr]
+    bps_code = _BITDEPTHS.index(p.bits_per_sample) if p.bits_per_sample in _BITDEPTHS[1:] else 0
+    return sr_code, bps_code
+
+
+def _header_ops(p, n, ch_mode, frame_count):
+    ops = _Ops()
+    sr_code, bps_code = stream_codes(p)
+    if n in _BLOCKSIZES[1:]:
+        bs0, bs1 = _BLOCKSIZES.index(n), -1
+    else:
+        bs0, bs1 = (6 if n <= 256 else 7), n - 1
+    ops.u(15, 0x7FFC)
+    ops.u(1, p.allow_vbs)
+    ops.u(4, bs0)
+    ops.u(4, sr_code[0])
+    ops.u(4, p.channels - 1 if ch_mode == CH_NOT_STEREO else ch_mode)
+    ops.u(3, bps_code)
+    ops.u(1, 0)
+    val = frame_count
+    if val < 0x80:
+        ops.u(8, val)
+    else:
+        nbytes = ((val.bit_length() - 1) + 4) // 5
+        shift = (nbytes - 1) * 6
+        ops.u(8, (256 - (256 >> nbytes)) | (val >> shift))
+        while shift >= 6:
+            shift -= 6
+            ops.u(8, 0x80 | ((val >> shift) & 0x3F))
+    if bs1 >= 0:
+        ops.u(8 if bs1 < 256 else 16, bs1)
+    if sr_code[1] > 0:
+        ops.u(8 if sr_code[1] < 256 else 16, sr_code[1])
+    return ops
+
+
+def emit_frame(ref, p, n, ch_mode, frame_count, subs, obits, wasted, cap):
+    """output_frame_header + output_subframes + output_frame_footer.  Every bit is written by
+    the reference's BitWriter; CRC-8/16 by its crc.c.  Returns bytes, or None on writer eof."""
+    hdr = _header_ops(p, n, ch_mode, frame_count)
+    head = hdr.run(ref, 64)
+    ops = _Ops()
+    for b in head:
+        ops.u(8, b)
+    ops.u(8, ref.crc8(head))
+    # the residual sections are written by ref.emit_residual (its own BitWriter) and spliced
+    # bit-wise: collect (bytes, nbits) pieces
+    pieces = []
+
+    def flush_ops():
+        nonlocal ops
+        if ops.nbits:
+            total = sum(ops.nbits)
+            data = ops.run(ref, (total + 7) // 8 + 16)
+            if data is None:
+                raise RuntimeError("writer eof in a header piece")
+            pieces.append((data, total))
+            ops = _Ops()
+
+    for c in range(p.channels):
+        sf = subs[c]
+        ops.u(1, 0)
+        ops.u(6, sf["type_code"])
+        if wasted[c]:
+            ops.u(1, 1)
+            if wasted[c] - 1:
+                ops.u(wasted[c] - 1, 0)
+            ops.u(1, 1)
+        else:
+            ops.u(1, 0)
+        res = sf["residual"]
+        if sf["type"] == SUB_CONSTANT:
+            ops.s(obits[c], res[0])
+        elif sf["type"] == SUB_VERBATIM:
+            for v in res[:n]:
+                ops.s(obits[c], v)
+        else:
+            for v in res[:sf["order"]]:
+                ops.s(obits[c], v)
+            if sf["type"] == SUB_LPC:
+                ops.u(4, p.lpc_precision - 1)
+                ops.s(5, sf["shift"])
+                for v in sf["coefs"][:sf["order"]]:
+                    ops.s(p.lpc_precision, v)
+            flush_ops()
+            data, nbits = ref.emit_residual(sf["method"], sf["porder"], sf["rparams"], sf["order"],
+                                            res, cap)
+            if data is None:
+                return None
+            pieces.append((data, nbits))
+    flush_ops()
+    body = _splice(pieces)
+    if len(body) + 2 > cap - 3:                    # BitWriter refuses the last bytes (bitio.h:90-93)
+        return None
+    crc = ref.crc16(body)
+    return np.concatenate([body, np.array([crc >> 8, crc & 255], np.uint8)])
+
+
+def _splice(pieces):
+    """MSB-first concatenation of (bytes, nbits) runs, zero-padded to a byte."""
+    bits = [np.unpackbits(np.asarray(d, np.uint8))[:nb] for d, nb in pieces]
+    allbits = np.concatenate(bits) if bits else np.zeros(0, np.uint8)
+    pad = (-allbits.size) % 8
+    if pad:
+        allbits = np.concatenate([allbits, np.zeros(pad, np.uint8)])
+    return np.packbits(allbits)
+
+
+def verbatim_size(p, n):
+    if p.channels == 2:
+        return 16 + ((n * (2 * p.bits_per_sample + 1) + 7) >> 3)
+    return 16 + ((n * p.channels * p.bits_per_sample + 7) >> 3)
+
+
+def encode_frame(ref, p, frame_count, pcm, n, buf_size=None):
+    """encode_frame() encode.c:919-977 (without the cross-frame counters)."""
+    smp, obits, wasted, mode = prepare_frame(ref, p, pcm, n)
+    subs = [encode_residual(ref, p, smp[c], obits[c]) for c in range(p.channels)]
+    vsize = verbatim_size(p, n)
+    cap = buf_size if buf_size is not None else vsize * 3 // 2 + 64
+    frame = emit_frame(ref, p, n, mode, frame_count, subs, obits, wasted, cap)
+    if frame is None or len(frame) > vsize:
+        for c in range(p.channels):                 # reencode_residual_verbatim optimize.c:278-289
+            subs[c] = dict(subs[c], type=SUB_VERBATIM, type_code=SUB_VERBATIM, residual=smp[c].copy())
+        frame = emit_frame(ref, p, n, mode, frame_count, subs, obits, wasted, cap)
+    return frame, subs, dict(samples=smp, obits=obits, wasted=wasted, ch_mode=mode)
+
+
+# ---------------------------------------------------------------------------
+# split_frame_v1  vbs.c:36-83
+# ---------------------------------------------------------------------------
+def vbs_split(pcm, channels, block_size):
+    """Pure integer arithmetic; the int abs()/imul wrap of vbs.c:69 spelled out."""
+    n = block_size // 8
+    x = np.asarray(pcm, np.int32).reshape(block_size, channels).astype(np.int64)
+    res = []
+    for i in range(8):
+        sec = x[i * n:(i + 1) * n]
+        d = _i32(sec[2:] - 2 * sec[1:-1] + sec[:-2]).astype(np.int64)    # int expression
+        a = _i32(np.abs(d)).astype(np.int64)                              # abs(int)
+        tot = int(a.sum())
+        q = abs(tot) // channels * (1 if tot >= 0 else -1)                # C division truncates
+        res.append(q + 1)
+    layout = [1] + [0] * 7
+    for i in range(1, 8):
+        diff = int(_i32(res[i - 1] - res[i]))                             # (int) truncation
+        a = int(_i32(abs(diff)))                                          # abs(int)
+        prod = int(_i32(a * 200))                                         # 32-bit imul
+        den = res[i - 1]
+        quo = abs(prod) // abs(den) * (1 if (prod >= 0) == (den >= 0) else -1) if den else 0
+        if quo > 50:
+            layout[i] = 1
+    sizes = []
+    for i in range(8):
+        if layout[i]:
+            sizes.append(0)
+        sizes[-1] += n
+    return sizes

@@ -59,9 +59,53 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(params, n, budget_s):
-    """The CPU restatement (oracle) on a bounded sample of the same workload,
-    one thread, timed on this box's host cores.  Reported, not the target."""
+def _cpu_worker(job):
+    """One host process of the all-cores leg: the oracle on its own copy of the sample."""
+    frames, n, reps, pvals = job
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib
+    import flake_amd
+    p = flake_amd.Params()
+    for (k, _), v in zip(p._fields_, pvals):
+        setattr(p, k, int(v))
+    orc = oraclelib.Oracle()
+    pcm = flake_amd.synth_pcm(frames, n, p.channels, p.bits_per_sample)
+    slot = flake_amd.rice_slot_bytes(p, n)
+    orc.encode_subframes_batch(p, pcm, n, want_residual=False, slot_bytes=slot)     # page in
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.encode_subframes_batch(p, pcm, n, want_residual=False, slot_bytes=slot)
+    return time.perf_counter() - t0
+
+
+def host_cores():
+    """Host cores this job may really use: the scheduler affinity, cut to the cgroup's CPU
+    quota where one is set (a GPU box hands each GPU a share of the host: 16 cores for one
+    GPU of this pool), and to BENCH_CPU_CORES if given."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    cap = int(os.environ.get("BENCH_CPU_CORES", "16"))
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(params, n, budget_s, gpu_bits_per_frame=None):
+    """CPU legs, timed on this box's host cores.  Reported, not the target.
+
+    value            the CPU restatement (oracle/flake_oracle.c, kind "port"), one thread, on a
+                     bounded sample of the same workload: prepare + encode_residual + Rice emit.
+    all_cores        the same on every host core this process may use, one process per core,
+                     each on its own frames (frames are independent: the frame-parallel bound).
+    reference_stages the stages of the path that compile from the reference's own sources
+                     (oracle/_ref: lpc.c, rice.c, bitio.h, crc.c) timed as the reference's code,
+                     one thread, on prepared subframes of the same sample; the integer FIR
+                     (optimize.c, not buildable here -- DESIGN.md 4) is a plain C loop beside them.
+    The reference binary itself (flake CLI / libflake) cannot be built under the rules of this
+    build (encode.h includes a CMake-generated config.h), so no leg is kind "reference"."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib
     import flake_amd
@@ -79,7 +123,7 @@ def cpu_baseline(params, n, budget_s):
         orc.encode_subframes_batch(params, pcm, n, want_residual=False, slot_bytes=slot)
     dt = time.perf_counter() - t0
     samples = reps * frames * n * params.channels
-    return {
+    out = {
         "value": round(samples / dt / 1e6, 3),
         "unit": "Msamples/s",
         "cores": 1,
@@ -88,6 +132,61 @@ def cpu_baseline(params, n, budget_s):
                   f"({samples / 1e6:.1f} Msamples, {dt:.1f} s), oracle/flake_oracle.c, "
                   "prepare + encode_residual + Rice emit",
     }
+
+    # ---- every host core, one process each (spawned: this process holds the GPU)
+    try:
+        import multiprocessing as mp
+        ncores = host_cores()
+        wf = 256
+        wreps = max(1, int(reps * frames / wf * 0.5))            # ~ half the one-thread budget each
+        pvals = [getattr(params, k) for k, _ in params._fields_]
+        with mp.get_context("spawn").Pool(ncores) as pool:
+            t0 = time.perf_counter()
+            times = pool.map(_cpu_worker, [(wf, n, wreps, pvals)] * ncores)
+            wall = time.perf_counter() - t0
+        tot = ncores * wreps * wf * n * params.channels
+        out["all_cores"] = {"value": round(tot / max(times) / 1e6, 1), "unit": "Msamples/s",
+                            "cores": ncores, "kind": "port",
+                            "sample": f"{ncores} processes x {wreps} x {wf} frames, slowest worker "
+                                      f"{max(times):.1f} s (pool wall {wall:.1f} s incl. start-up)"}
+    except Exception as e:                                        # a reported extra, never fatal
+        out["all_cores"] = {"error": repr(e)}
+
+    # ---- the compiled reference stages on prepared subframes
+    if oraclelib.Ref.available() and hasattr(oraclelib.Ref().L, "ref_time_hotpath") \
+            and params.order_method == flake_amd.OM_MAX:
+        ref = oraclelib.Ref()
+        rf = 256
+        smp = np.zeros((rf * params.channels, n), np.int32)
+        obits = np.zeros(rf * params.channels, np.int32)
+        t0 = time.perf_counter()
+        for f in range(rf):
+            _, s, sf = orc.prepare_frame(params, pcm[f], n)
+            smp[f * params.channels:(f + 1) * params.channels] = s
+            obits[f * params.channels:(f + 1) * params.channels] = sf["obits"]
+        t_prep = time.perf_counter() - t0
+        rreps = max(1, int(budget_s * 0.4 / max(dt1 * rf / frames, 1e-3)))
+        tt = np.zeros(5)
+        bits = 0
+        for _ in range(rreps):
+            bits, t = ref.time_hotpath(smp, obits, params.max_prediction_order, params.lpc_precision,
+                                       params.min_partition_order, params.max_partition_order)
+            tt += t
+        rs = rreps * rf * n * params.channels
+        names = ("lpc_calc_coefs [lpc.c]", "integer FIR [harness loop]",
+                 "calc_rice_params_lpc [rice.c]", "output_residual via BitWriter [bitio.h]",
+                 "calc_crc16 [crc.c]")
+        out["reference_stages"] = {
+            "value": round(rs / tt.sum() / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+            "kind": "reference functions compiled from /root/reference (oracle/_ref) + a C loop "
+                    "for the FIR; feeders (prepare) excluded",
+            "ns_per_sample": {k: round(float(v) / rs * 1e9, 3) for k, v in zip(names, tt)},
+            "prepare_ns_per_sample_port": round(t_prep / (rf * n * params.channels) * 1e9, 3),
+            "sample": f"{rreps} x {rf} frames ({rs / 1e6:.1f} Msamples, {tt.sum():.1f} s)",
+            "residual_bits_match_hip": (None if gpu_bits_per_frame is None
+                                        else bool(bits == int(gpu_bits_per_frame[:rf].sum()))),
+        }
+    return out
 
 
 def other_configs(dev_index, steps):
@@ -328,7 +427,9 @@ def main():
                 "pipeline_achieved": round(alg_bytes / (sum(per.values()) * 1e-3) / 1e9, 1),
             }
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(p, n, args.cpu_seconds)
+            per_frame_bits = info_np["rice_nbits"].clip(min=0).astype(np.int64) \
+                .reshape(nframes, p.channels).sum(axis=1)
+            cpu = cpu_baseline(p, n, args.cpu_seconds, per_frame_bits)
         if world == 1 and not args.no_other_configs:
             others = other_configs(dev_index, args.other_steps)
 

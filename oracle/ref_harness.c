@@ -142,3 +142,66 @@ EXPORT int ref_bitwriter_run(const int *nbits, const int32_t *vals, const uint8_
 
 EXPORT int ref_crc8(const uint8_t *d, uint32_t len)  { crc_init(); return calc_crc8(d, len); }
 EXPORT int ref_crc16(const uint8_t *d, uint32_t len) { crc_init(); return calc_crc16(d, len); }
+
+/* ------------------------------------------------------------------------
+ * Timing leg for bench.py's cpu_baseline: the hot path of one prepared subframe
+ * batch (LPC, order method MAX) with every stage that CAN be compiled here
+ * running as the reference's own code -- lpc_calc_coefs (lpc.c:224),
+ * calc_rice_params_lpc (rice.c:180), the BitWriter + bitwriter_write_rice_signed
+ * (bitio.h), calc_crc16 (crc.c) -- and the one stage that cannot (optimize.c needs
+ * the generated config.h) as a plain loop of this file: the integer FIR.
+ * t[0..4] receive seconds spent in lpc / fir / rice / emit / crc16.
+ * Returns the total number of residual-section bits (cross-checked by the caller
+ * against the HIP path's rice_nbits), or -1. */
+#include <time.h>
+
+static volatile unsigned crc_sink;      /* keeps the CRC pass from being optimised away */
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+EXPORT int64_t ref_time_hotpath(const int32_t *smp, const int *obits, int nsub, int n,
+                                int max_order, int precision, int pmin, int pmax,
+                                int32_t *res, uint8_t *out, int cap, double *t)
+{
+    int32_t coefs[MAX_LPC_ORDER][MAX_LPC_ORDER];
+    int shift[MAX_LPC_ORDER];
+    int64_t total = 0;
+    int s, i, j;
+    crc_init();
+    for (i = 0; i < 5; i++) t[i] = 0.0;
+    for (s = 0; s < nsub; s++) {
+        const int32_t *x = smp + (size_t)s * n;
+        RiceContext rc;
+        int64_t nbits;
+        int bytes;
+        double t0 = now_s(), t1;
+        lpc_calc_coefs(x, n, max_order, precision, FLAKE_ORDER_METHOD_MAX, coefs, shift);
+        t1 = now_s(); t[0] += t1 - t0; t0 = t1;
+        {
+            const int32_t *c = coefs[max_order - 1];
+            int sh = shift[max_order - 1];
+            for (i = 0; i < max_order; i++) res[i] = x[i];
+            for (i = max_order; i < n; i++) {
+                int64_t acc = 0;
+                for (j = max_order; j >= 1; j--) acc += (int64_t)c[j - 1] * x[i - j];
+                res[i] = (int32_t)(x[i] - (acc >> sh));
+            }
+        }
+        t1 = now_s(); t[1] += t1 - t0; t0 = t1;
+        memset(&rc, 0, sizeof(rc));
+        calc_rice_params_lpc(&rc, pmin, pmax, res, n, max_order, obits[s], precision);
+        t1 = now_s(); t[2] += t1 - t0; t0 = t1;
+        bytes = ref_emit_residual(rc.method, rc.porder, rc.params, max_order, res, n, out, cap, &nbits);
+        t1 = now_s(); t[3] += t1 - t0; t0 = t1;
+        if (bytes < 0) return -1;
+        crc_sink ^= calc_crc16(out, bytes);
+        t1 = now_s(); t[4] += t1 - t0;
+        total += nbits;
+    }
+    return total;
+}

@@ -10,6 +10,13 @@ Two families, kept in separate files and labelled in their `source` field:
 * ref_*.npz     outputs of the REAL reference functions (lpc.c, rice.c,
                 bitio.h, crc.c compiled where they lie into oracle/_ref) on
                 committed inputs.  These pin both the oracle and the HIP path.
+* ref_path.npz  whole-path outputs (prepare -> encode_residual -> frame bytes) of the
+                REPLAY in tests/refreplay.py: every arithmetic step is the compiled
+                reference (lpc.c, rice.c, bitio.h, crc.c) or a numpy integer
+                one-liner; only ~40 lines of control flow of optimize.c / encode.c
+                are re-stated.  Inputs are regenerated from committed seeds and
+                checked against a stored SHA-1.  These pin the oracle (CPU suite) and
+                the HIP path (-m gpu) to reference-compiled arithmetic end to end.
 * path_*.npz    whole-path outputs (prepare -> encode_residual -> emit -> frame)
                 produced by the oracle restatement, for the parts of libflake
                 that cannot be built here (optimize.c / encode.c / vbs.c need
@@ -31,6 +38,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import flake_amd                      # noqa: E402
 import oraclelib                      # noqa: E402
 from cases import edge_blocks, stereo_frames, param_sets, _rng   # noqa: E402
+import goldenlib                      # noqa: E402
+import refreplay                      # noqa: E402
 
 
 def blocks_for_lpc():
@@ -105,6 +114,49 @@ def make_ref_rice(ref):
                         crc16=np.array([ref.crc16(data[:l]) for l in lens], np.int32))
 
 
+def make_ref_path(ref):
+    """ref_path.npz: the replay's outputs for every case goldenlib.ref_path_cases() lists."""
+    save = {"source": "tests/refreplay.py: reference lpc.c/rice.c/bitio.h/crc.c via oracle/_ref + "
+                      "re-stated control flow of optimize.c:124-276, encode.c:541-977"}
+    kept = []
+    for name, p, n, pcm, first in goldenlib.ref_path_cases():
+        if (n & 1) and p.prediction_type == flake_amd.PRED_LEVINSON and n > p.max_prediction_order:
+            continue            # lpc.c:35,53: uninitialised window centre for odd n
+        nfr = pcm.shape[0]
+        info = np.zeros(nfr * p.channels, flake_amd.INFO_DTYPE)
+        sha = np.zeros((nfr * p.channels, 20), np.uint8)
+        frames, ok = [], True
+        fell = np.zeros(nfr, np.uint8)
+        step = n if p.allow_vbs else 1
+        for f in range(nfr):
+            frame, subs, prep = refreplay.encode_frame(ref, p, first + f * step, pcm[f], n)
+            if max(prep["obits"]) > 32:
+                ok = False      # bitwriter_writebits(33, ..): undefined shift (bitio.h:103)
+                break
+            frames.append(frame)
+            fell[f] = prep["fallback"]
+            for c in range(p.channels):
+                goldenlib.fill_info(info[f * p.channels + c], subs[c], prep, c, n, ref)
+                sha[f * p.channels + c] = goldenlib.residual_digest(subs[c], n)
+        if not ok:
+            continue
+        kept.append(name)
+        save[f"params_{name}"] = np.array([getattr(p, k) for k, _ in p._fields_], np.int32)
+        save[f"n_{name}"] = n
+        save[f"first_{name}"] = first
+        save[f"pcmsha_{name}"] = goldenlib.digest(pcm)
+        save[f"info_{name}"] = info
+        save[f"ressha_{name}"] = sha
+        save[f"fallback_{name}"] = fell
+        allf = np.concatenate(frames)
+        if allf.size <= 24576:          # larger cases keep only the per-frame SHA-1
+            save[f"frames_{name}"] = allf
+        save[f"framesha_{name}"] = np.stack([goldenlib.digest_bytes(f) for f in frames])
+        save[f"framelens_{name}"] = np.array([len(f) for f in frames], np.int32)
+    save["names"] = np.array(kept)
+    np.savez_compressed(os.path.join(HERE, "ref_path.npz"), **save)
+
+
 def make_path(orc):
     """Whole-path regression vectors from the oracle (small batches)."""
     save = {"source": "oracle/flake_oracle.c (restatement; optimize.c/encode.c not buildable here)"}
@@ -156,6 +208,7 @@ if __name__ == "__main__":
         raise SystemExit("oracle/_ref is not built: /root/reference is needed to make golden vectors")
     make_ref_lpc(oraclelib.Ref())
     make_ref_rice(oraclelib.Ref())
+    make_ref_path(oraclelib.Ref())
     make_path(oraclelib.Oracle())
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

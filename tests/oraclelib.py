@@ -316,6 +316,9 @@ class Ref:
         L.ref_bitwriter_run.restype = i
         L.ref_crc8.argtypes = [vp, C.c_uint32]
         L.ref_crc8.restype = i
+        if hasattr(L, "ref_time_hotpath"):
+            L.ref_time_hotpath.argtypes = [vp, vp, i, i, i, i, i, i, vp, vp, i, vp]
+            L.ref_time_hotpath.restype = C.c_int64
         L.ref_crc16.argtypes = [vp, C.c_uint32]
         L.ref_crc16.restype = i
 
@@ -385,6 +388,20 @@ class Ref:
         out = np.zeros(cap, np.uint8)
         rc = self.L.ref_bitwriter_run(_p(nbits), _p(vals), _p(signed), len(nbits), _p(out), cap)
         return rc, out
+
+    def time_hotpath(self, smp, obits, max_order, precision, pmin, pmax):
+        """bench.py's cpu_baseline leg: seconds per stage (lpc, fir, rice, emit, crc16) of the
+        compiled reference stages over prepared subframes smp[nsub][n]; returns (bits, t[5])."""
+        smp = np.ascontiguousarray(smp, np.int32)
+        nsub, n = smp.shape
+        ob = np.ascontiguousarray(obits, np.int32)
+        res = np.zeros(n, np.int32)
+        cap = 8 * n + 64
+        out = np.zeros(cap, np.uint8)
+        t = np.zeros(5, np.float64)
+        bits = self.L.ref_time_hotpath(_p(smp), _p(ob), nsub, n, max_order, precision, pmin, pmax,
+                                       _p(res), _p(out), cap, _p(t))
+        return int(bits), t
 
     def crc8(self, data):
         d = np.ascontiguousarray(data, np.uint8)

@@ -285,7 +285,9 @@ class _Ops:
 
     def run(self, ref, cap):
         v = np.array(self.vals, np.int64).astype(np.uint64).astype(np.uint32).view(np.int32)
-        return ref.bitwriter_run(np.array(self.nbits, np.int32), v, np.array(self.signed, np.uint8), cap)
+        rc, out = ref.bitwriter_run(np.array(self.nbits, np.int32), v,
+                                    np.array(self.signed, np.uint8), cap)
+        return None if rc < 0 else out[:rc]
 
 
 def stream_codes(p):
@@ -387,11 +389,11 @@ def emit_frame(ref, p, n, ch_mode, frame_count, subs, obits, wasted, cap):
                 for v in sf["coefs"][:sf["order"]]:
                     ops.s(p.lpc_precision, v)
             flush_ops()
-            data, nbits = ref.emit_residual(sf["method"], sf["porder"], sf["rparams"], sf["order"],
-                                            res, cap)
-            if data is None:
+            rc, nbits, data = ref.emit_residual(sf["method"], sf["porder"], sf["rparams"],
+                                                sf["order"], res, cap)
+            if rc < 0:
                 return None
-            pieces.append((data, nbits))
+            pieces.append((data[:rc], nbits))
     flush_ops()
     body = _splice(pieces)
     if len(body) + 2 > cap - 3:                    # BitWriter refuses the last bytes (bitio.h:90-93)
@@ -423,11 +425,13 @@ def encode_frame(ref, p, frame_count, pcm, n, buf_size=None):
     vsize = verbatim_size(p, n)
     cap = buf_size if buf_size is not None else vsize * 3 // 2 + 64
     frame = emit_frame(ref, p, n, mode, frame_count, subs, obits, wasted, cap)
-    if frame is None or len(frame) > vsize:
-        for c in range(p.channels):                 # reencode_residual_verbatim optimize.c:278-289
-            subs[c] = dict(subs[c], type=SUB_VERBATIM, type_code=SUB_VERBATIM, residual=smp[c].copy())
-        frame = emit_frame(ref, p, n, mode, frame_count, subs, obits, wasted, cap)
-    return frame, subs, dict(samples=smp, obits=obits, wasted=wasted, ch_mode=mode)
+    fallback = frame is None or len(frame) > vsize
+    if fallback:
+        verb = [dict(s, type=SUB_VERBATIM, type_code=SUB_VERBATIM, residual=smp[c].copy())
+                for c, s in enumerate(subs)]        # reencode_residual_verbatim optimize.c:278-289
+        frame = emit_frame(ref, p, n, mode, frame_count, verb, obits, wasted, cap)
+    # `subs` stay what encode_residual() decided (the HIP path reports those too)
+    return frame, subs, dict(samples=smp, obits=obits, wasted=wasted, ch_mode=mode, fallback=fallback)
 
 
 # ---------------------------------------------------------------------------

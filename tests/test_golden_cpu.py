@@ -1,6 +1,7 @@
 """The oracle against the committed golden vectors (no GPU, no /root/reference).
 
-ref_*.npz hold outputs of the real reference functions; path_*.npz hold
+ref_*.npz hold outputs of the real reference functions; ref_path.npz the whole-path
+outputs of the replay built on them (tests/refreplay.py); path_*.npz hold
 whole-path regression vectors made by the oracle itself (see make_golden.py).
 """
 import numpy as np
@@ -83,3 +84,29 @@ def test_path_stereo_edges(oracle):
     modes = set(int(m) for m in z["info"]["ch_mode"])
     assert {1, 8, 9, 10} <= modes, modes
     assert (z["info"]["type"] == 0).any()
+
+
+def test_ref_path(oracle):
+    """The oracle's prepare -> encode_residual -> frame bytes against the replay's vectors
+    (reference-compiled arithmetic + re-stated control flow), 141 cases."""
+    count = 0
+    for name, p, n, pcm, first, z in G.ref_path_loaded():
+        info, sha = z[f"info_{name}"], z[f"ressha_{name}"]
+        step = n if p.allow_vbs else 1
+        frames = []
+        for f in range(pcm.shape[0]):
+            rc, fb, sfs, res, verb = oracle.encode_frame(p, first + f * step, pcm[f], n)
+            assert rc > 0, name
+            frames.append(fb)
+            assert bool(verb) == bool(z[f"fallback_{name}"][f]), (name, f, "verbatim fallback")
+            if verb:
+                continue                         # the oracle reports the re-encoded subframes
+            for c in range(p.channels):
+                s = f * p.channels + c
+                nb = oracle.residual_section_bits(sfs[c], res[c]) if sfs[c]["type"] in (8, 32) else 0
+                G.assert_ref_path_info(sfs[c], info[s], f"{name} f{f} ch{c}", nbits=nb)
+                got = G.residual_digest({"type": sfs[c]["type"], "residual": res[c]}, n)
+                assert (got == sha[s]).all(), (name, f, c, "residual")
+        G.assert_ref_path_frames(name, z, frames)
+        count += 1
+    assert count >= 130

@@ -1,0 +1,169 @@
+"""Pins the UNBUILDABLE half of the oracle (its restatement of optimize.c, of the
+feeders and emit functions of encode.c, and of vbs.c) from a second side.
+
+tests/refreplay.py replays those functions with every arithmetic step taken from
+the compiled reference (oracle/_ref: lpc.c, rice.c, bitio.h, crc.c) or from numpy
+integer one-liners, and re-states only their control flow.  Here it must agree
+with oracle/flake_oracle.c field for field and byte for byte: on the BASELINE
+configs, on every order method, on the edge blocks, on every stereo mode, and on
+the 384 seeds of the GPU fuzz sweep.  The same replay generates the committed
+tests/golden/ref_path_*.npz, which the HIP path is held to under -m gpu.
+Skipped where oracle/_ref is absent."""
+import numpy as np
+import pytest
+
+import flake_amd
+import refreplay
+from cases import (ODD_BLOCK_SIZES, TINY_BLOCK_SIZES, edge_blocks, fuzz_case, param_sets,
+                   stereo_frames, _rng)
+
+
+def assert_subframe(sf, res, rep, n, what):
+    """oracle fhip_subframe_info + residual vs the replay's dict."""
+    for k in ("type", "type_code", "order", "shift"):
+        if k == "shift" and rep["type"] != refreplay.SUB_LPC:
+            continue
+        if k == "order" and rep["type"] in (refreplay.SUB_CONSTANT, refreplay.SUB_VERBATIM):
+            continue
+        assert int(sf[k]) == int(rep[k]), (what, k, int(sf[k]), int(rep[k]))
+    assert int(sf["est_bits"]) == int(rep["est_bits"]) & 0xFFFFFFFF, (what, "est_bits")
+    if rep["type"] == refreplay.SUB_CONSTANT:
+        assert int(res[0]) == int(rep["residual"][0]), what
+        return
+    assert (np.asarray(res[:n]) == rep["residual"][:n]).all(), (what, "residual")
+    if rep["type"] in (refreplay.SUB_FIXED, refreplay.SUB_LPC):
+        assert int(sf["rice_method"]) == rep["method"] and int(sf["porder"]) == rep["porder"], (what, "rc")
+        np_ = 1 << rep["porder"]
+        assert (sf["rparams"][:np_] == rep["rparams"][:np_]).all(), (what, "rparams")
+    if rep["type"] == refreplay.SUB_LPC:
+        o = rep["order"]
+        assert (sf["coefs"][:o] == rep["coefs"][:o]).all(), (what, "coefs")
+
+
+def check_frame(oracle, ref, p, frame_number, pcm, n, what):
+    rc, fb, sfs, res, verb = oracle.encode_frame(p, frame_number, pcm, n)
+    frame, subs, prep = refreplay.encode_frame(ref, p, frame_number, pcm, n)
+    mode, smp, psf = oracle.prepare_frame(p, pcm, n)
+    assert mode == prep["ch_mode"], (what, "ch_mode", mode, prep["ch_mode"])
+    assert (smp == prep["samples"]).all(), (what, "samples")
+    assert list(psf["obits"]) == prep["obits"] and list(psf["wasted"]) == prep["wasted"], (what, "obits/wasted")
+    assert bool(verb) == prep["fallback"], (what, "verbatim fallback")
+    if not verb:
+        for c in range(p.channels):
+            assert_subframe(sfs[c], res[c], subs[c], n, f"{what} ch{c}")
+    if max(prep["obits"]) > 32:
+        # 32-bit input with a side channel: obits = 33, and bitwriter_writebits(33, ...) shifts a
+        # uint32_t by 32 when one bit is left in its word (bitio.h:103) -- undefined behaviour,
+        # also violating the writer's own assert (bitio.h:116).  No parity exists to hold.
+        return
+    assert rc == len(frame), (what, "frame bytes", rc, len(frame))
+    assert (fb == frame).all(), (what, "frame", int(np.nonzero(fb != frame)[0][0]))
+
+
+@pytest.mark.parametrize("name,p,n", param_sets(), ids=[c[0] for c in param_sets()])
+def test_param_sets(oracle, ref, name, p, n):
+    nfr = 2 if (p.order_method == flake_amd.OM_SEARCH or p.channels > 2) else 3
+    pcm = flake_amd.synth_pcm(nfr, n, p.channels, p.bits_per_sample, first_frame=3)
+    for f in range(nfr):
+        check_frame(oracle, ref, p, 126 + f, pcm[f], n, f"{name} f{f}")
+
+
+@pytest.mark.parametrize("om", range(7))
+def test_order_methods_on_edge_blocks(oracle, ref, om):
+    p = flake_amd.level_params(5, channels=1, order_method=om, max_prediction_order=12,
+                               max_partition_order=8)
+    for n in (4096, 1152):
+        for k, b in edge_blocks(n, 16).items():
+            smp = np.ascontiguousarray(b, np.int32)
+            rc, sf, res = oracle.encode_residual(p, smp, 16)
+            rep = refreplay.encode_residual(ref, p, smp, 16)
+            assert_subframe(sf, res, rep, n, f"om{om} n{n} {k}")
+
+
+def test_fixed_ranges_and_partition_ranges(oracle, ref):
+    b = edge_blocks(1152, 16)
+    blocks = [b[k] for k in ("sine_plus_noise", "white", "decay", "ramp", "small_noise")]
+    for lo in range(5):
+        for hi in range(lo, 5):
+            for plo, phi in ((0, 0), (0, 3), (2, 6), (8, 8), (0, 8)):
+                p = flake_amd.level_params(2, channels=1, min_prediction_order=lo, max_prediction_order=hi,
+                                           min_partition_order=plo, max_partition_order=phi)
+                for i, smp in enumerate(blocks):
+                    rc, sf, res = oracle.encode_residual(p, smp, 16)
+                    rep = refreplay.encode_residual(ref, p, smp, 16)
+                    assert_subframe(sf, res, rep, 1152, f"fixed {lo}..{hi} p{plo}..{phi} b{i}")
+
+
+@pytest.mark.parametrize("n", TINY_BLOCK_SIZES + ODD_BLOCK_SIZES)
+def test_ragged_and_tiny_blocks(oracle, ref, n):
+    p = flake_amd.level_params(5, block_size=max(n, 16))
+    if n <= p.max_prediction_order:
+        p.min_prediction_order = min(p.min_prediction_order, 4)
+    elif n & 1:
+        # odd length: apply_welch_window leaves the centre of a malloc'd buffer unwritten
+        # (lpc.c:35,53) -- the compiled reference's LPC result then depends on heap
+        # contents.  Fixed prediction keeps the feeders, the search and the emit under test.
+        p.prediction_type = flake_amd.PRED_FIXED
+        p.min_prediction_order, p.max_prediction_order = 0, 4
+    pcm = flake_amd.synth_pcm(3, n, 2, 16, first_frame=n)
+    for f in range(3):
+        check_frame(oracle, ref, p, 2 ** 21 - 2 + f, pcm[f], n, f"n{n} f{f}")
+
+
+def test_stereo_modes_and_wasted_bits(oracle, ref):
+    """calc_decorr_scores / channel_decorrelation / remove_wasted_bits: every mode occurs."""
+    seen = set()
+    for bps in (16, 24):
+        p = flake_amd.level_params(5, bits_per_sample=bps)
+        for k, fr in stereo_frames(4096, bps).items():
+            check_frame(oracle, ref, p, 7, fr, 4096, f"stereo {bps} {k}")
+            seen.add(oracle.prepare_frame(p, fr, 4096)[0])
+    assert seen == {refreplay.CH_LR, refreplay.CH_LS, refreplay.CH_RS, refreplay.CH_MS}
+    p = flake_amd.level_params(5, channels=1)
+    for k in ("wasted_3", "wasted_max", "one_nonzero", "zeros", "dc_neg_fs", "white"):
+        check_frame(oracle, ref, p, 0, edge_blocks(4096, 16)[k][:, None], 4096, f"mono {k}")
+
+
+def test_verbatim_fallback_and_frame_numbers(oracle, ref):
+    r = _rng(12)
+    p = flake_amd.level_params(5)
+    noise = r.randint(-32768, 32768, (4096, 2)).astype(np.int32)
+    for num in (0, 127, 128, 2047, 2048, 65535, 65536, 2 ** 21 - 1, 2 ** 21, 2 ** 26 - 1, 2 ** 26, 2 ** 31 - 1):
+        check_frame(oracle, ref, p, num, noise, 4096, f"noise num{num}")
+    pv = flake_amd.level_params(9, variable_block_size=0)
+    check_frame(oracle, ref, pv, 3 * 4096, flake_amd.synth_pcm(1, 4096, 2, 16)[0], 4096, "allow_vbs")
+
+
+@pytest.mark.parametrize("chunk", range(8))
+def test_fuzz_seeds(oracle, ref, chunk):
+    """The 384 seeds of tests/test_gpu_fuzz.py::test_random_configuration."""
+    for seed in list(range(chunk * 48, chunk * 48 + 48)) + ([484, 3185] if chunk == 0 else []):
+        p, pcm, n, what = fuzz_case(seed)
+        for f in range(min(pcm.shape[0], 2)):
+            smp, obits, wasted, mode = refreplay.prepare_frame(ref, p, pcm[f], n)
+            omode, osmp, psf = oracle.prepare_frame(p, pcm[f], n)
+            assert omode == mode and (osmp == smp).all(), (what, "prepare")
+            if (n & 1) and p.prediction_type == flake_amd.PRED_LEVINSON and n > p.max_prediction_order:
+                continue                    # uninitialised window centre in the reference (see above)
+            for c in range(p.channels):
+                rc, sf, res = oracle.encode_residual(p, smp[c], obits[c])
+                rep = refreplay.encode_residual(ref, p, smp[c], obits[c])
+                assert_subframe(sf, res, rep, n, f"{what} f{f} ch{c}")
+
+
+def test_vbs_split_rule(oracle):
+    r = _rng(5)
+    for ch, bs in ((2, 4096), (1, 1024), (2, 8192), (6, 512)):
+        cases = [flake_amd.synth_pcm(1, bs, ch, 16, first_frame=s)[0] for s in range(6)]
+        x = r.randint(-3, 4, (bs, ch)).astype(np.int32)
+        x[bs // 2:] = r.randint(-30000, 30000, (bs - bs // 2, ch))        # a transient: splits
+        cases.append(x)
+        y = np.zeros((bs, ch), np.int32)
+        y[bs // 8 * 3: bs // 8 * 4] = r.randint(-2 ** 31, 2 ** 31 - 1, (bs // 8, ch))   # 32-bit wrap corner
+        cases.append(y)
+        z = r.randint(-2 ** 31, 2 ** 31 - 1, (bs, ch)).astype(np.int64)
+        z[: bs // 2] >>= 20
+        cases.append(z.astype(np.int32))
+        for i, pcm in enumerate(cases):
+            nf, sizes = oracle.vbs_split(pcm, ch, bs)
+            assert list(sizes) == refreplay.vbs_split(pcm, ch, bs), (ch, bs, i)

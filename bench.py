@@ -45,6 +45,10 @@ def parse_args():
                     help="untimed steps before the warm-up until this much wall time has passed: "
                          "the clocks ramp for ~20 ms under this load whatever --warmup says")
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
+    ap.add_argument("--ahead", action="store_true",
+                    help="hint the next batch's feeder stage ahead (fhip_prepare_ahead) so that it "
+                         "runs beside the kernels in flight; measured SLOWER on MI355X (DESIGN.md 5: "
+                         "the kernels contend, 0.163-0.194 vs 0.151 ms/step), hence opt-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="rough budget of CPU work for the cpu_baseline leg")
@@ -319,9 +323,12 @@ def main():
     nsub = nframes * p.channels
     slot = flake_amd.rice_slot_bytes(p, n)
 
-    pcm_host = flake_amd.synth_pcm(nframes, n, p.channels, p.bits_per_sample,
-                                   first_frame=rank * nframes)
-    pcm = torch.from_numpy(pcm_host).to(dev)
+    # two batches of this rank's shard alternate (different frames of the same signal model):
+    # while batch i is in flight the handle is told batch i+1 is ready (fhip_prepare_ahead)
+    pcms = [torch.from_numpy(flake_amd.synth_pcm(nframes, n, p.channels, p.bits_per_sample,
+                                                 first_frame=(2 * rank + k) * nframes)).to(dev)
+            for k in range(2)]
+    pcm = pcms[0]
     info_bytes = flake_amd.INFO_DTYPE.itemsize
     info = torch.zeros(nsub * info_bytes, dtype=torch.uint8, device=dev)
     bits = torch.zeros(nsub * slot, dtype=torch.uint8, device=dev)
@@ -329,21 +336,43 @@ def main():
         if args.with_residual else None
 
     enc = flake_amd.Encoder(p, max_frames=nframes, device=dev_index)
-    stream = torch.cuda.current_stream(dev)
+    # one stream of our own for the encoder and for torch's reads of its outputs (torch's default
+    # stream has handle 0, which the C ABI takes as "the handle's own stream": not ordered with it)
+    torch.cuda.synchronize(dev)          # uploads and fills above ran on the default stream
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
     enc.set_stream(stream.cuda_stream)
     # gloo reduces host tensors; RCCL device tensors
     cdev = dev if (world == 1 or backend == "nccl") else torch.device("cpu")
     stats = torch.zeros(3, dtype=torch.int64, device=cdev)
 
+    ahead = args.ahead
+    count = [0]
+
     def step():
-        enc.encode_subframes_dev(pcm, nframes, n, info, residual=resid, rice_bits=bits,
+        i = count[0]
+        count[0] += 1
+        enc.encode_subframes_dev(pcms[i % 2], nframes, n, info, residual=resid, rice_bits=bits,
                                  slot_bytes=slot)
+        if ahead:                 # the next batch's feeder stage, beside the kernels just queued
+            enc.prepare_ahead(pcms[(i + 1) % 2], nframes, n)
+
+    batch_bits = [0, 0]           # residual bits of the two batches (filled before the timed region)
+    batch_rice_bytes = [0, 0]
+
+    def info_bits():
+        nb = info.view(torch.int32).view(nsub, info_bytes // 4)[:, 10].clamp(min=0)
+        return int(nb.sum().item()), int(((nb + 31) // 32 * 4).sum().item())
 
     def job_stats(steps):
-        """The job's only exchange: {frames, residual bits} summed over ranks."""
-        nb = info.view(torch.int32).view(nsub, info_bytes // 4)[:, 10]
+        """The job's only exchange: {frames, residual bits} summed over ranks.
+        The bits of the batch encoded last are read back from its info records here; the two
+        alternating batches' totals were taken the same way before the timed region."""
+        last = (count[0] - 1) % 2
+        if steps:
+            batch_bits[last] = info_bits()[0]
         stats[0] = nframes * steps
-        stats[1] = int(nb.clamp(min=0).sum().item()) * steps
+        stats[1] = batch_bits[last] * ((steps + 1) // 2) + batch_bits[last ^ 1] * (steps // 2)
         stats[2] = 1                                   # ranks_seen
         if world > 1:
             dist.all_reduce(stats)
@@ -353,9 +382,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    step()
-    job_stats(0)                 # first use of these torch kernels loads their code objects
-    fence()                      # (seconds of host time: done before the clocks are ramped)
+    for k in range(2):           # also the first use of these torch kernels (loads their code
+        step()                   # objects: seconds of host time, before the clocks are ramped)
+        torch.cuda.synchronize(dev)
+        batch_bits[k], batch_rice_bytes[k] = info_bits()
+    job_stats(0)
+    fence()
     t_settle = time.perf_counter()
     while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
         for _ in range(10):
@@ -389,8 +421,7 @@ def main():
     cpu = None
     others = None
     if rank == 0:
-        info_np = np.frombuffer(info.cpu().numpy().tobytes(), dtype=flake_amd.INFO_DTYPE)
-        rice_bytes = int(((info_np["rice_nbits"].clip(min=0) + 31) // 32 * 4).sum())
+        rice_bytes = sum(batch_rice_bytes) // 2            # the two alternating batches, averaged
         alg_bytes = (nframes * n * p.channels * 4          # int32 PCM in
                      + rice_bytes                          # packed residual sections out
                      + nsub * info_bytes                   # side info out
@@ -398,11 +429,15 @@ def main():
         enc.set_profiling(True)
         enc.kernel_times(reset=True)
         for i in range(args.profile_steps):
-            enc.encode_subframes_dev(pcm, nframes, n, info, residual=resid,
-                                     rice_bits=bits, slot_bytes=slot)
+            step()                       # as in the timed region, the feeder of batch i+1 beside batch i
         enc.sync()
+        torch.cuda.synchronize(dev)
         kt = enc.kernel_times(reset=True)
         enc.set_profiling(False)
+        enc.encode_subframes_dev(pcms[0], nframes, n, info, residual=resid, rice_bits=bits,
+                                 slot_bytes=slot)           # batch 0's records for the CPU cross-check
+        enc.sync()
+        info_np = np.frombuffer(info.cpu().numpy().tobytes(), dtype=flake_amd.INFO_DTYPE)
         per = {k: (ms / max(c, 1)) for k, (ms, c) in kt.items() if c}
         if per:                          # empty with --profile-steps 0 (the PMC passes)
             dom = max(per, key=per.get)
@@ -420,11 +455,12 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": {k: round(v, 4) for k, v in per.items()},
-                # each event pair also times its own packets and the dispatch; in the timed
-                # region the kernels run back to back, so that share is (sum - step) / launches
-                "kernel_ms_net": {k: round(v - (sum(per.values()) - dt / args.steps * 1e3) / len(per), 4)
-                                  for k, v in per.items()},
-                "pipeline_achieved": round(alg_bytes / (sum(per.values()) * 1e-3) / 1e9, 1),
+                # with the next batch's k_prepare hinted ahead it runs on a stream of its own
+                # beside k_autocorr: the step is shorter than the sum of these durations
+                "prepare_ahead": ahead,
+                "step_ms": round(dt / args.steps * 1e3, 4),
+                "pipeline_achieved": round(alg_bytes / (dt / args.steps) / 1e9, 1),
+                "pipeline_frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
             }
         if world == 1 and not args.no_cpu_baseline:
             per_frame_bits = info_np["rice_nbits"].clip(min=0).astype(np.int64) \
@@ -457,6 +493,9 @@ def main():
                             "estimate), synthetic resonator PCM resident in HBM",
                 "frames_per_gpu": nframes,
                 "samples_per_step": samples_per_step,
+                "batches": "two batches of this shard alternate" +
+                           ("; the next one's feeder stage is hinted ahead (fhip_prepare_ahead)"
+                            if ahead else ""),
                 "outputs": "subframe info + packed Rice residual sections"
                            + (" + int32 residual" if args.with_residual else ""),
                 "parallelism": f"frame-sharded x{world}",

@@ -151,6 +151,7 @@ def load_library() -> C.CDLL:
         "fhip_version": (C.c_char_p, []),
         "fhip_encode_subframes_dev": (i, [vp, C.POINTER(Batch)]),
         "fhip_encode_subframes": (i, [vp, C.POINTER(Batch)]),
+        "fhip_prepare_ahead": (i, [vp, C.POINTER(Batch)]),
         "fhip_lpc_calc_coefs": (i, [vp, vp, i, i, i, i, i, vp, vp, vp, vp]),
         "fhip_encode_residual": (i, [vp, vp, i, i, vp, vp, vp, i64]),
         "fhip_prepare_frames": (i, [vp, vp, i, i, vp, vp]),
@@ -173,7 +174,7 @@ ABI_SYMBOLS = (
     "fhip_strerror", "fhip_last_error", "fhip_version", "fhip_encode_subframes_dev",
     "fhip_encode_subframes", "fhip_lpc_calc_coefs", "fhip_encode_residual",
     "fhip_prepare_frames", "fhip_calc_rice_params", "fhip_vbs_split", "fhip_set_profiling",
-    "fhip_get_kernel_times",
+    "fhip_get_kernel_times", "fhip_prepare_ahead",
 )
 
 
@@ -263,6 +264,13 @@ class Encoder:
                   _ptr(frame_bytes), first_frame_number, None)
         self._check(self.lib.fhip_encode_subframes_dev(self._h, C.byref(b)),
                     "fhip_encode_subframes_dev")
+
+    def prepare_ahead(self, pcm, nframes: int, block_size: int) -> None:
+        """Hint: start the feeder stage (K0) of the NEXT device-resident batch now, beside the
+        batch in flight; the next encode_subframes_dev() call must be for this batch."""
+        b = Batch(_ptr(pcm), nframes, block_size, None, None, None, 0, None, None, None, 0,
+                  None, 0, None)
+        self._check(self.lib.fhip_prepare_ahead(self._h, C.byref(b)), "fhip_prepare_ahead")
 
     def encode_subframes(self, pcm: np.ndarray, block_size: int, want_residual: bool = True,
                          want_bits: bool = True, want_samples: bool = False,

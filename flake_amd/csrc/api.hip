@@ -43,6 +43,22 @@ struct fhip_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     bool overlap = false;     // measured slower on C2 (K1 is chain-length bound): opt-in, FHIP_OVERLAP=1
 
+    // fhip_prepare_ahead: K0 of the NEXT batch on its own stream while this batch's K1 runs.
+    // Two sample buffers and two sets of K0 records of their own (allocated at first use), so
+    // that nothing an in-flight batch reads is written: ahead[b] is written by K0 on `pre`
+    // (after ev_enc[b]: the K3 that last read it) and read by K1/K3 on `stream` (after ev_prep[b]).
+    hipStream_t pre = nullptr;
+    int32_t *d_smp_ahead[2] = {nullptr, nullptr};
+    fhip_subframe_info *d_prep[2] = {nullptr, nullptr};
+    hipEvent_t ev_prep[2] = {nullptr, nullptr}, ev_enc[2] = {nullptr, nullptr};
+    bool enc_recorded[2] = {false, false};
+    int ahead_next = 0;
+    hipEvent_t ev_k1 = nullptr;      // after K1 of the batch queued last (experiment: gate K0 on it)
+    bool k1_recorded = false;
+    int ahead_gate = 0;              // FHIP_AHEAD_GATE: 0 none, 1 the next K0 starts when K1 has ended
+    struct Ahead { bool valid = false; const int32_t *pcm = nullptr; int nframes = 0, n = 0, buf = 0;
+                   bool narrow = false; } ahead;
+
     bool profiling = false;
     struct KTime { const char *name; double ms = 0; int launches = 0; };
     std::vector<KTime> ktimes;
@@ -111,12 +127,13 @@ struct Prof {
     fhip_ctx *c;
     int idx;
     hipEvent_t a = nullptr, b = nullptr;
-    Prof(fhip_ctx *ctx, int i) : c(ctx), idx(i)
+    hipStream_t st;
+    Prof(fhip_ctx *ctx, int i, hipStream_t on = nullptr) : c(ctx), idx(i), st(on ? on : ctx->stream)
     {
         if (!c->profiling) return;
         a = take();
         b = take();
-        if (a && b) (void)hipEventRecord(a, c->stream);
+        if (a && b) (void)hipEventRecord(a, st);
     }
     hipEvent_t take()
     {
@@ -132,23 +149,32 @@ struct Prof {
     ~Prof()
     {
         if (!c->profiling || !a || !b) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, st);
         c->pending.push_back({idx, a, b});
     }
 };
 
 void drain_profile(fhip_ctx *c)
 {
+    std::vector<fhip_ctx::Pending> later;
     for (auto &pd : c->pending) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, pd.a, pd.b) == hipSuccess) {
+        const hipError_t e = hipEventElapsedTime(&ms, pd.a, pd.b);
+        if (e == hipErrorNotReady) {              // a prepare-ahead launch still in flight
+            (void)hipGetLastError();
+            later.push_back(pd);
+            continue;
+        }
+        if (e == hipSuccess) {
             c->ktimes[pd.idx].ms += ms;
             c->ktimes[pd.idx].launches += 1;
+        } else {
+            (void)hipGetLastError();
         }
         c->event_pool.push_back(pd.a);
         c->event_pool.push_back(pd.b);
     }
-    c->pending.clear();
+    c->pending.swap(later);
 }
 
 // The four launches of one range of frames.  All pointers are device pointers
@@ -158,7 +184,8 @@ struct FrameOut { uint8_t *frames; int64_t stride; int32_t *bytes; uint32_t firs
 static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm, int nframes, int n,
                      fhip_subframe_info *info, int32_t *residual, uint8_t *bits,
                      int64_t slot_bytes, int32_t *smp, double *autoc, size_t sub0,
-                     const FrameOut &fo, bool want_rows = false)
+                     const FrameOut &fo, bool want_rows = false,
+                     const fhip_subframe_info *prepared = nullptr, bool prepared_narrow = false)
 {
     const fhip_params &p = c->p;
     const int nsub = nframes * p.channels;
@@ -174,11 +201,14 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
     };
     // stereo batches in whole tiles: K0 only decides (ch_mode, wasted bits), the K1
     // producers apply that to the PCM they stream anyway and write smp
-    const bool fused = lpc_path && fhip::autocorr_fuses_prepare(p, nsub, n);
+    // `prepared`: K0 of this batch already ran (fhip_prepare_ahead) into smp and these records
+    const bool fused = !prepared && lpc_path && fhip::autocorr_fuses_prepare(p, nsub, n);
     // rows of 16-bit samples where every kernel of this batch reads them that way and
     // nobody outside asked for the int32 rows
-    const bool narrow = !fused && !want_rows && fhip::narrow_rows_ok(p, nsub, n, lpc_path);
-    {
+    const bool narrow = prepared ? prepared_narrow
+                                 : (!fused && !want_rows && fhip::narrow_rows_ok(p, nsub, n, lpc_path));
+    const fhip_subframe_info *k0rec = prepared ? prepared : info;
+    if (!prepared) {
         MaybeProf pr(c, prof, 0);
         HIP_TRY(c, fhip::launch_prepare(st, p, pcm, nframes, n, smp, info, fused, narrow));
     }
@@ -189,7 +219,7 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
         {
             MaybeProf pr(c, prof, 1);
             HIP_TRY(c, fhip::launch_autocorr(st, smp, nsub, n, p.max_prediction_order, autoc,
-                                             fused ? pcm : nullptr, fused ? smp : nullptr, info,
+                                             fused ? pcm : nullptr, fused ? smp : nullptr, k0rec,
                                              lpc_tail ? &lo : nullptr, narrow));
         }
         if (!lpc_tail) {
@@ -198,10 +228,14 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
                                         p.order_method, coefs, shift, opt, fin));
         }
     }
+    if (c->ev_k1 && st == c->stream) {
+        HIP_TRY(c, hipEventRecord(c->ev_k1, st));
+        c->k1_recorded = true;
+    }
     {
         MaybeProf pr(c, prof, 3);
         HIP_TRY(c, fhip::launch_encode(st, p, smp, nsub, n, coefs, shift, opt, fin, info, residual,
-                                       bits, slot_bytes, -1, 0, narrow));
+                                       bits, slot_bytes, -1, 0, narrow, k0rec));
     }
     if (fo.frames) {
         MaybeProf pr(c, prof, 4);
@@ -225,6 +259,21 @@ int run_pipeline(fhip_ctx *c, const int32_t *pcm, int nframes, int n,
 {
     want_rows = want_rows || samples_out != nullptr;     // somebody reads FlacSubframe.samples as int32
     const fhip_params &p = c->p;
+    if (c->ahead.valid) {
+        // whatever was prepared ahead is ordered before this batch either way
+        const fhip_ctx::Ahead a = c->ahead;
+        c->ahead.valid = false;
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_prep[a.buf], 0));
+        if (a.pcm == pcm && a.nframes == nframes && a.n == n && !want_rows && !autoc_out) {
+            int rc = run_range(c, c->stream, c->profiling, pcm, nframes, n, info, residual, bits,
+                               slot_bytes, c->d_smp_ahead[a.buf], c->d_autoc, 0, fo, false,
+                               c->d_prep[a.buf], a.narrow);
+            if (rc != FHIP_OK) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev_enc[a.buf], c->stream));
+            c->enc_recorded[a.buf] = true;
+            return FHIP_OK;
+        }
+    }
     int32_t *smp = samples_out ? samples_out : c->d_smp;
     double *autoc = autoc_out ? autoc_out : c->d_autoc;
     const size_t nch = (size_t)p.channels;
@@ -371,6 +420,7 @@ void fhip_destroy(fhip_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->pre) (void)hipStreamSynchronize(c->pre);
     drain_profile(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     void *bufs[] = {c->d_smp, c->d_autoc, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
@@ -381,6 +431,14 @@ void fhip_destroy(fhip_ctx *c)
         if (c->ev_join[h]) (void)hipEventDestroy(c->ev_join[h]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->pre) { (void)hipStreamSynchronize(c->pre); (void)hipStreamDestroy(c->pre); }
+    if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+    for (int h = 0; h < 2; h++) {
+        if (c->ev_prep[h]) (void)hipEventDestroy(c->ev_prep[h]);
+        if (c->ev_enc[h]) (void)hipEventDestroy(c->ev_enc[h]);
+        if (c->d_smp_ahead[h]) (void)hipFree(c->d_smp_ahead[h]);
+        if (c->d_prep[h]) (void)hipFree(c->d_prep[h]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -433,6 +491,55 @@ int fhip_encode_subframes_dev(fhip_ctx *c, const fhip_batch *b)
                         b->rice_bits, b->rice_slot_bytes, b->samples, b->autoc,
                         FrameOut{b->frames, b->frame_stride, b->frame_bytes, b->first_frame_number,
                                  b->frame_numbers});
+}
+
+int fhip_prepare_ahead(fhip_ctx *c, const fhip_batch *b)
+{
+    if (!c || !b || !b->pcm) return fail(c, FHIP_E_INVALID, "null batch argument");
+    if (b->nframes < 0 || b->nframes > c->max_frames)
+        return fail(c, FHIP_E_INVALID, "nframes exceeds the handle's max_frames");
+    if (b->block_size < 1 || b->block_size > c->p.block_size)
+        return fail(c, FHIP_E_INVALID, "block_size out of range (encode.c:987)");
+    if (b->nframes == 0) return FHIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const fhip_params &p = c->p;
+    const size_t cap = (size_t)c->max_frames * p.channels;
+    if (!c->pre) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->pre, hipStreamNonBlocking));
+        if (const char *v = getenv("FHIP_AHEAD_GATE")) c->ahead_gate = atoi(v);
+        if (c->ahead_gate) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_k1, hipEventDisableTiming));
+        for (int h = 0; h < 2; h++) {
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_prep[h], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_enc[h], hipEventDisableTiming));
+            HIP_TRY(c, hipMalloc((void **)&c->d_smp_ahead[h], cap * (size_t)p.block_size * sizeof(int32_t)));
+            HIP_TRY(c, hipMalloc((void **)&c->d_prep[h], cap * sizeof(fhip_subframe_info)));
+            HIP_TRY(c, hipMemset(c->d_prep[h], 0, cap * sizeof(fhip_subframe_info)));
+        }
+    }
+    if (c->ahead.valid) {          // a second hint without an encode in between: the first one is dropped
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_prep[c->ahead.buf], 0));
+        c->ahead.valid = false;
+    }
+    const int buf = c->ahead_next;
+    c->ahead_next ^= 1;
+    const int n = b->block_size, nsub = b->nframes * p.channels;
+    const bool lpc_path = (p.prediction_type == 2) && (n > p.max_prediction_order) && n >= 5;
+    const bool narrow = fhip::narrow_rows_ok(p, nsub, n, lpc_path);
+    if (c->enc_recorded[buf]) HIP_TRY(c, hipStreamWaitEvent(c->pre, c->ev_enc[buf], 0));
+    if (c->ahead_gate == 1 && c->k1_recorded) HIP_TRY(c, hipStreamWaitEvent(c->pre, c->ev_k1, 0));
+    {
+        Prof pr(c, 0, c->pre);
+        HIP_TRY(c, fhip::launch_prepare(c->pre, p, b->pcm, b->nframes, n, c->d_smp_ahead[buf],
+                                        c->d_prep[buf], false, narrow));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_prep[buf], c->pre));
+    c->ahead.valid = true;
+    c->ahead.pcm = b->pcm;
+    c->ahead.nframes = b->nframes;
+    c->ahead.n = n;
+    c->ahead.buf = buf;
+    c->ahead.narrow = narrow;
+    return FHIP_OK;
 }
 
 // Lazily sized staging buffers for the host-pointer entry points.

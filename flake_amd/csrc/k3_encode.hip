@@ -266,7 +266,8 @@ template <int C>
 __global__ __launch_bounds__(NT)
 void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
               const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
-              const int32_t *__restrict__ opt_all, fhip_subframe_info *__restrict__ info,
+              const int32_t *__restrict__ opt_all, fhip_subframe_info *info,
+              const fhip_subframe_info *prep,
               int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
               int raw_order, int raw_lpc)
 {
@@ -295,7 +296,7 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     e.tid = tid;
     e.chunk = (n + NT - 1) / NT;
     e.i0 = tid * e.chunk;
-    e.obits = out->obits;
+    e.obits = prep[s].obits;
     e.precision = P.lpc_precision;
     e.pmin_req = P.min_partition_order;
     e.pmax_req = P.max_partition_order;
@@ -549,6 +550,9 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         out->est_bits = est_bits;
         out->rice_nbits = (int32_t)total_bits;
         out->reserved = 0;
+        out->obits = prep[s].obits;          // K0's fields: from the handle's prepare record
+        out->wasted = prep[s].wasted;        // (the caller's when the stages run in one call)
+        out->ch_mode = prep[s].ch_mode;
     }
     if (tid < FHIP_MAX_ORDER)
         out->coefs[tid] = (type == FHIP_SUB_LPC && tid < order && raw_order < 0) ? l.coef[tid] : 0;
@@ -615,7 +619,8 @@ __device__ __forceinline__ void residual_big(const EncCtx &e, const int32_t *__r
 __global__ __launch_bounds__(NT)
 void k_encode_big(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                   const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
-                  const int32_t *__restrict__ opt_all, fhip_subframe_info *__restrict__ info,
+                  const int32_t *__restrict__ opt_all, fhip_subframe_info *info,
+                  const fhip_subframe_info *prep,
                   int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
                   int raw_order, int raw_lpc)
 {
@@ -642,7 +647,7 @@ void k_encode_big(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     e.tid = tid;
     e.chunk = (n + NT - 1) / NT;                         // <= 256
     e.i0 = tid * e.chunk;
-    e.obits = out->obits;
+    e.obits = prep[s].obits;
     e.precision = P.lpc_precision;
     e.pmin_req = P.min_partition_order;
     e.pmax_req = P.max_partition_order;
@@ -913,6 +918,9 @@ void k_encode_big(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         out->est_bits = est_bits;
         out->rice_nbits = (int32_t)total_bits;
         out->reserved = 0;
+        out->obits = prep[s].obits;          // K0's fields: from the handle's prepare record
+        out->wasted = prep[s].wasted;        // (the caller's when the stages run in one call)
+        out->ch_mode = prep[s].ch_mode;
     }
     if (tid < FHIP_MAX_ORDER)
         out->coefs[tid] = (type == FHIP_SUB_LPC && tid < order && raw_order < 0) ? l.coef[tid] : 0;
@@ -1627,7 +1635,7 @@ __global__ __launch_bounds__(T, (MODE == 2 || C >= 14) ? 4 : 5)   // VGPR cap pe
 void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ smp_all,
                    const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                    const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,
-                   fhip_subframe_info *__restrict__ info,
+                   fhip_subframe_info *info, const fhip_subframe_info *prep,
                    int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
                    int narrow_ok)
 {
@@ -1677,7 +1685,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
         const int32_t *srcp = smp_all + (size_t)s * n;
         // K0 may have stored this row as int16 (info.reserved, honoured only when the
         // launcher says the flag is K0's): half the loads, one sign extension per sample
-        const int nflag = (C % 8 == 0 && narrow_ok) ? info[s].reserved : 0;     // 0, or 1 + bit length of max |x|
+        const int nflag = (C % 8 == 0 && narrow_ok) ? prep[s].reserved : 0;     // 0, or 1 + bit length of max |x|
         const bool narrow = nflag != 0;
         magbits_n = nflag - 1;
         if (C % 8 == 0 && narrow) {
@@ -1705,7 +1713,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
             for (int q = 0; q < C; q++) xn[q] = srcp[tid + T * q];
         }
         if (!narrow) first_n = srcp[0];
-        obits_n = info[s].obits;
+        obits_n = prep[s].obits;
         if (pre_row) {
             const int32_t *f = fin_all + (size_t)s * FIN_STRIDE;
             fcoef_n = f[tid & 31];
@@ -2185,6 +2193,9 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
         out->est_bits = est_bits;
         out->rice_nbits = (int32_t)total_bits;
         out->reserved = 0;
+        out->obits = prep[s].obits;          // K0's fields: from the handle's prepare record
+        out->wasted = prep[s].wasted;        // (the caller's when the stages run in one call)
+        out->ch_mode = prep[s].ch_mode;
     }
     if (tid < FHIP_MAX_ORDER) {
         out->coefs[tid] = (type == FHIP_SUB_LPC && tid < order) ? l.coef[tid] : 0;
@@ -2266,9 +2277,10 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
                          const int32_t *opt_order, const int32_t *fin,
                          fhip_subframe_info *info,
                          int32_t *residual, uint8_t *bits, int64_t slot_bytes,
-                         int raw_order, int raw_lpc, bool narrow_ok)
+                         int raw_order, int raw_lpc, bool narrow_ok, const fhip_subframe_info *prep)
 {
     if (nsub == 0) return hipSuccess;
+    if (!prep) prep = info;
     int fc = 0, ft = 0;
     static const bool force_generic = getenv("FHIP_K3_GENERIC") != nullptr;    // measurements only
     if (raw_order < 0 && !force_generic && fast_geometry(p, n, &fc, &ft)) {
@@ -2282,8 +2294,8 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_encode_pow2<CC, TT, MM>), dim3(nsub), dim3(TT), lds, st, p, n, \
-                           nsub, smp, coefs, shift, opt_order, fin, info, residual, bits,    \
-                           (long long)slot_bytes, narrow_ok ? 1 : 0);                        \
+                           nsub, smp, coefs, shift, opt_order, fin, info, prep, residual,    \
+                           bits, (long long)slot_bytes, narrow_ok ? 1 : 0);                  \
     } while (0)
         // one quantised row known up front (MAX / EST): the lean instance
         const bool single_row = (p.prediction_type == 2) && (n > p.max_prediction_order) && (p.order_method <= 1);
@@ -2331,7 +2343,8 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
     if (lds == 0) return hipErrorInvalidValue;
     if (n > FHIP_MAX_RESIDENT_BLOCK) {
         hipLaunchKernelGGL(k_encode_big, dim3(nsub), dim3(NT), lds, st, p, n, smp, coefs, shift,
-                           opt_order, info, residual, bits, (long long)slot_bytes, raw_order, raw_lpc);
+                           opt_order, info, prep, residual, bits, (long long)slot_bytes, raw_order,
+                           raw_lpc);
         return hipGetLastError();
     }
     const int chunk = (n + NT - 1) / NT;
@@ -2342,7 +2355,8 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
                                             (int)lds);                                       \
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL(k_encode<CC>, dim3(nsub), dim3(NT), lds, st, p, n, smp, coefs,    \
-                           shift, opt_order, info, residual, bits, (long long)slot_bytes,    \
+                           shift, opt_order, info, prep, residual, bits,                     \
+                           (long long)slot_bytes,                                            \
                            raw_order, raw_lpc);                                              \
     } while (0)
     if (chunk <= 16) LAUNCH_ENC(16);

@@ -174,6 +174,21 @@ FHIP_API int64_t fhip_frame_stride(const fhip_params *p, int block_size);
 
 FHIP_API int fhip_encode_subframes_dev(fhip_ctx *ctx, const fhip_batch *b);
 
+/* Optional hint for a caller that streams batch after batch through one handle
+ * (flake.c:622-663 calls flake_encode_frame block after block): start the feeder
+ * stage of the NEXT batch -- copy_samples + channel_decorrelation +
+ * remove_wasted_bits, encode.c:541-694 -- now, on a stream of the handle's own,
+ * so that it runs beside the autocorrelation of the batch in flight (K0 is
+ * HBM-bound, K1 is not).  Only next->pcm, nframes and block_size are read.
+ * Contract: next->pcm (device memory) already holds the samples when this is
+ * called -- it is NOT ordered after work queued on the handle's stream -- and
+ * stays unchanged until the fhip_encode_subframes_dev() call for the same
+ * pcm / nframes / block_size, which must be the next encode call on this handle,
+ * has completed.  That call then skips its own feeder stage; its results are
+ * identical with or without the hint.  A hint that the next call does not match
+ * (or a batch that asks for `samples` / `autoc`) is dropped without effect. */
+FHIP_API int fhip_prepare_ahead(fhip_ctx *ctx, const fhip_batch *next);
+
 /* Same with HOST pointers: copies in, runs, copies out, synchronises.  When
  * `frames` is requested, `info` and `rice_bits` may be NULL (the frames are
  * complete; the sections then live only in a device workspace of

@@ -71,7 +71,8 @@ struct fhip_ctx {
 
 namespace {
 
-const char *const kKernelNames[5] = {"k_prepare", "k_autocorr", "k_lpc", "k_encode", "k_assemble"};
+const char *const kKernelNames[6] = {"k_prepare", "k_autocorr", "k_lpc", "k_encode", "k_assemble",
+                                     "k_order_search"};
 
 int fail_hip(fhip_ctx *c, hipError_t e, const char *what)
 {
@@ -232,10 +233,17 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
         HIP_TRY(c, hipEventRecord(c->ev_k1, st));
         c->k1_recorded = true;
     }
+    // order searches: the table of candidates and the method's walk over it in a kernel of
+    // their own; K3 then encodes the one chosen row like a MAX / EST row
+    const bool searched = lpc_path && fhip::order_search_supported(p, n);
+    if (searched) {
+        MaybeProf pr(c, prof, 5);
+        HIP_TRY(c, fhip::launch_order_search(st, p, smp, nsub, n, coefs, shift, opt, fin, k0rec, narrow));
+    }
     {
         MaybeProf pr(c, prof, 3);
         HIP_TRY(c, fhip::launch_encode(st, p, smp, nsub, n, coefs, shift, opt, fin, info, residual,
-                                       bits, slot_bytes, -1, 0, narrow, k0rec));
+                                       bits, slot_bytes, -1, 0, narrow, k0rec, searched));
     }
     if (fo.frames) {
         MaybeProf pr(c, prof, 4);
@@ -382,7 +390,7 @@ int fhip_create(fhip_ctx **out, int device, const fhip_params *p, int max_frames
     c->device = device;
     c->p = *p;
     c->max_frames = max_frames;
-    for (int i = 0; i < 5; i++) c->ktimes.push_back({kKernelNames[i], 0.0, 0});
+    for (int i = 0; i < 6; i++) c->ktimes.push_back({kKernelNames[i], 0.0, 0});
 
     const size_t nsub = (size_t)max_frames * p->channels;
     const size_t n = (size_t)p->block_size;

@@ -199,5 +199,28 @@ __device__ __forceinline__ int rice_k_fast(uint64_t sum, int n, uint32_t *bits_o
     return k;
 }
 
+// rice_k_fast for a sum that fits 32 bits (every sum of 24-bit audio does): the same three
+// cases in 32-bit arithmetic -- the 64-bit shifts and leading-zero counts of the general
+// form are several instructions each.  Sums near 2^32 take the general form.
+__device__ __forceinline__ int rice_k_fast_u32(uint32_t sum, int n, uint32_t *bits_out)
+{
+    const uint32_t half = (uint32_t)(n >> 1);
+    if (sum < half) {
+        *bits_out = (uint32_t)n - (half - sum);
+        return 0;
+    }
+    const uint32_t S = sum - half;
+    if (n <= 0 || S >= 0xFFE00000u) return rice_k_fast((uint64_t)sum, n, bits_out);
+    const uint32_t two = 2u * (uint32_t)n;
+    int k = 0;
+    if (S > two) {
+        k = __clz((int)two) - __clz((int)S);
+        if ((S >> k) > two) k++;
+        if (k > 30) k = 30;
+    }
+    *bits_out = (uint32_t)(n * (k + 1)) + (S >> k);
+    return k;
+}
+
 }  // namespace
 }  // namespace fhip

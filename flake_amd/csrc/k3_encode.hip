@@ -2209,6 +2209,398 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
   }
 }
 
+// ---------------------------------------------------------------------------
+// K3-S  k_order_search<C, T, G>: the order searches of encode_residual()
+// (optimize.c:201-261: 2/4/8-LEVEL, SEARCH, LOG) as a kernel of their own.
+// ---------------------------------------------------------------------------
+// bits[order] depends on nothing but the order, so the reference's sequential search is a
+// walk over a table.  This kernel fills the table -- FIR (optimize.c:70-122), fold, partition
+// sums, Rice parameter / partition-order search (rice.c:105-187) for every candidate order
+// the method can visit -- G candidates per round, so that the fixed phases of a search (the
+// barriers, the node pass, the level selection) are paid once per round instead of once per
+// candidate, and nothing of the emit's state (residuals, parameters, windows) is carried.
+// It then replays the method's decision on the table and leaves the winner the way K2 leaves
+// the single row of the MAX / EST methods: opt_order[s] and the compact row fin[s].  The lean
+// K3 instance (MODE 0 / 3) encodes that row -- the reference's own final call
+// (optimize.c:266-275) -- so est_bits, parameters and bits come from the same code as before.
+template <int G>
+struct SrchLds {
+    unsigned long long *sums;   // [G][512] heap order per candidate slot
+    unsigned long long *wtot;   // [G][16]  per-wave totals
+    double *coefd;              // [G][32]  candidate rows as doubles, zero past the order
+    int32_t *smp;               // SmpImg<C, T>
+    uint32_t *lvl_bits;         // [2][G][12] (double-buffered by round parity)
+    uint32_t *lvl_meth;         // [2][G]
+    int32_t *pairs;             // [G][8]   taps as int16 pairs (packed FIR)
+    int32_t *rowi;              // [G][4]   order index, shift, sum |coef|, spare
+    uint32_t *trial;            // [32]     bits[order index], 0xFFFFFFFF = not evaluated
+    int32_t *list;              // [32]     candidate order indices of this subframe
+    int32_t *misc;              // [16]
+};
+
+template <int G>
+__host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[11])
+{
+    size_t o = 0;
+    off[0] = o; o += 8 * 512 * G;
+    off[1] = o; o += 8 * 16 * G;
+    off[2] = o; o += 8 * 32 * G;
+    off[3] = o; o += 4 * img_ints;
+    o = (o + 15) & ~(size_t)15;
+    off[4] = o; o += 4 * 2 * G * 12;
+    off[5] = o; o += 4 * 2 * G;
+    off[6] = o; o += 4 * 8 * G;
+    off[7] = o; o += 4 * 4 * G;
+    off[8] = o; o += 4 * 32;
+    off[9] = o; o += 4 * 32;
+    off[10] = o; o += 4 * 16;
+    return (o + 15) & ~(size_t)15;
+}
+
+template <int C, int T, int G>
+__global__ __launch_bounds__(T, (T <= 256) ? 4 : (T <= 512) ? 2 : 1)       // at most 128 VGPRs
+void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
+                    const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
+                    int32_t *__restrict__ opt_all, int32_t *__restrict__ fin_all,
+                    const fhip_subframe_info *__restrict__ prep, int narrow_ok)
+{
+    static_assert(C % 8 == 0 && T >= 64 && (T & (T - 1)) == 0, "k_order_search: runs of 8 or 16");
+    using Img = SmpImg<C, T>;
+    constexpr int LT = clog2(T);
+    constexpr int NW = T / WAVE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    size_t off[11];
+    srch_lds_layout<G>((size_t)Img::SIZE, off);
+    SrchLds<G> l;
+    l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
+    l.wtot = reinterpret_cast<unsigned long long *>(lds_raw + off[1]);
+    l.coefd = reinterpret_cast<double *>(lds_raw + off[2]);
+    l.smp = reinterpret_cast<int32_t *>(lds_raw + off[3]);
+    l.lvl_bits = reinterpret_cast<uint32_t *>(lds_raw + off[4]);
+    l.lvl_meth = reinterpret_cast<uint32_t *>(lds_raw + off[5]);
+    l.pairs = reinterpret_cast<int32_t *>(lds_raw + off[6]);
+    l.rowi = reinterpret_cast<int32_t *>(lds_raw + off[7]);
+    l.trial = reinterpret_cast<uint32_t *>(lds_raw + off[8]);
+    l.list = reinterpret_cast<int32_t *>(lds_raw + off[9]);
+    l.misc = reinterpret_cast<int32_t *>(lds_raw + off[10]);
+
+    // fp64 rounding toward -inf: fir_lpc's floor (see k_encode_pow2)
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2" ::: "memory");
+
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    FastCtx<C, T> e;
+    e.l.smp = l.smp; e.l.sums = nullptr; e.l.kpar = nullptr; e.l.coefd = l.coefd; e.l.wtot = nullptr;
+    e.l.lvl_bits = nullptr; e.l.lvl_meth = nullptr; e.l.coef = nullptr; e.l.misc = nullptr;
+    e.l.trial = nullptr; e.l.bits = nullptr;
+    e.n = n; e.tid = tid; e.lane = lane; e.wv = wv; e.i0 = tid * C;
+    e.obits = prep[s].obits;
+    e.precision = P.lpc_precision;
+    e.pmin_req = P.min_partition_order;
+    e.pmax_req = P.max_partition_order;
+
+    // ---- stage the samples (the same image k_encode_pow2 builds) ----------------------
+    int magbits = -1;
+    int differs;
+    {
+        const int32_t *srcp = smp_all + (size_t)s * n;
+        const int nflag = narrow_ok ? prep[s].reserved : 0;
+        magbits = nflag - 1;
+        int32_t xn[C];
+        int32_t first;
+        if (nflag != 0) {
+            const int4 *src4 = reinterpret_cast<const int4 *>(reinterpret_cast<const int16_t *>(srcp) + e.i0);
+#pragma unroll
+            for (int q = 0; q < C / 8; q++) {
+                const int4 t4 = src4[q];
+                xn[8 * q] = (int32_t)(int16_t)t4.x;     xn[8 * q + 1] = t4.x >> 16;
+                xn[8 * q + 2] = (int32_t)(int16_t)t4.y; xn[8 * q + 3] = t4.y >> 16;
+                xn[8 * q + 4] = (int32_t)(int16_t)t4.z; xn[8 * q + 5] = t4.z >> 16;
+                xn[8 * q + 6] = (int32_t)(int16_t)t4.w; xn[8 * q + 7] = t4.w >> 16;
+            }
+            first = (int32_t)*reinterpret_cast<const int16_t *>(srcp);
+        } else {
+            const int4 *src4 = reinterpret_cast<const int4 *>(srcp + e.i0);
+#pragma unroll
+            for (int q = 0; q < C / 4; q++) {
+                const int4 t4 = src4[q];
+                xn[4 * q] = t4.x; xn[4 * q + 1] = t4.y; xn[4 * q + 2] = t4.z; xn[4 * q + 3] = t4.w;
+            }
+            first = srcp[0];
+        }
+        int32_t mx = first, mn = first;
+#pragma unroll
+        for (int o = 0; o < C; o++) { mx = max(mx, xn[o]); mn = min(mn, xn[o]); }
+        differs = (mx != mn);
+#pragma unroll
+        for (int g4 = 0; g4 < C; g4 += 4)
+            *reinterpret_cast<int4 *>(l.smp + tid * 4 + Img::off(g4)) =
+                make_int4(xn[g4], xn[g4 + 1], xn[g4 + 2], xn[g4 + 3]);
+    }
+    if (tid < Img::COL0 * C) l.smp[Img::at(tid / C, tid % C)] = 0;
+    if (tid < 32) l.trial[tid] = 0xFFFFFFFFu;
+
+    const int omethod = P.order_method;
+    const int min_order = P.min_prediction_order, max_order = P.max_prediction_order;
+    const int32_t *crow_base = coefs_all + (size_t)s * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
+    const int32_t *srow = shift_all + (size_t)s * FHIP_MAX_ORDER;
+
+    // the orders the method can visit (indices = order - 1), each once
+    if (tid == 0) {
+        int nc = 0;
+        if (omethod >= 2 && omethod <= 4) {
+            const int levels = 1 << (omethod - 1);
+            uint32_t seen = 0;
+            for (int i = levels - 1; i >= 0; i--) {
+                int o = min_order + (((max_order - min_order + 1) * (i + 1)) / levels) - 2;
+                if (o < 0) o = 0;
+                if (!((seen >> o) & 1u)) { seen |= 1u << o; l.list[nc++] = o; }
+            }
+        } else if (omethod == 5) {
+            for (int i = 0; i < max_order; i++) l.list[nc++] = i;
+        } else {
+            for (int i = min_order - 1; i < max_order; i++) l.list[nc++] = i;
+        }
+        l.misc[0] = nc;
+    }
+    const int wave_differs = (__ballot(differs) != 0ull) ? 1 : 0;
+    if (lane == 0) l.misc[4 + wv] = wave_differs;
+    __syncthreads();
+    int any_differs = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) any_differs |= l.misc[4 + w];
+    const bool constant = (__builtin_amdgcn_readfirstlane(any_differs) == 0);
+    const int nc = constant ? 0 : __builtin_amdgcn_readfirstlane(l.misc[0]);   // CONSTANT: K3 needs no row
+
+    // partition-order window over all candidates (rice.c:148-155): the highest order has the
+    // tightest clamp, order 1 the loosest
+    const int pmin_lo = clamp_porder(e.pmin_req, n, max_order);
+    const int pmax_hi = clamp_porder(e.pmax_req, n, 1);
+
+    for (int g0 = 0, round = 0; g0 < nc; g0 += G, round++) {
+        const int ng = min(G, nc - g0);
+        const int par = round & 1;
+        // ---- the round's rows: doubles, int16 pairs, sum |coef|, shift ----
+        if (tid < G * 32) {
+            const int g = tid >> 5, j = tid & 31;
+            const int cand = (g < ng) ? l.list[g0 + g] : 0;
+            const int ord = cand + 1;
+            const int32_t cv = (g < ng && j < ord) ? crow_base[cand * FHIP_MAX_ORDER + j] : 0;
+            l.coefd[g * 32 + j] = (double)cv;
+            const int32_t nb = __shfl_xor(cv, 1, WAVE);
+            if (j < 16 && (j & 1) == 0) l.pairs[g * 8 + (j >> 1)] = (nb & 0xFFFF) | (cv << 16);
+            int32_t sa = cv < 0 ? -cv : cv;
+            sa += __shfl_xor(sa, 1, WAVE); sa += __shfl_xor(sa, 2, WAVE);
+            sa += __shfl_xor(sa, 4, WAVE); sa += __shfl_xor(sa, 8, WAVE);
+            sa += __shfl_xor(sa, 16, WAVE);
+            if (j == 0) {
+                l.rowi[g * 4 + 0] = cand;
+                l.rowi[g * 4 + 1] = (g < ng) ? srow[cand] : 0;
+                l.rowi[g * 4 + 2] = sa;
+                // rice.c:148-155 for this order, once (an integer division each)
+                l.rowi[g * 4 + 3] = clamp_porder(e.pmin_req, n, ord) | (clamp_porder(e.pmax_req, n, ord) << 8);
+            }
+        }
+        if (tid < G * 12) l.lvl_bits[par * G * 12 + tid] = 0;
+        if (tid < G) l.lvl_meth[par * G + tid] = 0;
+        __syncthreads();
+
+        // ---- per candidate: FIR, fold, thread sum, in-wave pyramid ----
+#pragma unroll 1
+        for (int g = 0; g < ng; g++) {
+            const int cand = __builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 0]);
+            const int cshift = __builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 1]);
+            const uint32_t cabs = (uint32_t)__builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 2]);
+            const int ord = cand + 1;
+            int32_t r[C];
+            FastCtx<C, T> eg = e;
+            eg.l.coefd = l.coefd + g * 32;
+#if defined(FHIP_SRCH_PROBE) && FHIP_SRCH_PROBE == 1      // timing probe: no FIR
+#pragma unroll
+            for (int o = 0; o < C; o++) r[o] = l.smp[tid * 4 + Img::off(o)] + cshift;
+#else
+            if (ord <= 16 && magbits >= 0 && ((unsigned long long)cabs << magbits) < (1ull << 31)) {
+                if (ord <= 8) fir_lpc_dotn<C, T, 4>(eg, r, ord, cshift, l.pairs + g * 8);
+                else fir_lpc_dotn<C, T, 8>(eg, r, ord, cshift, l.pairs + g * 8);
+            } else {
+                fir_lpc<C, T>(eg, r, ord, cshift);
+            }
+#endif
+            // rice.c:120-123 fold; partition 0 of every level starts at `ord` (rice.c:85-94)
+            unsigned long long v = 0;
+            if (e.i0 < ord) {
+#pragma unroll
+                for (int o = 0; o < C; o++) v += (e.i0 + o < ord) ? 0u : zigzag32(r[o]);
+            } else {
+#pragma unroll
+                for (int o = 0; o < C; o++) v += zigzag32(r[o]);
+            }
+            const int pmm = __builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 3]);
+            const int pmin = pmm & 0xFF, pmax = pmm >> 8;
+            unsigned long long *sums = l.sums + g * 512;
+#define SPYR_STORE(S_, V_)                                                                  \
+    do {                                                                                    \
+        const int lev_ = LT - (S_);                                                         \
+        if (lev_ <= pmax && lev_ >= pmin && lev_ <= 8 && (lane & ((1 << (S_)) - 1)) == 0)   \
+            sums[(1 << lev_) - 1 + (tid >> (S_))] = (V_);                                   \
+    } while (0)
+            if (!__any((v >> 26) != 0ull)) {
+                // every thread sum below 2^26: the wave's total fits 32 bits, one DPP add per step
+                uint32_t w = (uint32_t)v;
+                SPYR_STORE(0, (unsigned long long)w); w += dpp_u32<0x101>(w);
+                SPYR_STORE(1, (unsigned long long)w); w += dpp_u32<0x102>(w);
+                SPYR_STORE(2, (unsigned long long)w); w += dpp_u32<0x104>(w);
+                SPYR_STORE(3, (unsigned long long)w); w += dpp_u32<0x108>(w);
+                SPYR_STORE(4, (unsigned long long)w); w += (uint32_t)__shfl_down((int)w, 16, WAVE);
+                SPYR_STORE(5, (unsigned long long)w); w += (uint32_t)__shfl_down((int)w, 32, WAVE);
+                SPYR_STORE(6, (unsigned long long)w);
+                v = w;
+            } else {
+                SPYR_STORE(0, v); v += row_shl_u64<1>(v);
+                SPYR_STORE(1, v); v += row_shl_u64<2>(v);
+                SPYR_STORE(2, v); v += row_shl_u64<4>(v);
+                SPYR_STORE(3, v); v += row_shl_u64<8>(v);
+                SPYR_STORE(4, v); v += __shfl_down(v, 16, WAVE);
+                SPYR_STORE(5, v); v += __shfl_down(v, 32, WAVE);
+                SPYR_STORE(6, v);
+            }
+#undef SPYR_STORE
+            if (lane == 0) l.wtot[g * 16 + wv] = v;
+        }
+        __syncthreads();
+
+        // ---- one thread per (candidate, level, partition) node ----
+        {
+            const int first = (1 << pmin_lo) - 1, last = (2 << pmax_hi) - 2;
+#pragma unroll 1
+            for (int g = 0; g < ng; g++) {
+                const int ord = __builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 0]) + 1;
+                const int pmm = __builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 3]);
+                const int pmin = pmm & 0xFF, pmax = pmm >> 8;
+                for (int q0 = first; q0 <= last; q0 += T) {
+                    const int q = q0 + tid;
+                    const int p = ilog2_dev((uint32_t)(q + 1));
+                    const bool live = q <= last && p >= pmin && p <= pmax;
+                    uint32_t b = 0;
+                    int k = 0;
+                    if (live) {
+                        const int jn = q + 1 - (1 << p);
+                        const int cnt = (n >> p) - (jn == 0 ? ord : 0);
+                        unsigned long long sum;
+                        if (p <= LT - 7) {
+                            const int span = NW >> p;
+                            sum = 0;
+                            for (int w = 0; w < span; w++) sum += l.wtot[g * 16 + jn * span + w];
+                        } else {
+                            sum = l.sums[g * 512 + q];
+                        }
+                        k = (sum >> 32) ? rice_k_fast(sum, cnt, &b) : rice_k_fast_u32((uint32_t)sum, cnt, &b);
+                    }
+                    // a wave whose 64 nodes lie on one level (every wave past the first node
+                    // row) adds them up in registers: one LDS atomic per wave instead of 64
+                    const int p_first = __builtin_amdgcn_readfirstlane(p);
+                    const int p_last = ilog2_dev((uint32_t)(q0 + (tid | 63) + 1));
+                    if (p_first == p_last) {
+                        uint32_t t = b;
+                        t += dpp_u32<0x111>(t); t += dpp_u32<0x112>(t);
+                        t += dpp_u32<0x114>(t); t += dpp_u32<0x118>(t);
+                        t += dpp_u32<0x142, 0xA>(t); t += dpp_u32<0x143, 0xC>(t);
+                        const bool rice2 = __any(live && k > 14);
+                        if (lane == 63 && p_first >= pmin && p_first <= pmax) {
+                            atomicAdd(&l.lvl_bits[(par * G + g) * 12 + p_first], t);
+                            if (rice2) atomicOr(&l.lvl_meth[par * G + g], 1u << p_first);
+                        }
+                    } else if (live) {
+                        atomicAdd(&l.lvl_bits[(par * G + g) * 12 + p], b);
+                        if (k > 14) atomicOr(&l.lvl_meth[par * G + g], 1u << p);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- rice.c:127-138 and :157-171 per candidate ----
+        if (tid < ng) {
+            const int ord = l.rowi[tid * 4 + 0] + 1;
+            const int pmin = l.rowi[tid * 4 + 3] & 0xFF, pmax = l.rowi[tid * 4 + 3] >> 8;
+            const uint32_t lmask = l.lvl_meth[par * G + tid];
+            uint32_t best = 0, method = 0;
+            for (int p = pmin; p <= pmax; p++) {
+                const uint32_t b = l.lvl_bits[(par * G + tid) * 12 + p] + 4u * (1u << p);
+                if (p == pmin || b <= best) { best = b; method = (lmask >> p) & 1u; }
+            }
+            uint32_t bits = (uint32_t)(ord * e.obits + 2) + (uint32_t)(4 + 5 + ord * e.precision);
+            bits += best;
+            bits += method + 4u;
+            l.trial[ord - 1] = bits;
+        }
+        // (the next round's row staging is ordered behind this round's FIR by the barrier
+        // above; its level words are the other parity's)
+    }
+    __syncthreads();
+
+    // ---- the method's walk over the table (optimize.c:201-261) ----
+    if (tid == 0) {
+        int best = 0;
+        if (constant) {
+            best = 0;
+        } else if (omethod >= 2 && omethod <= 4) {
+            const int levels = 1 << (omethod - 1);
+            uint32_t best_bits = 0;
+            best = max_order - 1;
+            for (int i = levels - 1; i >= 0; i--) {
+                int o = min_order + (((max_order - min_order + 1) * (i + 1)) / levels) - 2;
+                if (o < 0) o = 0;
+                const uint32_t b = l.trial[o];
+                if (i == levels - 1) best_bits = b;
+                else if (b < best_bits) { best_bits = b; best = o; }
+            }
+        } else if (omethod == 5) {
+            uint32_t best_bits = l.trial[0];
+            for (int i = 1; i < max_order; i++) {
+                const uint32_t b = l.trial[i];
+                if (b < best_bits) { best_bits = b; best = i; }
+            }
+        } else {
+            uint32_t seen = 0;
+            best = min_order - 1 + (max_order - min_order) / 3;
+            for (int step = 16; step > 0; step >>= 1) {
+                const int last = best;
+                for (int i = last - step; i <= last + step; i += step) {
+                    if (i < min_order - 1 || i >= max_order || ((seen >> i) & 1u)) continue;
+                    seen |= 1u << i;
+                    const uint32_t cur = ((seen >> best) & 1u) ? l.trial[best] : 0xFFFFFFFFu;
+                    if (l.trial[i] < cur) best = i;
+                }
+            }
+        }
+        l.misc[1] = best;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        // the winner as K2's compact row (kernels.h: FIN_STRIDE / FIN_DBL / FIN_PAIRS)
+        const int best = l.misc[1];
+        const int order = best + 1;
+        int32_t *f = fin_all + (size_t)s * FIN_STRIDE;
+        const int32_t cv = (tid < order) ? crow_base[best * FHIP_MAX_ORDER + tid] : 0;
+        f[tid] = cv;
+        int32_t sa = cv < 0 ? -cv : cv;
+        sa += __shfl_xor(sa, 1, WAVE); sa += __shfl_xor(sa, 2, WAVE);
+        sa += __shfl_xor(sa, 4, WAVE); sa += __shfl_xor(sa, 8, WAVE);
+        sa += __shfl_xor(sa, 16, WAVE);
+        const int32_t nb = __shfl_xor(cv, 1, WAVE);
+        if (tid < 8) {
+            reinterpret_cast<double *>(f + FIN_DBL)[tid] = (double)cv;
+            if ((tid & 1) == 0) f[FIN_PAIRS + (tid >> 1)] = (nb & 0xFFFF) | (int32_t)((uint32_t)cv << 16);
+        }
+        if (tid == 0) {
+            f[32] = srow[best];
+            f[33] = order;
+            f[34] = sa;
+            opt_all[s] = order;
+        }
+    }
+}
 
 }  // namespace
 
@@ -2277,7 +2669,8 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
                          const int32_t *opt_order, const int32_t *fin,
                          fhip_subframe_info *info,
                          int32_t *residual, uint8_t *bits, int64_t slot_bytes,
-                         int raw_order, int raw_lpc, bool narrow_ok, const fhip_subframe_info *prep)
+                         int raw_order, int raw_lpc, bool narrow_ok, const fhip_subframe_info *prep,
+                         bool order_known)
 {
     if (nsub == 0) return hipSuccess;
     if (!prep) prep = info;
@@ -2298,7 +2691,9 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
                            bits, (long long)slot_bytes, narrow_ok ? 1 : 0);                  \
     } while (0)
         // one quantised row known up front (MAX / EST): the lean instance
-        const bool single_row = (p.prediction_type == 2) && (n > p.max_prediction_order) && (p.order_method <= 1);
+        // ... or chosen by the order-search kernel, which leaves the same compact row
+        const bool single_row = (p.prediction_type == 2) && (n > p.max_prediction_order) &&
+                                (p.order_method <= 1 || order_known);
         const bool fixed_only = (p.prediction_type == 1) && n >= 5;
         // orders 9..16 on 16-bit rows: their own instance, so that the lean one (orders <= 8,
         // the default presets) does not carry the second packed FIR (it cost it 3 %)
@@ -2363,6 +2758,54 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
     else if (chunk <= 32) LAUNCH_ENC(32);
     else LAUNCH_ENC(64);
 #undef LAUNCH_ENC
+    return hipGetLastError();
+}
+
+// The order-search kernel serves the LPC order searches (order methods 2..6) of block sizes
+// whose fast-path geometry has runs of 8 or 16 samples in at least 256 threads.
+bool order_search_supported(const fhip_params &p, int n)
+{
+    static const bool off = getenv("FHIP_NO_ORDER_SEARCH") != nullptr;      // measurements only
+    if (off) return false;
+    if (p.prediction_type != 2 || n <= p.max_prediction_order || n < 5) return false;
+    // LOG (order method 6) visits about 7 of the 12 orders of the level-8 preset one after the
+    // other; a table of all of them measured slower (342 + 74 us against 327 for the search
+    // inside K3), so it stays there.  FHIP_ORDER_SEARCH_LOG=1 routes it here (measurements).
+    static const bool log_too = getenv("FHIP_ORDER_SEARCH_LOG") != nullptr;
+    if (p.order_method < 2 || p.order_method > (log_too ? 6 : 5)) return false;
+    int fc = 0, ft = 0;
+    if (!fast_geometry(p, n, &fc, &ft)) return false;
+    return (fc == 16 && (ft == 256 || ft == 512 || ft == 1024)) || (fc == 8 && ft == 256);
+}
+
+hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32_t *smp, int nsub,
+                               int n, const int32_t *coefs, const int32_t *shift,
+                               int32_t *opt_order, int32_t *fin, const fhip_subframe_info *prep,
+                               bool narrow_ok)
+{
+    if (nsub == 0) return hipSuccess;
+    int fc = 0, ft = 0;
+    if (!order_search_supported(p, n) || !fast_geometry(p, n, &fc, &ft)) return hipErrorInvalidValue;
+    constexpr int G = 4;
+    size_t off[11];
+#define LAUNCH_SRCH(CC, TT)                                                                  \
+    do {                                                                                     \
+        const size_t lds = srch_lds_layout<G>((size_t)SmpImg<CC, TT>::SIZE, off);            \
+        hipError_t er = hipFuncSetAttribute(                                                 \
+            reinterpret_cast<const void *>(&k_order_search<CC, TT, G>),                      \
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        if (er != hipSuccess) return er;                                                     \
+        hipLaunchKernelGGL((k_order_search<CC, TT, G>), dim3(nsub), dim3(TT), lds, st, p, n, \
+                           smp, coefs, shift, opt_order, fin, prep, narrow_ok ? 1 : 0);      \
+    } while (0)
+    switch (fc * 10000 + ft) {
+    case 160256: LAUNCH_SRCH(16, 256); break;
+    case 160512: LAUNCH_SRCH(16, 512); break;
+    case 161024: LAUNCH_SRCH(16, 1024); break;
+    case 80256: LAUNCH_SRCH(8, 256); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef LAUNCH_SRCH
     return hipGetLastError();
 }
 

@@ -74,7 +74,17 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
                          fhip_subframe_info *info,
                          int32_t *residual, uint8_t *bits, int64_t slot_bytes,
                          int raw_order = -1, int raw_lpc = 0, bool narrow_ok = false,
-                         const fhip_subframe_info *prep = nullptr);
+                         const fhip_subframe_info *prep = nullptr, bool order_known = false);
+
+// K3-S: the LPC order searches (order methods 2..6, optimize.c:201-261) for block sizes it
+// supports: bits[order] for every order the method can visit, the method's walk over that
+// table, and the winner left as K2 leaves the single row of MAX / EST (opt_order[s], fin[s]);
+// launch_encode(..., order_known = true) then encodes it with the lean instance.
+bool order_search_supported(const fhip_params &p, int n);
+hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32_t *smp, int nsub,
+                               int n, const int32_t *coefs, const int32_t *shift,
+                               int32_t *opt_order, int32_t *fin, const fhip_subframe_info *prep,
+                               bool narrow_ok);
 
 // K4: whole frames on the device (encode.c:718-764, :800-917, :949-964):
 // frames [nframes][frame_stride] bytes, frame_bytes [nframes].

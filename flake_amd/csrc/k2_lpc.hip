@@ -185,6 +185,123 @@ void k_lpc_reg(const double *__restrict__ autoc_all, int nsub, int max_order, in
     lpc_reg_one<MO>(ac, s, max_order, precision, omethod, coefs, shift, opt_order, fin);
 }
 
+// ---------------------------------------------------------------------------
+// K2  k_lpc_rows: every row of a large-order search (orders 13 .. 32)
+// ---------------------------------------------------------------------------
+// The order searches quantise all max_order rows (lpc.c:249-254): 528 error-feedback steps
+// for order 32, each a dependent chain, on top of ~800 dependent Levinson steps -- with one
+// lane per subframe and the arrays in LDS (k_lpc) that is 113 us of pure latency for 8192
+// subframes.  Here a workgroup owns 32 subframes:
+//   phase A  lanes 0..31 of wave 0 run Levinson-Durbin (lpc.c:77-117) with autoc[] and
+//            lpc_tmp[] in registers (loops unrolled to compile-time indices) and leave every
+//            row lpc[i][0..i] in LDS;
+//   phase B  the rows are independent of each other: 512 threads quantise the 32 x 32 rows
+//            (lpc.c:167-219), two each.
+constexpr int LR_NT = 512;
+constexpr int LR_SUB = 32;
+constexpr int LR_STRIDE = 529;          // 528 doubles of rows per subframe, odd: lanes on distinct banks
+
+__device__ __forceinline__ void quantize_row_lds(const double *__restrict__ a, int order, int precision,
+                                                 int32_t *__restrict__ out, int32_t *__restrict__ shift_out)
+{
+    const int qmax = (1 << (precision - 1)) - 1;
+    double cmax = 0.0;
+    for (int j = 0; j < order; j++) {
+        const double m = fabs(a[j]);
+        if (m > cmax) cmax = m;
+    }
+    if (cmax * 32768.0 < 1.0) {
+        *shift_out = 0;
+        for (int j = 0; j < order; j++) out[j] = 0;
+        return;
+    }
+    int sh = 15;
+    while (sh > 0 && cmax * (double)(1 << sh) > (double)qmax) sh--;
+    const bool rescale = (sh == 0) && (cmax > (double)qmax);
+    const double scale = rescale ? ((double)qmax / cmax) : 1.0;
+    const double mul = (double)(1 << sh);
+    double carry = 0.0;
+    for (int j = 0; j < order; j++) {
+        double v = -a[j];
+        if (rescale) v = v * scale;
+        const double t = v * mul;
+        carry = carry + t;
+        int q = c_double_to_int(carry + 0.5);
+        if (q <= -qmax) q = -qmax + 1;
+        if (q > qmax) q = qmax;
+        carry = carry - (double)q;
+        out[j] = q;
+    }
+    *shift_out = sh;
+}
+
+__global__ __launch_bounds__(LR_NT)
+void k_lpc_rows(const double *__restrict__ autoc_all, int nsub, int max_order, int precision,
+                int32_t *__restrict__ coefs, int32_t *__restrict__ shift,
+                int32_t *__restrict__ opt_order)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double *rows = reinterpret_cast<double *>(lds_raw);              // [LR_SUB][LR_STRIDE]
+    constexpr int MO = FHIP_MAX_ORDER;
+    const int tid = threadIdx.x;
+    const int s0 = blockIdx.x * LR_SUB;
+
+    if (tid < LR_SUB && s0 + tid < nsub) {
+        const int s = s0 + tid;
+        double ac[MO + 1];
+#pragma unroll
+        for (int i = 0; i <= MO; i++) ac[i] = (i <= max_order) ? autoc_all[(size_t)s * FHIP_MAX_LAGS + i] : 0.0;
+        double a[MO];
+#pragma unroll
+        for (int i = 0; i < MO; i++) a[i] = 0.0;
+        double err = ac[0];
+        double *mine = rows + tid * LR_STRIDE;
+#pragma unroll
+        for (int i = 0; i < MO; i++) {
+            if (i < max_order) {
+                double r = -ac[i + 1];
+#pragma unroll
+                for (int j = 0; j < i; j++) {
+                    const double t = a[j] * ac[i - j];
+                    r = r - t;
+                }
+                r = r / err;
+                const double rr = r * r;
+                const double om = 1.0 - rr;
+                err = err * om;
+                a[i] = r;
+#pragma unroll
+                for (int j = 0; j < (i >> 1); j++) {
+                    const double lo = a[j];
+                    const double hi = a[i - 1 - j];
+                    const double t0 = r * hi;
+                    a[j] = lo + t0;
+                    const double t1 = r * lo;
+                    a[i - 1 - j] = hi + t1;
+                }
+                if (i & 1) {
+                    const double m = a[i >> 1];
+                    const double t = m * r;
+                    a[i >> 1] = m + t;
+                }
+#pragma unroll
+                for (int j = 0; j <= i; j++) mine[i * (i + 1) / 2 + j] = a[j];
+            }
+        }
+        opt_order[s] = max_order;
+    }
+    __syncthreads();
+
+    for (int item = tid; item < LR_SUB * MO; item += LR_NT) {
+        const int sub = item >> 5, row = item & 31;
+        const int s = s0 + sub;
+        if (s >= nsub || row >= max_order) continue;
+        quantize_row_lds(rows + sub * LR_STRIDE + row * (row + 1) / 2, row + 1, precision,
+                         coefs + ((size_t)s * FHIP_MAX_ORDER + row) * FHIP_MAX_ORDER,
+                         shift + (size_t)s * FHIP_MAX_ORDER + row);
+    }
+}
+
 }  // namespace
 
 hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_order,
@@ -199,7 +316,15 @@ hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_ord
     else if (max_order <= 12)
         hipLaunchKernelGGL(k_lpc_reg<12>, dim3(blocks), dim3(LPC_NT), 0, st, autoc, nsub, max_order,
                            precision, omethod, coefs, shift, opt_order, fin);
-    else
+    else if (omethod >= 2 && getenv("FHIP_K2_ONE_LANE") == nullptr) {
+        // every row wanted (lpc.c:249-254): Levinson in registers, rows quantised side by side
+        const size_t lds = (size_t)LR_SUB * LR_STRIDE * sizeof(double);
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lpc_rows),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (er != hipSuccess) return er;
+        hipLaunchKernelGGL(k_lpc_rows, dim3((nsub + LR_SUB - 1) / LR_SUB), dim3(LR_NT), lds, st, autoc, nsub,
+                           max_order, precision, coefs, shift, opt_order);
+    } else
         hipLaunchKernelGGL(k_lpc, dim3(blocks), dim3(LPC_NT), 0, st, autoc, nsub, max_order,
                            precision, omethod, coefs, shift, opt_order, fin);
     return hipGetLastError();

@@ -2358,9 +2358,9 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             }
         } else if (omethod == 5) {
             for (int i = 0; i < max_order; i++) l.list[nc++] = i;
-        } else {
-            for (int i = min_order - 1; i < max_order; i++) l.list[nc++] = i;
         }
+        // (LOG, order method 6: the candidates of a step depend on the winner so far; its
+        // rounds are the steps of optimize.c:244-261, see below)
         l.misc[0] = nc;
     }
     const int wave_differs = (__ballot(differs) != 0ull) ? 1 : 0;
@@ -2370,20 +2370,47 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 #pragma unroll
     for (int w = 0; w < NW; w++) any_differs |= l.misc[4 + w];
     const bool constant = (__builtin_amdgcn_readfirstlane(any_differs) == 0);
-    const int nc = constant ? 0 : __builtin_amdgcn_readfirstlane(l.misc[0]);   // CONSTANT: K3 needs no row
+    const int nc = __builtin_amdgcn_readfirstlane(l.misc[0]);
 
     // partition-order window over all candidates (rice.c:148-155): the highest order has the
     // tightest clamp, order 1 the loosest
     const int pmin_lo = clamp_porder(e.pmin_req, n, max_order);
     const int pmax_hi = clamp_porder(e.pmax_req, n, 1);
 
-    for (int g0 = 0, round = 0; g0 < nc; g0 += G, round++) {
-        const int ng = min(G, nc - g0);
+    // LOG walk (optimize.c:240-261), carried by every thread alike: the winner so far, the
+    // orders evaluated, the step
+    const bool is_log = (omethod == 6);
+    int lg_best = min_order - 1 + (max_order - min_order) / 3;
+    uint32_t lg_seen = 0;
+    int lg_step = 16;
+    static_assert(G >= 3, "a LOG step has up to three new candidates");
+
+    for (int g0 = 0, round = 0;; g0 += G, round++) {
+        int ng;
+        int lg_c[3] = {0, 0, 0};
+        if (constant) break;
+        if (!is_log) {
+            ng = min(G, nc - g0);
+            if (ng <= 0) break;
+        } else {
+            // the next step that has orders not yet evaluated: last - step, last, last + step
+            ng = 0;
+            while (lg_step > 0) {
+                for (int i = lg_best - lg_step; i <= lg_best + lg_step; i += lg_step) {
+                    if (i < min_order - 1 || i >= max_order || ((lg_seen >> i) & 1u)) continue;
+                    lg_c[ng++] = i;
+                }
+                if (ng) break;
+                lg_step >>= 1;
+            }
+            if (ng == 0) break;
+        }
         const int par = round & 1;
         // ---- the round's rows: doubles, int16 pairs, sum |coef|, shift ----
         if (tid < G * 32) {
             const int g = tid >> 5, j = tid & 31;
-            const int cand = (g < ng) ? l.list[g0 + g] : 0;
+            const int cand = (g >= ng) ? 0 : is_log ? (g == 0 ? lg_c[0] : g == 1 ? lg_c[1] : lg_c[2])
+                                                    : l.list[g0 + g];
             const int ord = cand + 1;
             const int32_t cv = (g < ng && j < ord) ? crow_base[cand * FHIP_MAX_ORDER + j] : 0;
             l.coefd[g * 32 + j] = (double)cv;
@@ -2536,6 +2563,17 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         }
         // (the next round's row staging is ordered behind this round's FIR by the barrier
         // above; its level words are the other parity's)
+        if (is_log) {
+            // optimize.c:249-259: the step's orders in ascending order against the winner so far
+            __syncthreads();
+            for (int k = 0; k < ng; k++) {
+                const int i = lg_c[k];
+                const uint32_t cur = ((lg_seen >> lg_best) & 1u) ? l.trial[lg_best] : 0xFFFFFFFFu;
+                lg_seen |= 1u << i;
+                if (l.trial[i] < cur) lg_best = i;
+            }
+            lg_step >>= 1;
+        }
     }
     __syncthreads();
 
@@ -2562,17 +2600,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                 if (b < best_bits) { best_bits = b; best = i; }
             }
         } else {
-            uint32_t seen = 0;
-            best = min_order - 1 + (max_order - min_order) / 3;
-            for (int step = 16; step > 0; step >>= 1) {
-                const int last = best;
-                for (int i = last - step; i <= last + step; i += step) {
-                    if (i < min_order - 1 || i >= max_order || ((seen >> i) & 1u)) continue;
-                    seen |= 1u << i;
-                    const uint32_t cur = ((seen >> best) & 1u) ? l.trial[best] : 0xFFFFFFFFu;
-                    if (l.trial[i] < cur) best = i;
-                }
-            }
+            best = lg_best;
         }
         l.misc[1] = best;
     }
@@ -2768,11 +2796,10 @@ bool order_search_supported(const fhip_params &p, int n)
     static const bool off = getenv("FHIP_NO_ORDER_SEARCH") != nullptr;      // measurements only
     if (off) return false;
     if (p.prediction_type != 2 || n <= p.max_prediction_order || n < 5) return false;
-    // LOG (order method 6) visits about 7 of the 12 orders of the level-8 preset one after the
-    // other; a table of all of them measured slower (342 + 74 us against 327 for the search
-    // inside K3), so it stays there.  FHIP_ORDER_SEARCH_LOG=1 routes it here (measurements).
-    static const bool log_too = getenv("FHIP_ORDER_SEARCH_LOG") != nullptr;
-    if (p.order_method < 2 || p.order_method > (log_too ? 6 : 5)) return false;
+    // (LOG, order method 6, walks step by step: a round per step of optimize.c:244-261, up to
+    // three candidates each.  A table of all orders measured slower: 342 + 74 us at level 8.)
+    static const bool no_log = getenv("FHIP_ORDER_SEARCH_NO_LOG") != nullptr;     // measurements only
+    if (p.order_method < 2 || p.order_method > (no_log ? 5 : 6)) return false;
     int fc = 0, ft = 0;
     if (!fast_geometry(p, n, &fc, &ft)) return false;
     return (fc == 16 && (ft == 256 || ft == 512 || ft == 1024)) || (fc == 8 && ft == 256);

@@ -262,6 +262,49 @@ def other_configs(dev_index, steps):
     return out
 
 
+def host_path(nframes=4096, n=4096):
+    """The PCIe-inclusive rate through the host C layer (flake_amd_encode_frames: pageable host
+    PCM -> complete FLAC frames in host memory), with and without the stream MD5.  Reported
+    beside the headline, never as `value`."""
+    import ctypes as C
+    import flake_amd
+    pcm = flake_amd.synth_pcm(nframes, n, 2, 16)
+    flat = np.ascontiguousarray(pcm, dtype=np.int32).reshape(-1, 2)
+    cap = 64 + pcm.size * 5 + 64 * (nframes + 1) * 8
+    out = np.ones(cap, dtype=np.uint8)                   # touched: no page faults in the timed calls
+    sizes = np.zeros(nframes, dtype=np.int32)
+    res = {"frames": nframes, "samples": nframes * n * 2}
+    saved = {k: os.environ.get(k) for k in ("FLAKE_AMD_MD5", "FLAKE_AMD_BATCH")}
+    try:
+        os.environ["FLAKE_AMD_BATCH"] = str(nframes)
+        for key, md5 in (("ms_md5_off", "0"), ("ms_md5_on", "1")):
+            os.environ["FLAKE_AMD_MD5"] = md5
+            enc = flake_amd.HostEncoder(level=5, channels=2, bits_per_sample=16, sample_rate=44100,
+                                        block_size=n, order_method=flake_amd.OM_MAX)
+            best = None
+            for call in range(4 if md5 == "0" else 2):   # the first call pays one-time allocations
+                t0 = time.perf_counter()
+                w = enc.lib.flake_amd_encode_frames(C.byref(enc.ctx), flat.ctypes.data, nframes, n, 0,
+                                                    out.ctypes.data, cap, sizes.ctypes.data)
+                dt = time.perf_counter() - t0
+                if w <= 0:
+                    raise RuntimeError("flake_amd_encode_frames failed")
+                if call:
+                    best = dt if best is None else min(best, dt)
+            enc.close()
+            res[key] = round(best * 1e3, 3)
+        res["Msamples_per_s_md5_off"] = round(res["samples"] / res["ms_md5_off"] / 1e3, 1)
+        res["note"] = ("pageable host memory in and out; copies over PCIe, kernels and frame packing "
+                       "overlap across two handles; MD5 (sequential over the stream) on a helper thread")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return res
+
+
 def launch_ranks(ngpus):
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD
     processes (torch.distributed.run, one per GPU) and pass their output through;
@@ -420,6 +463,7 @@ def main():
     roofline = None
     cpu = None
     others = None
+    host = None
     if rank == 0:
         rice_bytes = sum(batch_rice_bytes) // 2            # the two alternating batches, averaged
         alg_bytes = (nframes * n * p.channels * 4          # int32 PCM in
@@ -468,6 +512,10 @@ def main():
             cpu = cpu_baseline(p, n, args.cpu_seconds, per_frame_bits)
         if world == 1 and not args.no_other_configs:
             others = other_configs(dev_index, args.other_steps)
+            try:
+                host = host_path()
+            except Exception as e:                      # a reported extra, never fatal
+                host = {"error": repr(e)}
 
     if world > 1:
         torch.cuda.synchronize(dev)
@@ -503,6 +551,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "other_configs": others,
+            "host_path": host,
         }
         out["job_frames"] = int(stats[0].item())
         out["job_residual_bits"] = int(stats[1].item())

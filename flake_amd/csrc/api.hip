@@ -37,6 +37,10 @@ struct fhip_ctx {
     size_t d_frames_bytes = 0;
     int32_t *d_fbytes = nullptr;
     uint32_t *d_fnum = nullptr;
+    uint8_t *d_packed = nullptr;      // fhip_encode_frames_packed: the frames back to back
+    size_t d_packed_bytes = 0;
+    long long *d_offsets = nullptr;   // [max_frames + 1]
+    long long packed_ready = 0;       // bytes waiting in d_packed between _begin and _fetch
 
     // two internal streams for the split-batch overlap (run_pipeline)
     hipStream_t aux[2] = {nullptr, nullptr};
@@ -432,7 +436,8 @@ void fhip_destroy(fhip_ctx *c)
     drain_profile(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     void *bufs[] = {c->d_smp, c->d_autoc, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
-                    c->d_pcm, c->d_info, c->d_res, c->d_bits, c->d_frames, c->d_fbytes, c->d_fnum};
+                    c->d_pcm, c->d_info, c->d_res, c->d_bits, c->d_frames, c->d_fbytes, c->d_fnum,
+                    c->d_packed, c->d_offsets};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int h = 0; h < 2; h++) {
         if (c->aux[h]) { (void)hipStreamSynchronize(c->aux[h]); (void)hipStreamDestroy(c->aux[h]); }
@@ -620,6 +625,89 @@ int fhip_encode_subframes(fhip_ctx *c, const fhip_batch *b)
     if (b->autoc)
         HIP_TRY(c, hipMemcpyAsync(b->autoc, c->d_autoc, nsub * FHIP_MAX_LAGS * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     return fhip_sync(c);
+}
+
+int fhip_frames_packed_begin(fhip_ctx *c, const fhip_batch *b, int64_t *total_bytes)
+{
+    if (!c || !b || !b->pcm || !total_bytes || !b->frame_bytes)
+        return fail(c, FHIP_E_INVALID, "null argument");
+    if (b->nframes < 0 || b->nframes > c->max_frames)
+        return fail(c, FHIP_E_INVALID, "nframes exceeds the handle's max_frames");
+    if (b->block_size < 1 || b->block_size > c->p.block_size)
+        return fail(c, FHIP_E_INVALID, "block_size out of range (encode.c:987)");
+    *total_bytes = 0;
+    c->packed_ready = 0;
+    if (b->nframes == 0) return FHIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nch = (size_t)c->p.channels, n = (size_t)b->block_size;
+    const size_t nsub = (size_t)b->nframes * nch;
+    const int64_t stride = fhip_frame_stride(&c->p, b->block_size);
+    const int64_t slot = (stride + 3) & ~(int64_t)3;            // a subframe's section fits the frame's slot
+    int rc = ensure_staging(c, nsub * (size_t)slot);
+    if (rc != FHIP_OK) return rc;
+    const size_t fb = (size_t)b->nframes * (size_t)stride;
+    if (fb > c->d_frames_bytes) {
+        if (c->d_frames) (void)hipFree(c->d_frames);
+        c->d_frames = nullptr; c->d_frames_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_frames, fb));
+        c->d_frames_bytes = fb;
+    }
+    if (fb > c->d_packed_bytes) {
+        if (c->d_packed) (void)hipFree(c->d_packed);
+        c->d_packed = nullptr; c->d_packed_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_packed, fb));
+        c->d_packed_bytes = fb;
+    }
+    if (!c->d_fbytes) HIP_TRY(c, hipMalloc((void **)&c->d_fbytes, (size_t)c->max_frames * sizeof(int32_t)));
+    if (!c->d_offsets) HIP_TRY(c, hipMalloc((void **)&c->d_offsets, ((size_t)c->max_frames + 1) * sizeof(long long)));
+    FrameOut fo{c->d_frames, stride, c->d_fbytes, b->first_frame_number, nullptr};
+    if (b->frame_numbers) {
+        if (!c->d_fnum) HIP_TRY(c, hipMalloc((void **)&c->d_fnum, (size_t)c->max_frames * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemcpyAsync(c->d_fnum, b->frame_numbers, (size_t)b->nframes * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        fo.numbers = c->d_fnum;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_pcm, b->pcm, nsub * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    rc = run_pipeline(c, c->d_pcm, b->nframes, b->block_size, c->d_info, nullptr, c->d_bits, slot,
+                      nullptr, nullptr, fo, false);
+    if (rc != FHIP_OK) return rc;
+    HIP_TRY(c, fhip::launch_pack_frames(c->stream, c->d_frames, stride, c->d_fbytes, b->nframes,
+                                        c->d_offsets, c->d_packed));
+    long long total = 0;
+    HIP_TRY(c, hipMemcpyAsync(b->frame_bytes, c->d_fbytes, (size_t)b->nframes * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&total, c->d_offsets + b->nframes, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    if (b->info)
+        HIP_TRY(c, hipMemcpyAsync(b->info, c->d_info, nsub * sizeof(fhip_subframe_info), hipMemcpyDeviceToHost, c->stream));
+    rc = fhip_sync(c);
+    if (rc != FHIP_OK) return rc;
+    c->packed_ready = total;
+    *total_bytes = total;
+    return FHIP_OK;
+}
+
+int fhip_frames_packed_fetch(fhip_ctx *c, uint8_t *out, int64_t out_cap)
+{
+    if (!c || !out) return fail(c, FHIP_E_INVALID, "null argument");
+    if (c->packed_ready > out_cap) return fail(c, FHIP_E_INVALID, "output buffer too small for the batch's frames");
+    if (c->packed_ready > 0) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipMemcpy(out, c->d_packed, (size_t)c->packed_ready, hipMemcpyDeviceToHost));
+    }
+    c->packed_ready = 0;
+    return FHIP_OK;
+}
+
+int fhip_encode_frames_packed(fhip_ctx *c, const fhip_batch *b, uint8_t *out, int64_t out_cap,
+                              int64_t *out_bytes)
+{
+    if (!out || !out_bytes) return fail(c, FHIP_E_INVALID, "null argument");
+    *out_bytes = 0;
+    int64_t total = 0;
+    int rc = fhip_frames_packed_begin(c, b, &total);
+    if (rc != FHIP_OK) return rc;
+    rc = fhip_frames_packed_fetch(c, out, out_cap);
+    if (rc != FHIP_OK) return rc;
+    *out_bytes = total;
+    return FHIP_OK;
 }
 
 int fhip_prepare_frames(fhip_ctx *c, const int32_t *pcm, int nframes, int n,

@@ -412,4 +412,74 @@ hipError_t launch_assemble(hipStream_t st, const fhip_params &p, const int32_t *
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// K4-P  the batch's frames back to back (what flake_encode_frame's callers write to the file)
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int SCAN_NT = 1024;
+
+// offsets[f] = bytes of frames 0 .. f-1 (exclusive scan of frame_bytes, negatives count 0);
+// offsets[nframes] = the batch's stream length.  One workgroup.
+__global__ __launch_bounds__(SCAN_NT)
+void k_frame_offsets(const int32_t *__restrict__ fbytes, int nframes, long long *__restrict__ offsets)
+{
+    __shared__ long long s_part[SCAN_NT];
+    const int tid = threadIdx.x;
+    const int per = (nframes + SCAN_NT - 1) / SCAN_NT;
+    const int f0 = tid * per, f1 = min(f0 + per, nframes);
+    long long sum = 0;
+    for (int f = f0; f < f1; f++) sum += max(fbytes[f], 0);
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < SCAN_NT; off <<= 1) {          // Hillis-Steele inclusive scan
+        const long long v = (tid >= off) ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    long long run = s_part[tid] - sum;
+    for (int f = f0; f < f1; f++) { offsets[f] = run; run += max(fbytes[f], 0); }
+    if (tid == SCAN_NT - 1) offsets[nframes] = s_part[tid];
+}
+
+// One workgroup per frame: its bytes from the (4-byte aligned) slot to byte offset
+// offsets[f] of the packed stream.  Destination dwords are formed from two source dwords
+// (v_alignbyte); up to three bytes at either end go one at a time.
+__global__ __launch_bounds__(NT)
+void k_pack_frames(const uint8_t *__restrict__ frames, long long stride, const int32_t *__restrict__ fbytes,
+                   const long long *__restrict__ offsets, uint8_t *__restrict__ packed)
+{
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int len = max(fbytes[f], 0);
+    const uint8_t *src = frames + (size_t)f * (size_t)stride;
+    uint8_t *dst = packed + offsets[f];
+    const int head = min((int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3), len);
+    if (tid < head) dst[tid] = src[tid];
+    const int ndw = (len - head) >> 2;
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
+    const int sh = head & 3;                               // source byte phase of every destination dword
+    for (int j = tid; j < ndw; j += NT) {
+        const uint32_t lo = s32[j + (head >> 2)];
+        const uint32_t hi = sh ? s32[j + (head >> 2) + 1] : 0u;   // inside the slot: stride has 8 bytes of slack
+        d32[j] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+    }
+    const int done = head + 4 * ndw;
+    if (tid < len - done) dst[done + tid] = src[done + tid];
+}
+
+}  // namespace
+
+hipError_t launch_pack_frames(hipStream_t st, const uint8_t *frames, int64_t frame_stride,
+                              const int32_t *frame_bytes, int nframes, long long *offsets,
+                              uint8_t *packed)
+{
+    if (nframes == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_frame_offsets, dim3(1), dim3(SCAN_NT), 0, st, frame_bytes, nframes, offsets);
+    hipLaunchKernelGGL(k_pack_frames, dim3(nframes), dim3(NT), 0, st, frames, (long long)frame_stride,
+                       frame_bytes, offsets, packed);
+    return hipGetLastError();
+}
+
 }  // namespace fhip

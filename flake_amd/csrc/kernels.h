@@ -94,6 +94,12 @@ hipError_t launch_assemble(hipStream_t st, const fhip_params &p, const int32_t *
                            int32_t *frame_bytes, uint32_t number_base, uint32_t number_step,
                            const uint32_t *numbers = nullptr);
 
+// K4-P: offsets[f] = exclusive scan of frame_bytes (offsets[nframes] = total) and the frames
+// copied back to back into packed[] -- the stream order flake_encode_frame's callers write.
+hipError_t launch_pack_frames(hipStream_t st, const uint8_t *frames, int64_t frame_stride,
+                              const int32_t *frame_bytes, int nframes, long long *offsets,
+                              uint8_t *packed);
+
 // K-vbs: split_frame_v1 (vbs.c:36-83) for nblocks blocks: nframes_out [nblocks],
 // sizes_out [nblocks][8].
 hipError_t launch_vbs_split(hipStream_t st, const int32_t *pcm, int nblocks, int block_size,

@@ -33,6 +33,9 @@
 
 typedef struct host_ctx {
     fhip_ctx *hip;
+    fhip_ctx *hip2;                       /* second handle: chunks of a large batch alternate between two
+                                             host threads so that uploads, kernels and downloads overlap */
+    int chunk_frames;                     /* FLAKE_AMD_CHUNK (default 1024); 0 = one handle, one pass */
     fhip_params hp;
     int max_batch;                        /* blocks per GPU batch */
     int sr_code[2], bps_code, ch_code;
@@ -378,6 +381,15 @@ FLAKE_AMD_API int flake_amd_encode_init(FlakeAmdContext *s)
         flake_amd_encode_close(s);
         return rc;
     }
+    {
+        /* large uniform batches run in chunks through two handles (run_chunked) */
+        const char *ec = getenv("FLAKE_AMD_CHUNK");
+        c->chunk_frames = ec ? atoi(ec) : 1024;
+        if (c->chunk_frames < 0) c->chunk_frames = 0;
+        if (c->chunk_frames > 0 && c->max_batch >= 2 * c->chunk_frames && !c->host_assembly &&
+            fhip_create(&c->hip2, ed ? atoi(ed) : 0, hp, c->chunk_frames) != FHIP_OK)
+            c->hip2 = NULL;                                        /* fine: one handle, one pass */
+    }
     c->slot = (frame_verbatim_size(c, s->params.block_size) + 3) & ~3;
     const size_t nsub = (size_t)max_frames * (size_t)s->channels;
     c->info = (fhip_subframe_info *)malloc(nsub * sizeof(fhip_subframe_info));
@@ -408,6 +420,7 @@ FLAKE_AMD_API void flake_amd_encode_close(FlakeAmdContext *s)
     host_ctx *c = (host_ctx *)s->private_ctx;
     if (c) {
         if (c->hip) fhip_destroy(c->hip);
+        if (c->hip2) fhip_destroy(c->hip2);
         free(c->frame_buffer); free(c->info); free(c->bits); free(c->gather); free(c->q_pcm);
         free(c->frames); free(c->fbytes); free(c->fnum);
         free(c);
@@ -611,6 +624,106 @@ static void *md5_worker(void *arg)
     return NULL;
 }
 
+/* A uniform batch in chunks through two handles (one host thread each): chunk k's upload and
+ * kernels run while chunk k-1's frames come back -- PCIe is full duplex -- and a chunk's frames
+ * go to `out` as soon as the chunks before it have reported their sizes. */
+typedef struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    long long *end;                       /* end[k]: stream offset behind chunk k, -1 = not known yet */
+    int failed;
+} chunk_sync;
+typedef struct {
+    host_ctx *c;
+    fhip_ctx *h;
+    chunk_sync *sy;
+    const int32_t *pcm;
+    int n, nch, np, chunk, first, nchunks;
+    uint8_t *out;
+    long long cap;
+    int rc;
+} chunk_job;
+
+static void *chunk_worker(void *arg)
+{
+    chunk_job *j = (chunk_job *)arg;
+    host_ctx *c = j->c;
+    for (int k = j->first; k < j->nchunks; k += 2) {
+        const int f0 = k * j->chunk, nf = (j->np - f0 < j->chunk) ? j->np - f0 : j->chunk;
+        fhip_batch b;
+        memset(&b, 0, sizeof b);
+        b.pcm = j->pcm + (size_t)f0 * (size_t)j->n * (size_t)j->nch;
+        b.nframes = nf; b.block_size = j->n;
+        b.frame_bytes = c->fbytes + f0;
+        b.frame_numbers = c->fnum + f0;
+        int64_t total = 0;
+        int rc = fhip_frames_packed_begin(j->h, &b, &total);
+        pthread_mutex_lock(&j->sy->mu);
+        while (!j->sy->failed && k > 0 && j->sy->end[k - 1] < 0) pthread_cond_wait(&j->sy->cv, &j->sy->mu);
+        const long long start = (k > 0) ? j->sy->end[k - 1] : 0;
+        if (rc != FHIP_OK || j->sy->failed || start + total > j->cap) {
+            j->sy->failed = 1;
+            j->sy->end[k] = 0;
+            pthread_cond_broadcast(&j->sy->cv);
+            pthread_mutex_unlock(&j->sy->mu);
+            j->rc = (rc != FHIP_OK) ? rc : FHIP_E_INVALID;
+            return NULL;
+        }
+        j->sy->end[k] = start + total;
+        pthread_cond_broadcast(&j->sy->cv);
+        pthread_mutex_unlock(&j->sy->mu);
+        rc = fhip_frames_packed_fetch(j->h, j->out + start, j->cap - start);
+        if (rc != FHIP_OK) {
+            pthread_mutex_lock(&j->sy->mu);
+            j->sy->failed = 1;
+            pthread_cond_broadcast(&j->sy->cv);
+            pthread_mutex_unlock(&j->sy->mu);
+            j->rc = rc;
+            return NULL;
+        }
+    }
+    j->rc = FHIP_OK;
+    return NULL;
+}
+
+/* returns bytes written, or -1 */
+static long long run_chunked(host_ctx *c, const int32_t *pcm, int np, int n, int nch, uint8_t *out, size_t cap)
+{
+    const int chunk = c->chunk_frames;
+    const int nchunks = (np + chunk - 1) / chunk;
+    chunk_sync sy;
+    long long *end = (long long *)malloc(sizeof(long long) * (size_t)nchunks);
+    if (!end) return -1;
+    for (int k = 0; k < nchunks; k++) end[k] = -1;
+    pthread_mutex_init(&sy.mu, NULL);
+    pthread_cond_init(&sy.cv, NULL);
+    sy.end = end; sy.failed = 0;
+    chunk_job ja = { c, c->hip, &sy, pcm, n, nch, np, chunk, 0, nchunks, out, (long long)cap, FHIP_OK };
+    chunk_job jb = ja;
+    jb.h = c->hip2; jb.first = 1;
+    pthread_t tb;
+    const int have_b = pthread_create(&tb, NULL, chunk_worker, &jb) == 0;
+    if (!have_b) {                         /* no second thread: this one walks every chunk */
+        for (int k = 0; k < nchunks && ja.rc == FHIP_OK; k++) {
+            chunk_job one = ja;
+            one.first = k; one.nchunks = k + 1;
+            chunk_worker(&one);
+            ja.rc = one.rc;
+        }
+    } else {
+        chunk_worker(&ja);
+        pthread_join(tb, NULL);
+    }
+    long long total = -1;
+    if (!sy.failed && ja.rc == FHIP_OK && (!have_b || jb.rc == FHIP_OK)) total = end[nchunks - 1];
+    else snprintf(c->err, sizeof c->err, "chunked batch failed: %s / %s", fhip_last_error(c->hip),
+                  c->hip2 ? fhip_last_error(c->hip2) : "");
+    pthread_mutex_destroy(&sy.mu);
+    pthread_cond_destroy(&sy.cv);
+    free(end);
+    return total;
+}
+
 /* Encode `count` blocks starting at pcm (each block_size samples/channel). */
 static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pcm, int count,
                               int block_size, uint8_t *out, size_t cap, int *frame_sizes)
@@ -676,6 +789,49 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
         /* frame numbers in stream order (encode.c:969-975) */
         uint32_t fc = c->frame_count;
         for (int i = 0; i < np; i++) { num_of[i] = fc; fc += s->params.allow_vbs ? (uint32_t)pieces[i].n : 1u; }
+    }
+    /* every piece the same length and in place (no VBS split happened): the device packs the
+     * frames back to back and the copy over PCIe lands them in `out` directly */
+    {
+        int uniform = !c->host_assembly && np > 0;
+        for (int i = 1; i < np && uniform; i++)
+            uniform = pieces[i].n == pieces[0].n &&
+                      pieces[i].pcm == pieces[0].pcm + (size_t)i * (size_t)pieces[0].n * nch;
+        if (uniform) {
+            const double tg0 = now_ms();
+            fhip_batch b;
+            memset(&b, 0, sizeof b);
+            b.pcm = pieces[0].pcm; b.nframes = np; b.block_size = pieces[0].n;
+            b.frame_bytes = c->fbytes;
+            for (int i = 0; i < np; i++) c->fnum[i] = num_of[i];
+            b.frame_numbers = c->fnum;
+            int64_t wrote = 0;
+            if (c->hip2 && c->chunk_frames > 0 && np >= 2 * c->chunk_frames) {
+                wrote = run_chunked(c, pieces[0].pcm, np, pieces[0].n, nch, out, cap);
+                if (wrote < 0) goto out;
+            } else {
+                const int rc = fhip_encode_frames_packed(c->hip, &b, out, (int64_t)cap, &wrote);
+                if (rc != FHIP_OK) {
+                    snprintf(c->err, sizeof c->err, "fhip_encode_frames_packed: %s (%s)", fhip_strerror(rc),
+                             fhip_last_error(c->hip));
+                    goto out;
+                }
+            }
+            t_gpu = now_ms() - tg0; ngroups = 1;
+            int cur_block = -1;
+            for (int i = 0; i < np; i++) {
+                const int fs = c->fbytes[i];
+                if (fs <= 0) { snprintf(c->err, sizeof c->err, "frame %d was not encoded", i); goto out; }
+                if (fs > c->max_frame_size) c->max_frame_size = fs;    /* encode.c:967 */
+                c->frame_count += s->params.allow_vbs ? (uint32_t)pieces[i].n : 1u;   /* encode.c:969-975 */
+                if (frame_sizes) {
+                    if (pieces[i].block != cur_block) { cur_block = pieces[i].block; frame_sizes[cur_block] = 0; }
+                    frame_sizes[cur_block] += fs;
+                }
+            }
+            total = (long long)wrote;
+            goto hashed;
+        }
     }
     {
         int next_slot = 0;
@@ -752,6 +908,7 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
         total = (long long)pos;
         t_out = now_ms() - to0;
     }
+hashed:
     if (c->trace)
         fprintf(stderr, "flake_amd batch: %d blocks -> %d frames in %d size groups; split %.2f ms, gather %.2f, "
                         "gpu (H2D + kernels + D2H) %.2f, copy-out %.2f\n", count, np, ngroups, t_split, t_gather,

@@ -174,6 +174,23 @@ FHIP_API int64_t fhip_frame_stride(const fhip_params *p, int block_size);
 
 FHIP_API int fhip_encode_subframes_dev(fhip_ctx *ctx, const fhip_batch *b);
 
+/* Host batch -> the batch's frames back to back in host memory: what the loop around
+ * flake_encode_frame() writes to the file (flake.c:633-637), for nframes blocks at once.
+ * b->pcm is host memory; b->frame_bytes (host, [nframes]) receives the size of every frame
+ * (encode_frame's return value, encode.c:976); b->frame_numbers / first_frame_number as in
+ * fhip_encode_subframes; b->info (host) is optional; the other outputs are ignored.  Frames
+ * are assembled, packed (exclusive scan of their sizes + copy) and only then brought over:
+ * the transfer is the stream's bytes, not the frames' verbatim-size slots.  *out_bytes = the
+ * bytes written to out (<= out_cap, else FHIP_E_INVALID and nothing is written). */
+FHIP_API int fhip_encode_frames_packed(fhip_ctx *ctx, const fhip_batch *b, uint8_t *out,
+                                       int64_t out_cap, int64_t *out_bytes);
+/* The same in two steps, for a caller that runs chunks of a stream through several handles
+ * side by side (one host thread each) and only knows where a chunk's frames go once the
+ * chunks before it have reported their sizes: _begin uploads, encodes, packs and returns the
+ * chunk's byte count (b->frame_bytes filled); _fetch brings the packed frames to `out`. */
+FHIP_API int fhip_frames_packed_begin(fhip_ctx *ctx, const fhip_batch *b, int64_t *total_bytes);
+FHIP_API int fhip_frames_packed_fetch(fhip_ctx *ctx, uint8_t *out, int64_t out_cap);
+
 /* Optional hint for a caller that streams batch after batch through one handle
  * (flake.c:622-663 calls flake_encode_frame block after block): start the feeder
  * stage of the NEXT batch -- copy_samples + channel_decorrelation +

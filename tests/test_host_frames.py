@@ -290,3 +290,25 @@ def test_long_blocks_through_the_host_layer(oracle, decoder, n):
         out, _ = decoder.decode(data, 2, 16, pcm.shape[0])
         assert (out == pcm).all()
         assert bytes(enc.streaminfo().md5sum) == pcm_md5(pcm, 16)
+
+
+def test_chunked_two_handle_batches_equal_the_single_pass(monkeypatch, decoder):
+    """Large uniform batches run in chunks through two handles on two host threads
+    (run_chunked): the stream must be the single-pass stream byte for byte, sizes included,
+    whatever the chunk size (ragged last chunk, odd and even chunk counts)."""
+    n, nblocks = 576, 301
+    pcm = flake_amd.synth_pcm(nblocks, n, 2, 16, first_frame=11).reshape(-1, 2)
+    monkeypatch.setenv("FLAKE_AMD_BATCH", "4096")
+    monkeypatch.setenv("FLAKE_AMD_CHUNK", "0")
+    with flake_amd.HostEncoder(5, block_size=n) as enc:
+        ref, ref_sizes = enc.encode_frames(pcm, n, 0)
+        ref_md5 = bytes(enc.streaminfo().md5sum)
+    for chunk in (32, 50, 100, 150):
+        monkeypatch.setenv("FLAKE_AMD_CHUNK", str(chunk))
+        with flake_amd.HostEncoder(5, block_size=n) as enc:
+            data, sizes = enc.encode_frames(pcm, n, 0)
+            assert (sizes == ref_sizes).all(), chunk
+            assert data.tobytes() == ref.tobytes(), chunk
+            assert bytes(enc.streaminfo().md5sum) == ref_md5
+    out, bs = decoder.decode(ref, 2, 16, pcm.shape[0])
+    assert (out == pcm).all() and len(bs) == nblocks

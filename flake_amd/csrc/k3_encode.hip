@@ -2234,12 +2234,13 @@ struct SrchLds {
     int32_t *pairs;             // [G][8]   taps as int16 pairs (packed FIR)
     int32_t *rowi;              // [G][4]   order index, shift, sum |coef|, spare
     uint32_t *trial;            // [32]     bits[order index], 0xFFFFFFFF = not evaluated
+    uint32_t *leaf;             // [16][T]  MFMA instance: finest-level sums of a group of 16 candidates
     int32_t *list;              // [32]     candidate order indices of this subframe
     int32_t *misc;              // [16]
 };
 
 template <int G>
-__host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[11])
+__host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[12], int leaf_tiles = 0)
 {
     size_t o = 0;
     off[0] = o; o += 8 * 512 * G;
@@ -2254,11 +2255,138 @@ __host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[11
     off[8] = o; o += 4 * 32;
     off[9] = o; o += 4 * 32;
     off[10] = o; o += 4 * 16;
+    o = (o + 15) & ~(size_t)15;
+    // MFMA instance: leaf [16][tiles] u32.  A group either goes wave-per-candidate (the leaves
+    // plus one 1 KB heap per wave at the head of `sums`) or, after an overflow, through the
+    // rounds (all of `sums`, no leaves): the leaves overlay `sums` behind the heaps.
+    off[11] = 0;
+    if (leaf_tiles) {
+        const size_t heaps = 8 * 128 * (size_t)(leaf_tiles / 64);
+        off[11] = off[0] + heaps;
+        const size_t need = off[11] + 4 * 16 * (size_t)leaf_tiles;
+        // regions 1.. were laid out behind the G * 4 KB of sums: push everything behind the overlay
+        const size_t have = off[1];
+        if (need > have) {
+            const size_t shift = (need - have + 15) & ~(size_t)15;
+            for (int q = 1; q <= 10; q++) off[q] += shift;
+            o += shift;
+        }
+    }
     return (o + 15) & ~(size_t)15;
 }
 
-template <int C, int T, int G>
-__global__ __launch_bounds__(T, (T <= 256) ? 4 : (T <= 512) ? 2 : 1)       // at most 128 VGPRs
+
+// rice.c:105-187 for ONE candidate by ONE wave, from the finest-level sums the MFMA phase of
+// k_order_search left in LDS (leaf[tile], tile = 16 samples): no barrier, no atomics.  A lane
+// takes T/64 consecutive leaves and owns the nodes above them down to level 6 (always seven
+// that can be asked for: four at level 8, two at 7, one at 6); levels 5..0 are 63 nodes built
+// through a small per-wave heap in LDS and evaluated one per lane.  Level totals: a wave
+// reduction for the three lane-local levels, a wave scan over the heap lanes for the rest.
+// Returns the subframe estimate of calc_rice_params_lpc (rice.c:180-187).
+template <int T>
+__device__ __forceinline__ uint32_t wave_candidate_bits(const uint32_t *__restrict__ leaf,
+                                                        unsigned long long *__restrict__ heap, int n, int ord,
+                                                        int pmin, int pmax, int obits, int precision, int lane)
+{
+    constexpr int LPL = T / 64;                 // leaves per lane: 4 (n = 4096), 8, 16
+    constexpr int L8 = LPL / 4;                 // leaves per level-8 node
+    static_assert(LPL >= 4 && LPL <= 16, "wave_candidate_bits: 256 .. 1024 tiles");
+    uint32_t lf[LPL];
+#pragma unroll
+    for (int q = 0; q < LPL; q += 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(leaf + lane * LPL + q);
+        lf[q] = v.x; lf[q + 1] = v.y; lf[q + 2] = v.z; lf[q + 3] = v.w;
+    }
+    unsigned long long s8[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        s8[i] = 0;
+#pragma unroll
+        for (int q = 0; q < L8; q++) s8[i] += lf[i * L8 + q];
+    }
+    const unsigned long long s7[2] = {s8[0] + s8[1], s8[2] + s8[3]};
+    const unsigned long long s6 = s7[0] + s7[1];
+
+    auto node = [&](unsigned long long sum, int p, int jn, uint32_t *b) -> int {
+        const int cnt = (n >> p) - (jn == 0 ? ord : 0);
+        return (sum >> 32) ? rice_k_fast(sum, cnt, b) : rice_k_fast_u32((uint32_t)sum, cnt, b);
+    };
+    uint32_t lb[9];
+#pragma unroll
+    for (int p = 0; p < 9; p++) lb[p] = 0;
+    uint32_t rice2 = 0;                         // bit p: some parameter of level p is above 14
+    // ---- lane-local levels 8, 7, 6 ----
+    {
+        uint32_t b8 = 0, b7 = 0, b6 = 0;
+        bool k8 = false, k7 = false, k6 = false;
+        if (pmax >= 8 && pmin <= 8) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { uint32_t b; k8 |= node(s8[i], 8, 4 * lane + i, &b) > 14; b8 += b; }
+        }
+        if (pmax >= 7 && pmin <= 7) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) { uint32_t b; k7 |= node(s7[i], 7, 2 * lane + i, &b) > 14; b7 += b; }
+        }
+        if (pmax >= 6 && pmin <= 6) { uint32_t b; k6 = node(s6, 6, lane, &b) > 14; b6 = b; }
+        uint32_t t8 = b8, t7 = b7, t6 = b6;
+#define WSUM(X_) do { X_ += dpp_u32<0x111>(X_); X_ += dpp_u32<0x112>(X_); X_ += dpp_u32<0x114>(X_);       \
+                      X_ += dpp_u32<0x118>(X_); X_ += dpp_u32<0x142, 0xA>(X_); X_ += dpp_u32<0x143, 0xC>(X_); } while (0)
+        WSUM(t8); WSUM(t7); WSUM(t6);
+#undef WSUM
+        lb[8] = (uint32_t)__builtin_amdgcn_readlane((int)t8, 63);
+        lb[7] = (uint32_t)__builtin_amdgcn_readlane((int)t7, 63);
+        lb[6] = (uint32_t)__builtin_amdgcn_readlane((int)t6, 63);
+        if (__any(k8)) rice2 |= 1u << 8;
+        if (__any(k7)) rice2 |= 1u << 7;
+        if (__any(k6)) rice2 |= 1u << 6;
+    }
+    // ---- levels 5 .. 0: a 127-entry heap of this wave (entry 2^p - 1 + j = node j of level p) ----
+    if (pmin <= 5) {
+        heap[63 + lane] = s6;
+#pragma unroll
+        for (int p = 5; p >= 0; p--) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < (1 << p)) {
+                const int c = (2 << p) - 1 + 2 * lane;
+                heap[(1 << p) - 1 + lane] = heap[c] + heap[c + 1];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int p = ilog2_dev((uint32_t)(lane + 1));           // lanes 0..62: node `lane`, level p
+        uint32_t b = 0;
+        bool big = false;
+        if (lane < 63 && p >= pmin && p <= pmax) big = node(heap[lane], p, lane + 1 - (1 << p), &b) > 14;
+        const uint32_t sc = wave_incl_scan_u32_dpp(b);
+        const unsigned long long bigm = __ballot(big);
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)sc, (2 << q) - 2);
+            const uint32_t lo = q ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (1 << q) - 2) : 0u;
+            lb[q] = hi - lo;
+            const unsigned long long lvl = ((1ull << ((2 << q) - 1)) - 1) & ~((1ull << ((1 << q) - 1)) - 1);
+            if (bigm & lvl) rice2 |= 1u << q;
+        }
+        __builtin_amdgcn_wave_barrier();                        // the heap is reused by the next candidate
+    }
+    // rice.c:127-138, :157-171, :180-187
+    uint32_t best = 0, method = 0;
+#pragma unroll
+    for (int p = 0; p < 9; p++) {
+        const uint32_t b = lb[p] + 4u * (1u << p);
+        if (p >= pmin && p <= pmax && (p == pmin || b <= best)) { best = b; method = (rice2 >> p) & 1u; }
+    }
+    uint32_t bits = (uint32_t)(ord * obits + 2) + (uint32_t)(4 + 5 + ord * precision);
+    bits += best;
+    bits += method + 4u;
+    return bits;
+}
+
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+template <int C, int T, int G, bool MF>
+__global__ __launch_bounds__(T, (T <= 256) ? 4 : (T <= 512) ? 2 : 1)
 void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                     const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                     int32_t *__restrict__ opt_all, int32_t *__restrict__ fin_all,
@@ -2269,9 +2397,10 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     constexpr int LT = clog2(T);
     constexpr int NW = T / WAVE;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    size_t off[11];
-    srch_lds_layout<G>((size_t)Img::SIZE, off);
+    size_t off[12];
+    srch_lds_layout<G>((size_t)Img::SIZE, off, MF ? T : 0);
     SrchLds<G> l;
+    l.leaf = reinterpret_cast<uint32_t *>(lds_raw + off[11]);
     l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
     l.wtot = reinterpret_cast<unsigned long long *>(lds_raw + off[1]);
     l.coefd = reinterpret_cast<double *>(lds_raw + off[2]);
@@ -2339,6 +2468,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     }
     if (tid < Img::COL0 * C) l.smp[Img::at(tid / C, tid % C)] = 0;
     if (tid < 32) l.trial[tid] = 0xFFFFFFFFu;
+    if (tid < 2) l.misc[2 + tid] = 0;                  // MFMA instance: "a tile sum left 32 bits", per group parity
 
     const int omethod = P.order_method;
     const int min_order = P.min_prediction_order, max_order = P.max_prediction_order;
@@ -2406,6 +2536,110 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             if (ng == 0) break;
         }
         const int par = round & 1;
+        bool use_leaf = false;
+        if constexpr (MF) {
+            // ---- a group of 16 candidates: their FIRs as one matrix product per tile ----
+            // pred[m][i] = sum_j coef[m][j] x[i-1-j] for 16 candidate rows m and the 16 samples i
+            // of a tile IS a 16 x 16 x (4 per instruction) product: A = coefficients (zero past a
+            // row's order), B = the tile's Toeplitz window of samples.  As doubles everything is
+            // an exact integer below 2^53 (as in fir_lpc), so v_mfma_f64_16x16x4_f64 gives the
+            // reference's int64 sums bit for bit whatever its internal order -- and it runs on
+            // the matrix pipe, which this VALU-bound kernel leaves idle.  Lane l supplies
+            // A[m = l%16][k = l/16] and B[k = l/16][i = l%16] and receives D[m = 4r + l/16][i = l%16]
+            // in register r (layout checked on the hardware, tools/mfma_probe.hip).  The epilogue
+            // per register: floor(pred * 2^-shift) by the fma of fir_lpc, residual, fold
+            // (rice.c:122), warm-up zeroed, and the tile's sum by a DPP row reduction: the
+            // finest-level partition sum (a tile = 16 samples = one thread of the pyramid).
+            const int grp_n = is_log ? 0 : min(16, nc - (g0 & ~15));
+            if (grp_n >= 5 && (g0 & 15) == 0) {
+                const int gbase = g0;
+                const int mi = lane & 15, kq = lane >> 4;
+                const int gpar = (g0 >> 4) & 1;
+                if (tid == 0) l.misc[2 + (gpar ^ 1)] = 0;
+                const int candA = (mi < grp_n) ? l.list[gbase + mi] : -1;
+                double a[8];
+#pragma unroll
+                for (int kb = 0; kb < 8; kb++) {
+                    const int tap = 4 * kb + kq;
+                    a[kb] = (candA >= 0 && tap <= candA) ? (double)crow_base[candA * FHIP_MAX_ORDER + tap] : 0.0;
+                }
+                double inv[4];
+                int ordr[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int m = 4 * r + kq;
+                    const int cand = (m < grp_n) ? l.list[gbase + m] : 0;
+                    ordr[r] = (m < grp_n) ? cand + 1 : 0;
+                    inv[r] = __builtin_ldexp(1.0, -srow[cand]);
+                }
+                int omax = 0;
+                for (int j = 0; j < grp_n; j++) omax = max(omax, l.list[gbase + j] + 1);
+                const int kbmax = __builtin_amdgcn_readfirstlane((omax + 3) >> 2);
+                int baddr[8];
+#pragma unroll
+                for (int kb = 0; kb < 8; kb++) {
+                    const int d = mi - 1 - kq - 4 * kb;               // sample offset inside the tile, >= -32
+                    const int fd = (d + 32) / 16 - 2;                 // floor(d / 16)
+                    const int rr = d - 16 * fd;
+                    baddr[kb] = ((rr >> 2) * Img::S + fd + Img::COL0) * 4 + (rr & 3);
+                }
+                const int xaddr = ((mi >> 2) * Img::S + Img::COL0) * 4 + (mi & 3);
+                uint32_t uor = 0;
+                auto epilogue = [&](const mfma_d4 &D, int tile) {
+                    const uint32_t x = (uint32_t)l.smp[xaddr + 4 * tile];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const double z = __builtin_fma(D[r], inv[r], 6755399441055744.0);   // floor, see fir_lpc
+                        const int32_t res = (int32_t)(x - (uint32_t)__double2loint(z));
+                        uint32_t u = zigzag32(res);
+                        if (tile < 2 && 16 * tile + mi < ordr[r]) u = 0u;        // rice.c:85-94
+                        uor |= u;
+                        u += dpp_u32<0x111>(u);
+                        u += dpp_u32<0x112>(u);
+                        u += dpp_u32<0x114>(u);
+                        u += dpp_u32<0x118>(u);
+                        if (mi == 15 && 4 * r + kq < grp_n) l.leaf[(4 * r + kq) * T + tile] = u;
+                    }
+                };
+#pragma unroll 1
+                for (int tp = 0; tp < 64; tp += 2) {
+                    const int t0 = wv * 64 + tp, t1 = t0 + 1;
+                    mfma_d4 D0 = {0.0, 0.0, 0.0, 0.0}, D1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kb = 0; kb < 8; kb++) {
+                        if (kb < kbmax) {
+                            const double b0 = (double)l.smp[baddr[kb] + 4 * t0];
+                            const double b1 = (double)l.smp[baddr[kb] + 4 * t1];
+                            D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb], b0, D0, 0, 0, 0);
+                            D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb], b1, D1, 0, 0, 0);
+                        }
+                    }
+                    epilogue(D0, t0);
+                    epilogue(D1, t1);
+                }
+                // 16 folded values below 2^28 each sum inside 32 bits; otherwise the group's
+                // candidates take the VALU FIR and its 64-bit sums below
+                if (__any((uor >> 28) != 0u) && lane == 0) atomicOr(reinterpret_cast<uint32_t *>(&l.misc[2 + gpar]), 1u);
+            }
+            if (grp_n >= 5 && (g0 & 15) == 0) {
+                __syncthreads();
+                if (l.misc[2 + ((g0 >> 4) & 1)] == 0) {
+                    // a wave per candidate straight from the tile sums (no rounds for this group)
+                    for (int m = wv; m < grp_n; m += NW) {
+                        const int cand = l.list[g0 + m];
+                        const int ord = cand + 1;
+                        const uint32_t b = wave_candidate_bits<T>(
+                            l.leaf + m * T, l.sums + wv * 128, n, ord, clamp_porder(e.pmin_req, n, ord),
+                            clamp_porder(e.pmax_req, n, ord), e.obits, e.precision, lane);
+                        if (lane == 0) l.trial[cand] = b;
+                    }
+                    __syncthreads();                   // the leaves may be overwritten; bits[] is in place
+                    g0 += 16 - G;                      // (the loop adds G)
+                    continue;
+                }
+            }
+            (void)use_leaf;
+        }
         // ---- the round's rows: doubles, int16 pairs, sum |coef|, shift ----
         if (tid < G * 32) {
             const int g = tid >> 5, j = tid & 31;
@@ -2439,6 +2673,11 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             const int cshift = __builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 1]);
             const uint32_t cabs = (uint32_t)__builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 2]);
             const int ord = cand + 1;
+            unsigned long long v = 0;
+            const bool from_leaf = MF && use_leaf && l.misc[2 + ((g0 >> 4) & 1)] == 0;
+            if (from_leaf) {
+                v = l.leaf[((g0 + g) & 15) * T + tid];       // thread = tile: its finest-level sum
+            } else {
             int32_t r[C];
             FastCtx<C, T> eg = e;
             eg.l.coefd = l.coefd + g * 32;
@@ -2454,13 +2693,13 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             }
 #endif
             // rice.c:120-123 fold; partition 0 of every level starts at `ord` (rice.c:85-94)
-            unsigned long long v = 0;
             if (e.i0 < ord) {
 #pragma unroll
                 for (int o = 0; o < C; o++) v += (e.i0 + o < ord) ? 0u : zigzag32(r[o]);
             } else {
 #pragma unroll
                 for (int o = 0; o < C; o++) v += zigzag32(r[o]);
+            }
             }
             const int pmm = __builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 3]);
             const int pmin = pmm & 0xFF, pmax = pmm >> 8;
@@ -2814,22 +3053,27 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
     int fc = 0, ft = 0;
     if (!order_search_supported(p, n) || !fast_geometry(p, n, &fc, &ft)) return hipErrorInvalidValue;
     constexpr int G = 4;
-    size_t off[11];
-#define LAUNCH_SRCH(CC, TT)                                                                  \
+    size_t off[12];
+    // many candidates known up front (SEARCH, 8-LEVEL) and tiles of 16 samples: the instance
+    // whose FIRs run on the matrix pipe
+    static const bool no_mfma = getenv("FHIP_NO_MFMA") != nullptr;          // measurements only
+    const bool mf = !no_mfma && fc == 16 &&
+                    ((p.order_method == 5 && p.max_prediction_order >= 5) || p.order_method == 4);
+#define LAUNCH_SRCH(CC, TT, MM)                                                              \
     do {                                                                                     \
-        const size_t lds = srch_lds_layout<G>((size_t)SmpImg<CC, TT>::SIZE, off);            \
+        const size_t lds = srch_lds_layout<G>((size_t)SmpImg<CC, TT>::SIZE, off, MM ? TT : 0); \
         hipError_t er = hipFuncSetAttribute(                                                 \
-            reinterpret_cast<const void *>(&k_order_search<CC, TT, G>),                      \
+            reinterpret_cast<const void *>(&k_order_search<CC, TT, G, MM>),                  \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         if (er != hipSuccess) return er;                                                     \
-        hipLaunchKernelGGL((k_order_search<CC, TT, G>), dim3(nsub), dim3(TT), lds, st, p, n, \
+        hipLaunchKernelGGL((k_order_search<CC, TT, G, MM>), dim3(nsub), dim3(TT), lds, st, p, n, \
                            smp, coefs, shift, opt_order, fin, prep, narrow_ok ? 1 : 0);      \
     } while (0)
     switch (fc * 10000 + ft) {
-    case 160256: LAUNCH_SRCH(16, 256); break;
-    case 160512: LAUNCH_SRCH(16, 512); break;
-    case 161024: LAUNCH_SRCH(16, 1024); break;
-    case 80256: LAUNCH_SRCH(8, 256); break;
+    case 160256: if (mf) LAUNCH_SRCH(16, 256, true); else LAUNCH_SRCH(16, 256, false); break;
+    case 160512: if (mf) LAUNCH_SRCH(16, 512, true); else LAUNCH_SRCH(16, 512, false); break;
+    case 161024: if (mf) LAUNCH_SRCH(16, 1024, true); else LAUNCH_SRCH(16, 1024, false); break;
+    case 80256: LAUNCH_SRCH(8, 256, false); break;
     default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_SRCH

@@ -497,3 +497,27 @@ def test_orders_9_to_16_on_16bit_rows(oracle, n, order):
     for om in (flake_amd.OM_MAX, flake_amd.OM_EST):
         p = flake_amd.level_params(5, block_size=n, max_prediction_order=order, order_method=om)
         check(oracle, p, pcm, n, f"order{order} n{n} om{om}")
+
+
+@pytest.mark.parametrize("n", [4096, 8192, 16384, 2048])
+@pytest.mark.parametrize("om,mo", [(flake_amd.OM_SEARCH, 32), (flake_amd.OM_SEARCH, 9), (flake_amd.OM_8LEVEL, 32),
+                                   (flake_amd.OM_4LEVEL, 12), (flake_amd.OM_2LEVEL, 8), (flake_amd.OM_LOG, 32)])
+def test_order_search_kernel(oracle, n, om, mo):
+    """k_order_search (the LEVEL / SEARCH / LOG walks over a table of candidates) and its two
+    instances: the MFMA one (FIR of 16 candidates per matrix product, a wave per candidate from
+    the tile sums) incl. its overflow fall-back to the VALU rounds -- 32-bit noise leaves tile
+    sums above 32 bits --, and the VALU one.  Mixed batch: resonator frames, full-scale 32-bit
+    noise, a constant frame, a frame whose first tile is an impulse (warm-up masking)."""
+    for bps in (24, 32, 16):
+        p = flake_amd.level_params(5, bits_per_sample=bps, block_size=n, order_method=om,
+                                   min_prediction_order=1 if om != flake_amd.OM_8LEVEL else 3,
+                                   max_prediction_order=mo, max_partition_order=8)
+        r = np.random.RandomState(n + mo + bps)
+        full = 1 << (bps - 1)
+        pcm = flake_amd.synth_pcm(5, n, 2, bps, first_frame=7).astype(np.int64)
+        pcm[1] = r.randint(-full, full, (n, 2))                       # noise: the fall-back for 32 bits
+        pcm[2] = 1234
+        pcm[3, :16] = 0
+        pcm[3, 3] = full - 1
+        pcm[4, :, 1] = pcm[4, :, 0] >> 1
+        check(oracle, p, pcm.astype(np.int32), n, f"order search n={n} om={om} mo={mo} bps={bps}")

@@ -163,12 +163,10 @@ def cpu_baseline(params, n, budget_s, gpu_bits_per_frame=None):
         rf = 256
         smp = np.zeros((rf * params.channels, n), np.int32)
         obits = np.zeros(rf * params.channels, np.int32)
-        t0 = time.perf_counter()
         for f in range(rf):
             _, s, sf = orc.prepare_frame(params, pcm[f], n)
             smp[f * params.channels:(f + 1) * params.channels] = s
             obits[f * params.channels:(f + 1) * params.channels] = sf["obits"]
-        t_prep = time.perf_counter() - t0
         rreps = max(1, int(budget_s * 0.4 / max(dt1 * rf / frames, 1e-3)))
         tt = np.zeros(5)
         bits = 0
@@ -185,7 +183,6 @@ def cpu_baseline(params, n, budget_s, gpu_bits_per_frame=None):
             "kind": "reference functions compiled from /root/reference (oracle/_ref) + a C loop "
                     "for the FIR; feeders (prepare) excluded",
             "ns_per_sample": {k: round(float(v) / rs * 1e9, 3) for k, v in zip(names, tt)},
-            "prepare_ns_per_sample_port": round(t_prep / (rf * n * params.channels) * 1e9, 3),
             "sample": f"{rreps} x {rf} frames ({rs / 1e6:.1f} Msamples, {tt.sum():.1f} s)",
             "residual_bits_match_hip": (None if gpu_bits_per_frame is None
                                         else bool(bits == int(gpu_bits_per_frame[:rf].sum()))),
@@ -356,7 +353,17 @@ def main():
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
-            dist.init_process_group(backend=backend)
+            # gloo prints a connection banner on stdout (C++ side): stdout carries the one JSON line
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend=backend)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
 
     # ---- workload: BASELINE.json configs[1] --------------------------------
     p = flake_amd.level_params(5, channels=2, bits_per_sample=16, sample_rate=44100,
@@ -366,11 +373,15 @@ def main():
     nsub = nframes * p.channels
     slot = flake_amd.rice_slot_bytes(p, n)
 
-    # two batches of this rank's shard alternate (different frames of the same signal model):
-    # while batch i is in flight the handle is told batch i+1 is ready (fhip_prepare_ahead)
+    # default: the one resident batch of BASELINE configs[1].  With --ahead two batches of this
+    # rank's shard alternate (different frames of the same signal model): while batch i is in
+    # flight the handle is told batch i+1 is ready (fhip_prepare_ahead)
+    nbatches = 2 if args.ahead else 1
     pcms = [torch.from_numpy(flake_amd.synth_pcm(nframes, n, p.channels, p.bits_per_sample,
-                                                 first_frame=(2 * rank + k) * nframes)).to(dev)
-            for k in range(2)]
+                                                 first_frame=(nbatches * rank + k) * nframes)).to(dev)
+            for k in range(nbatches)]
+    if nbatches == 1:
+        pcms.append(pcms[0])       # BASELINE configs[1]: one resident batch of 4096 frames per GPU
     pcm = pcms[0]
     info_bytes = flake_amd.INFO_DTYPE.itemsize
     info = torch.zeros(nsub * info_bytes, dtype=torch.uint8, device=dev)
@@ -541,9 +552,8 @@ def main():
                             "estimate), synthetic resonator PCM resident in HBM",
                 "frames_per_gpu": nframes,
                 "samples_per_step": samples_per_step,
-                "batches": "two batches of this shard alternate" +
-                           ("; the next one's feeder stage is hinted ahead (fhip_prepare_ahead)"
-                            if ahead else ""),
+                "batches": ("two batches of this shard alternate; the next one's feeder stage is "
+                            "hinted ahead (fhip_prepare_ahead)") if ahead else "one resident batch",
                 "outputs": "subframe info + packed Rice residual sections"
                            + (" + int32 residual" if args.with_residual else ""),
                 "parallelism": f"frame-sharded x{world}",

@@ -27,6 +27,8 @@ struct fhip_ctx {
     int32_t *d_shift = nullptr;       // [nsub][32]
     int32_t *d_opt = nullptr;         // [nsub]
     int32_t *d_fin = nullptr;         // [nsub][FIN_STRIDE]
+    fhip_subframe_info *d_k0rec = nullptr;   // [nsub] K0's records (obits, wasted, ch_mode, row flag): K1 and
+                                             // K3 read them here, K3 copies them into the caller's info[]
     // staging for the host-pointer entry points
     int32_t *d_pcm = nullptr;
     fhip_subframe_info *d_info = nullptr;
@@ -212,10 +214,12 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
     // nobody outside asked for the int32 rows
     const bool narrow = prepared ? prepared_narrow
                                  : (!fused && !want_rows && fhip::narrow_rows_ok(p, nsub, n, lpc_path));
-    const fhip_subframe_info *k0rec = prepared ? prepared : info;
+    // K0's records never live in the caller's info[] (K3's pointers to the two do not alias)
+    fhip_subframe_info *own_rec = c->d_k0rec + sub0;
+    const fhip_subframe_info *k0rec = prepared ? prepared : own_rec;
     if (!prepared) {
         MaybeProf pr(c, prof, 0);
-        HIP_TRY(c, fhip::launch_prepare(st, p, pcm, nframes, n, smp, info, fused, narrow));
+        HIP_TRY(c, fhip::launch_prepare(st, p, pcm, nframes, n, smp, own_rec, fused, narrow));
     }
     if (lpc_path) {
         // K2 rides on K1's tail where K1 is the wave-typed kernel and the order fits registers
@@ -412,6 +416,8 @@ int fhip_create(fhip_ctx **out, int device, const fhip_params *p, int max_frames
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_shift, nsub * FHIP_MAX_ORDER * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_opt, nsub * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_fin, nsub * fhip::FIN_STRIDE * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_k0rec, nsub * sizeof(fhip_subframe_info));
+    if (e == hipSuccess) e = hipMemset(c->d_k0rec, 0, nsub * sizeof(fhip_subframe_info));
     if (e == hipSuccess) e = hipMemset(c->d_fin, 0, nsub * fhip::FIN_STRIDE * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(c->d_coefs, 0, nsub * FHIP_MAX_ORDER * FHIP_MAX_ORDER * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(c->d_shift, 0, nsub * FHIP_MAX_ORDER * sizeof(int32_t));
@@ -435,7 +441,7 @@ void fhip_destroy(fhip_ctx *c)
     if (c->pre) (void)hipStreamSynchronize(c->pre);
     drain_profile(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
-    void *bufs[] = {c->d_smp, c->d_autoc, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
+    void *bufs[] = {c->d_smp, c->d_autoc, c->d_coefs, c->d_shift, c->d_opt, c->d_fin, c->d_k0rec,
                     c->d_pcm, c->d_info, c->d_res, c->d_bits, c->d_frames, c->d_fbytes, c->d_fnum,
                     c->d_packed, c->d_offsets};
     for (void *b : bufs) if (b) (void)hipFree(b);
@@ -783,9 +789,10 @@ int fhip_encode_residual(fhip_ctx *c, const int32_t *samples, int nsub, int n,
         HIP_TRY(c, fhip::launch_lpc(c->stream, c->d_autoc, nsub, p.max_prediction_order,
                                     p.lpc_precision, p.order_method, c->d_coefs, c->d_shift, c->d_opt, c->d_fin));
     }
+    HIP_TRY(c, hipMemcpyAsync(c->d_k0rec, c->d_info, ns * sizeof(fhip_subframe_info), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, fhip::launch_encode(c->stream, p, c->d_smp, nsub, n, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
                                    c->d_info, residual ? c->d_res : nullptr,
-                                   rice_bits ? c->d_bits : nullptr, rice_slot_bytes));
+                                   rice_bits ? c->d_bits : nullptr, rice_slot_bytes, -1, 0, false, c->d_k0rec));
     HIP_TRY(c, hipMemcpyAsync(info, c->d_info, ns * sizeof(fhip_subframe_info), hipMemcpyDeviceToHost, c->stream));
     if (residual)
         HIP_TRY(c, hipMemcpyAsync(residual, c->d_res, ns * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -842,9 +849,10 @@ int fhip_calc_rice_params(fhip_ctx *c, const int32_t *residual, int nsub, int n,
     for (auto &s : seed) s.obits = bps;
     HIP_TRY(c, hipMemcpyAsync(c->d_smp, residual, ns * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_info, seed.data(), ns * sizeof(fhip_subframe_info), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_k0rec, seed.data(), ns * sizeof(fhip_subframe_info), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, fhip::launch_encode(c->stream, p, c->d_smp, nsub, n, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
                                    c->d_info, nullptr, rice_bits ? c->d_bits : nullptr,
-                                   rice_slot_bytes, pred_order, lpc ? 1 : 0));
+                                   rice_slot_bytes, pred_order, lpc ? 1 : 0, false, c->d_k0rec));
     HIP_TRY(c, hipMemcpyAsync(info, c->d_info, ns * sizeof(fhip_subframe_info), hipMemcpyDeviceToHost, c->stream));
     if (rice_bits)
         HIP_TRY(c, hipMemcpyAsync(rice_bits, c->d_bits, bits_bytes, hipMemcpyDeviceToHost, c->stream));

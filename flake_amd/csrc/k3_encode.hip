@@ -266,8 +266,8 @@ template <int C>
 __global__ __launch_bounds__(NT)
 void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
               const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
-              const int32_t *__restrict__ opt_all, fhip_subframe_info *info,
-              const fhip_subframe_info *prep,
+              const int32_t *__restrict__ opt_all, fhip_subframe_info *__restrict__ info,
+              const fhip_subframe_info *__restrict__ prep,
               int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
               int raw_order, int raw_lpc)
 {
@@ -619,8 +619,8 @@ __device__ __forceinline__ void residual_big(const EncCtx &e, const int32_t *__r
 __global__ __launch_bounds__(NT)
 void k_encode_big(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                   const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
-                  const int32_t *__restrict__ opt_all, fhip_subframe_info *info,
-                  const fhip_subframe_info *prep,
+                  const int32_t *__restrict__ opt_all, fhip_subframe_info *__restrict__ info,
+                  const fhip_subframe_info *__restrict__ prep,
                   int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
                   int raw_order, int raw_lpc)
 {
@@ -1635,7 +1635,7 @@ __global__ __launch_bounds__(T, (MODE == 2 || C >= 14) ? 4 : 5)   // VGPR cap pe
 void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ smp_all,
                    const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                    const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,
-                   fhip_subframe_info *info, const fhip_subframe_info *prep,
+                   fhip_subframe_info *__restrict__ info, const fhip_subframe_info *__restrict__ prep,
                    int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
                    int narrow_ok)
 {
@@ -2940,7 +2940,7 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
                          bool order_known)
 {
     if (nsub == 0) return hipSuccess;
-    if (!prep) prep = info;
+    if (!prep || prep == info) return hipErrorInvalidValue;      // K3 reads K0's records beside the ones it writes
     int fc = 0, ft = 0;
     static const bool force_generic = getenv("FHIP_K3_GENERIC") != nullptr;    // measurements only
     if (raw_order < 0 && !force_generic && fast_geometry(p, n, &fc, &ft)) {

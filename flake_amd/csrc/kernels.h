@@ -63,9 +63,9 @@ hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_ord
                       int precision, int omethod, int32_t *coefs, int32_t *shift,
                       int32_t *opt_order, int32_t *fin);
 
-// prep: the records K0 filled (obits, wasted, ch_mode, the 16-bit-row flag) when they are
-// not the caller's info[] (a batch prepared ahead, fhip_prepare_ahead); K3 copies K0's
-// fields from there into info[].  nullptr = info itself.
+// prep: the records K0 filled (obits, wasted, ch_mode, the 16-bit-row flag) -- the handle's
+// own buffer, never info[] itself (the kernels' pointers to the two are __restrict__); K3
+// copies K0's fields from there into info[].
 // K3: encode_residual (optimize.c:124-276) incl. the Rice search (rice.c) and,
 // when bits != NULL, the residual section of output_residual (encode.c:766-798).
 hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *smp,

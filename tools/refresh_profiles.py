@@ -3,7 +3,7 @@ usage: python tools/refresh_profiles.py TAG STATS_DIR FETCH_DIR WRITE_DIR BENCH_
 import collections, csv, glob, json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, stats, fetch, write, bench = sys.argv[1:6]
-def one(d, pat): return glob.glob(os.path.join(R, 'gpurun_out', d, '*', pat))[0]
+def one(d, pat): return max(glob.glob(os.path.join(R, 'gpurun_out', d, '*', pat)), key=os.path.getmtime)   # the newest run
 def avg(path, counter):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
@@ -13,7 +13,7 @@ shutil.copy(one(stats, '*kernel_stats.csv'), f'{R}/profiles/{tag}_kernel_stats.c
 shutil.copy(os.path.join(R, 'gpurun_out', bench), f'{R}/profiles/{tag}_bench.json')
 f = avg(one(fetch, '*counter_collection.csv'), 'FETCH_SIZE')
 w = avg(one(write, '*counter_collection.csv'), 'WRITE_SIZE')
-names = {'k_prepare': 'k_prepare_stereo', 'k_autocorr': 'k_autocorr_wt', 'k_lpc': 'k_lpc', 'k_encode': 'k_encode_pow2'}
+names = {'k_prepare': 'k_prepare_stereo', 'k_autocorr': 'k_autocorr_wt', 'k_encode': 'k_encode_pow2'}
 old = json.load(open(f'{R}/profiles/pmc_traffic.json'))
 out = {"_note": old["_note"], "_calibration": old["_calibration"], "_tag": tag}
 for short, sym in names.items():

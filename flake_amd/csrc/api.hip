@@ -422,6 +422,8 @@ int fhip_create(fhip_ctx **out, int device, const fhip_params *p, int max_frames
     if (e == hipSuccess) e = hipMemset(c->d_coefs, 0, nsub * FHIP_MAX_ORDER * FHIP_MAX_ORDER * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(c->d_shift, 0, nsub * FHIP_MAX_ORDER * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(c->d_opt, 0, nsub * sizeof(int32_t));
+    // (the fills run on the null stream; the handle's streams are non-blocking: wait for them)
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         int rc = (e == hipErrorOutOfMemory) ? FHIP_E_NOMEM : FHIP_E_HIP;
         fhip_destroy(c);
@@ -534,6 +536,9 @@ int fhip_prepare_ahead(fhip_ctx *c, const fhip_batch *b)
             HIP_TRY(c, hipMalloc((void **)&c->d_prep[h], cap * sizeof(fhip_subframe_info)));
             HIP_TRY(c, hipMemset(c->d_prep[h], 0, cap * sizeof(fhip_subframe_info)));
         }
+        // hipMemset runs on the null stream, which does not order with this handle's
+        // non-blocking streams: finish the fills before any kernel may write these buffers
+        HIP_TRY(c, hipDeviceSynchronize());
     }
     if (c->ahead.valid) {          // a second hint without an encode in between: the first one is dropped
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_prep[c->ahead.buf], 0));

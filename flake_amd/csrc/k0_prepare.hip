@@ -204,6 +204,83 @@ void k_prepare_multi(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
     }
 }
 
+// K0 for 1, 3 .. 8 channels with the frame in REGISTERS (round 2): k_prepare_multi above reads
+// the interleaved block twice (the OR pass, then the shift-and-write pass) through an LDS
+// transpose tile; here thread t owns the sample-frame quads 4(t + RT*m) .. +3 -- 4*NCH
+// consecutive ints, i.e. NCH 16-byte loads per quad -- keeps them through the OR reduction
+// (remove_wasted_bits, encode.c:558-593: no decorrelation without exactly two channels,
+// encode.c:660-663) and the shift, and stores four consecutive samples of one channel at a time
+// (16 bytes).  One read of the PCM, no LDS beyond the cross-wave OR.  n % 4 == 0 and
+// n <= 4 * RT * M.
+constexpr int RT = 1024;       // threads per frame
+template <int NCH, int M>
+__global__ __launch_bounds__(RT)
+void k_prepare_multi_reg(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
+                         fhip_subframe_info *__restrict__ info, int n, int bps)
+{
+    __shared__ uint32_t s_orr[RT / 64][8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = blockIdx.x;
+    const int quads = n >> 2;
+    const int32_t *src = pcm + (size_t)f * n * NCH;
+    int32_t v[M][4 * NCH];                 // v[m][4*NCH]: element e = sample-frame (e / NCH), channel (e % NCH)
+    uint32_t orv[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) orv[c] = 0;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const int q = tid + RT * m;
+        if (q < quads) {
+            const int4 *p4 = reinterpret_cast<const int4 *>(src + (size_t)q * 4 * NCH);   // 16 * NCH bytes: aligned
+#pragma unroll
+            for (int k = 0; k < NCH; k++) {
+                const int4 t4 = p4[k];
+                v[m][4 * k] = t4.x; v[m][4 * k + 1] = t4.y; v[m][4 * k + 2] = t4.z; v[m][4 * k + 3] = t4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4 * NCH; e++) orv[e % NCH] |= (uint32_t)v[m][e];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const uint32_t o = wave_or_u32(orv[c]);
+        if (lane == 0) s_orr[wv][c] = o;
+    }
+    __syncthreads();
+    int wasted[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int w = 0; w < RT / 64; w++) o |= s_orr[w][c];
+        int w = o ? min(__ffs((int)o) - 1, bps - 1) : bps - 1;
+        if (w == bps - 1) w = 0;                                   // encode.c:583-584
+        wasted[c] = w;
+    }
+    if (tid < NCH) {
+        fhip_subframe_info *oi = &info[(size_t)f * NCH + tid];
+        int w = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) if (c == tid) w = wasted[c];
+        oi->obits = bps - w;
+        oi->wasted = w;
+        oi->ch_mode = FHIP_CH_NOT_STEREO;
+        oi->reserved = 0;
+    }
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const int q = tid + RT * m;
+        if (q < quads) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int4 o4 = make_int4(v[m][c] >> wasted[c], v[m][NCH + c] >> wasted[c],
+                                          v[m][2 * NCH + c] >> wasted[c], v[m][3 * NCH + c] >> wasted[c]);
+                *reinterpret_cast<int4 *>(smp + ((size_t)f * NCH + c) * n + 4 * q) = o4;
+            }
+        }
+    }
+}
+
 // K0 fast path for stereo frames with n % 4 == 0 and n <= 8192: the frame never
 // touches LDS.  Thread t owns the sample-frame quads 4(t + 256m) .. +3,
 // m < M: two 16-byte loads per quad (coalesced 32 B per lane), both channels
@@ -451,6 +528,24 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
     }
     if (decide_only || allow_narrow) return hipErrorInvalidValue;
     if (nch != 2) {
+        static const bool two_pass = getenv("FHIP_K0_MULTI_TWO_PASS") != nullptr;      // measurements only
+        if (!two_pass && (n & 3) == 0 && n <= 8192 && n >= 256) {
+            // the frame in registers: one read of the PCM
+#define LAUNCH_MR(C_, M_) hipLaunchKernelGGL((k_prepare_multi_reg<C_, M_>), dim3(nframes), dim3(RT), 0, st, pcm, smp, info, n, p.bits_per_sample)
+#define LAUNCH_MRC(C_) do { if (n <= 4 * RT) LAUNCH_MR(C_, 1); else LAUNCH_MR(C_, 2); } while (0)
+            switch (nch) {
+            case 1: LAUNCH_MRC(1); break;
+            case 3: LAUNCH_MRC(3); break;
+            case 4: LAUNCH_MRC(4); break;
+            case 5: LAUNCH_MRC(5); break;
+            case 6: LAUNCH_MRC(6); break;
+            case 7: LAUNCH_MRC(7); break;
+            default: LAUNCH_MRC(8); break;
+            }
+#undef LAUNCH_MRC
+#undef LAUNCH_MR
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL(k_prepare_multi, dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, nch,
                            p.bits_per_sample);
         return hipGetLastError();

@@ -344,26 +344,41 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1: go through the collective path (RCCL init, all-reduce, barrier,
+    # all-gather on this rank's stream) even with one rank -- what a one-GPU box can rehearse
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST", "") == "1"
+    if use_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
+        if "MASTER_ADDR" not in os.environ:            # forced single-rank rehearsal without a launcher
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]),
+                              RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+            sk.close()
         # "nccl" is RCCL on ROCm.  With fewer GPUs than ranks (a rehearsal of the N > 1
         # path on a one-GPU box) ranks share a card, which RCCL refuses: gloo then.
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl" if ndev >= world else "gloo")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            # gloo prints a connection banner on stdout (C++ side): stdout carries the one JSON line
-            sys.stdout.flush()
-            saved_fd = os.dup(1)
-            os.dup2(2, 1)
-            try:
+        # RCCL and gloo both print a banner on stdout from their C++ side when the first
+        # communicator comes up; stdout carries the one JSON line, so it points at stderr meanwhile
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=dev)
+                warm = torch.zeros(1, dtype=torch.int64, device=dev)
+            else:
                 dist.init_process_group(backend=backend)
-                dist.barrier()
-            finally:
-                sys.stdout.flush()
-                os.dup2(saved_fd, 1)
-                os.close(saved_fd)
+                warm = torch.zeros(1, dtype=torch.int64)
+            dist.all_reduce(warm)                      # brings the communicator up
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     # ---- workload: BASELINE.json configs[1] --------------------------------
     p = flake_amd.level_params(5, channels=2, bits_per_sample=16, sample_rate=44100,
@@ -397,7 +412,7 @@ def main():
     torch.cuda.set_stream(stream)
     enc.set_stream(stream.cuda_stream)
     # gloo reduces host tensors; RCCL device tensors
-    cdev = dev if (world == 1 or backend == "nccl") else torch.device("cpu")
+    cdev = dev if (not use_dist or backend == "nccl") else torch.device("cpu")
     stats = torch.zeros(3, dtype=torch.int64, device=cdev)
 
     ahead = args.ahead
@@ -428,11 +443,11 @@ def main():
         stats[0] = nframes * steps
         stats[1] = batch_bits[last] * ((steps + 1) // 2) + batch_bits[last ^ 1] * (steps // 2)
         stats[2] = 1                                   # ranks_seen
-        if world > 1:
+        if use_dist:
             dist.all_reduce(stats)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -456,7 +471,7 @@ def main():
     job_stats(args.steps)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -528,7 +543,7 @@ def main():
             except Exception as e:                      # a reported extra, never fatal
                 host = {"error": repr(e)}
 
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize(dev)
         dist.barrier()
 
@@ -567,11 +582,11 @@ def main():
         out["job_residual_bits"] = int(stats[1].item())
         out["ranks_seen"] = int(stats[2].item())
         out["rank_frames"] = [rank_frames.get(r, 0) for r in range(world)]
-        out["dist_backend"] = backend if world > 1 else None
+        out["dist_backend"] = backend if use_dist else None
         print(json.dumps(out), flush=True)
 
     enc.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -102,10 +102,30 @@ def test_bench_launches_its_own_ranks():
                         "--profile-steps", "0", "--no-cpu-baseline", "--no-other-configs"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]      # nothing but the JSON line
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2
     assert out["rank_frames"] == [256 * 5, 256 * 5] and out["job_frames"] == 2 * 256 * 5
     assert out["config"]["samples_per_step"] == 2 * 256 * 4096 * 2
     assert out["value"] > 0 and out["scaling"] == "weak"
+
+
+def test_bench_rccl_path_with_one_rank():
+    """The collective path of bench.py over RCCL (init with device_id, all-reduce, barrier,
+    all-gather on this rank's stream) -- what a one-GPU box can rehearse of the N-GPU run --
+    and stdout carrying nothing but the one JSON line (RCCL prints a banner on stdout)."""
+    env = dict(os.environ, BENCH_FORCE_DIST="1", BENCH_DIST_BACKEND="nccl",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1",
+                        "--steps", "5", "--warmup", "2", "--settle-ms", "1", "--frames", "256",
+                        "--profile-steps", "0", "--no-cpu-baseline", "--no-other-configs"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["dist_backend"] == "nccl" and out["ranks_seen"] == 1 and out["n_gpus"] == 1
+    assert out["job_frames"] == 256 * 5

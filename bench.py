@@ -512,17 +512,25 @@ def main():
         if per:                          # empty with --profile-steps 0 (the PMC passes)
             dom = max(per, key=per.get)
             achieved = alg_bytes / (per[dom] * 1e-3) / 1e9
+            # HBM bytes per launch of that kernel: rocprofv3 --pmc passes (FETCH_SIZE and
+            # WRITE_SIZE, separate runs of this bench; tools/prof_round.sh) summarised into
+            # profiles/pmc_traffic.json -- counters cannot be read from inside this process, so the
+            # figure belongs to the code state named in traffic_source, not to this run
             traffic = None
+            traffic_source = None
             tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tp):
                 try:
-                    traffic = json.load(open(tp)).get(dom, {}).get("hbm_bytes_per_launch")
+                    tj = json.load(open(tp))
+                    traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
+                    traffic_source = f"profiles/pmc_traffic.json, tag {tj.get('_tag')}"
                 except Exception:
                     traffic = None
             roofline = {
                 "bound": "hbm", "kernel": dom,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": {k: round(v, 4) for k, v in per.items()},
                 # with the next batch's k_prepare hinted ahead it runs on a stream of its own

@@ -2536,7 +2536,6 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             if (ng == 0) break;
         }
         const int par = round & 1;
-        bool use_leaf = false;
         if constexpr (MF) {
             // ---- a group of 16 candidates: their FIRs as one matrix product per tile ----
             // pred[m][i] = sum_j coef[m][j] x[i-1-j] for 16 candidate rows m and the 16 samples i
@@ -2638,7 +2637,6 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                     continue;
                 }
             }
-            (void)use_leaf;
         }
         // ---- the round's rows: doubles, int16 pairs, sum |coef|, shift ----
         if (tid < G * 32) {
@@ -2674,10 +2672,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             const uint32_t cabs = (uint32_t)__builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 2]);
             const int ord = cand + 1;
             unsigned long long v = 0;
-            const bool from_leaf = MF && use_leaf && l.misc[2 + ((g0 >> 4) & 1)] == 0;
-            if (from_leaf) {
-                v = l.leaf[((g0 + g) & 15) * T + tid];       // thread = tile: its finest-level sum
-            } else {
+            {
             int32_t r[C];
             FastCtx<C, T> eg = e;
             eg.l.coefd = l.coefd + g * 32;

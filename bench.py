@@ -291,6 +291,36 @@ def host_path(nframes=4096, n=4096):
             enc.close()
             res[key] = round(best * 1e3, 3)
         res["Msamples_per_s_md5_off"] = round(res["samples"] / res["ms_md5_off"] / 1e3, 1)
+        # BASELINE configs[4] territory: variable block size (vbs.c) + order / partition search,
+        # through the same host entry: split, gather of the pieces, one pass of the path per piece
+        # length and the packing of the frames all stay on the device
+        os.environ["FLAKE_AMD_MD5"] = "0"
+        vbs = {}
+        for level in (10, 12):
+            nblk = 1024
+            os.environ["FLAKE_AMD_BATCH"] = str(nblk)
+            enc = flake_amd.HostEncoder(level=level, channels=2, bits_per_sample=16, sample_rate=44100)
+            bs = enc.params().block_size
+            vp = flake_amd.synth_pcm(nblk, bs, 2, 16)
+            vp[::3, bs // 2:, :] //= 16                  # a transient in every third block: something to split
+            vflat = np.ascontiguousarray(vp, dtype=np.int32).reshape(-1, 2)
+            vcap = 64 + vp.size * 5 + 64 * (nblk + 1) * 8
+            vout = np.ones(vcap, dtype=np.uint8)
+            vsizes = np.zeros(nblk, dtype=np.int32)
+            best = None
+            for call in range(3):
+                t0 = time.perf_counter()
+                w = enc.lib.flake_amd_encode_frames(C.byref(enc.ctx), vflat.ctypes.data, nblk, bs, 0,
+                                                    vout.ctypes.data, vcap, vsizes.ctypes.data)
+                dt = time.perf_counter() - t0
+                if w <= 0:
+                    raise RuntimeError("flake_amd_encode_frames (vbs) failed")
+                if call:
+                    best = dt if best is None else min(best, dt)
+            enc.close()
+            vbs[f"level{level}"] = {"blocks": nblk, "block_size": bs, "ms": round(best * 1e3, 3),
+                                    "Msamples_per_s": round(nblk * bs * 2 / best / 1e6, 1)}
+        res["vbs_presets_md5_off"] = vbs
         res["note"] = ("pageable host memory in and out; copies over PCIe, kernels and frame packing "
                        "overlap across two handles; MD5 (sequential over the stream) on a helper thread")
     finally:

@@ -155,6 +155,8 @@ def load_library() -> C.CDLL:
         "fhip_encode_frames_packed": (i, [vp, C.POINTER(Batch), vp, i64, C.POINTER(i64)]),
         "fhip_frames_packed_begin": (i, [vp, C.POINTER(Batch), C.POINTER(i64)]),
         "fhip_frames_packed_fetch": (i, [vp, vp, i64]),
+        "fhip_encode_blocks_vbs_packed": (i, [vp, vp, i, i, C.c_uint32, vp, i64, vp, vp, C.POINTER(i64),
+                                              C.POINTER(i), C.POINTER(C.c_uint32)]),
         "fhip_lpc_calc_coefs": (i, [vp, vp, i, i, i, i, i, vp, vp, vp, vp]),
         "fhip_encode_residual": (i, [vp, vp, i, i, vp, vp, vp, i64]),
         "fhip_prepare_frames": (i, [vp, vp, i, i, vp, vp]),
@@ -178,7 +180,7 @@ ABI_SYMBOLS = (
     "fhip_encode_subframes", "fhip_lpc_calc_coefs", "fhip_encode_residual",
     "fhip_prepare_frames", "fhip_calc_rice_params", "fhip_vbs_split", "fhip_set_profiling",
     "fhip_get_kernel_times", "fhip_prepare_ahead", "fhip_encode_frames_packed",
-    "fhip_frames_packed_begin", "fhip_frames_packed_fetch",
+    "fhip_frames_packed_begin", "fhip_frames_packed_fetch", "fhip_encode_blocks_vbs_packed",
 )
 
 

@@ -43,6 +43,10 @@ struct fhip_ctx {
     size_t d_packed_bytes = 0;
     long long *d_offsets = nullptr;   // [max_frames + 1]
     long long packed_ready = 0;       // bytes waiting in d_packed between _begin and _fetch
+    // fhip_encode_blocks_vbs_packed: group-contiguous copy of the pieces and the piece tables
+    int32_t *d_gather = nullptr;
+    long long *d_gsrc = nullptr, *d_gdst = nullptr, *d_srcoff = nullptr;
+    int32_t *d_glen = nullptr, *d_order = nullptr;
 
     // two internal streams for the split-batch overlap (run_pipeline)
     hipStream_t aux[2] = {nullptr, nullptr};
@@ -445,7 +449,8 @@ void fhip_destroy(fhip_ctx *c)
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     void *bufs[] = {c->d_smp, c->d_autoc, c->d_coefs, c->d_shift, c->d_opt, c->d_fin, c->d_k0rec,
                     c->d_pcm, c->d_info, c->d_res, c->d_bits, c->d_frames, c->d_fbytes, c->d_fnum,
-                    c->d_packed, c->d_offsets};
+                    c->d_packed, c->d_offsets, c->d_gather, c->d_gsrc, c->d_gdst, c->d_srcoff,
+                    c->d_glen, c->d_order};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int h = 0; h < 2; h++) {
         if (c->aux[h]) { (void)hipStreamSynchronize(c->aux[h]); (void)hipStreamDestroy(c->aux[h]); }
@@ -717,6 +722,156 @@ int fhip_encode_frames_packed(fhip_ctx *c, const fhip_batch *b, uint8_t *out, in
     if (rc != FHIP_OK) return rc;
     rc = fhip_frames_packed_fetch(c, out, out_cap);
     if (rc != FHIP_OK) return rc;
+    *out_bytes = total;
+    return FHIP_OK;
+}
+
+int fhip_encode_blocks_vbs_packed(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size,
+                                  uint32_t first_frame_number, uint8_t *out, int64_t out_cap,
+                                  int32_t *block_bytes, int32_t *block_frames, int64_t *out_bytes,
+                                  int32_t *max_frame_bytes, uint32_t *next_frame_number)
+{
+    if (!c || !pcm || !out || !out_bytes || !block_bytes) return fail(c, FHIP_E_INVALID, "null argument");
+    const fhip_params &p = c->p;
+    if (!p.variable_block_size || !p.allow_vbs)
+        return fail(c, FHIP_E_INVALID, "the handle's parameters have no variable block size");
+    if (block_size > p.block_size || block_size < 128 || (block_size % 8))
+        return fail(c, FHIP_E_INVALID, "vbs needs block_size % 8 == 0 and >= 128 (vbs.c:93)");
+    if (nblocks < 0 || (long long)nblocks * 8 > c->max_frames)
+        return fail(c, FHIP_E_INVALID, "nblocks * 8 exceeds the handle's max_frames");
+    *out_bytes = 0;
+    if (max_frame_bytes) *max_frame_bytes = 0;
+    if (next_frame_number) *next_frame_number = first_frame_number;
+    if (nblocks == 0) return FHIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nch = (size_t)p.channels;
+    const size_t cap_sub = (size_t)c->max_frames * nch;
+    int rc = ensure_staging(c, 0);
+    if (rc != FHIP_OK) return rc;
+    const size_t np_max = (size_t)c->max_frames;
+    if (!c->d_gather) HIP_TRY(c, hipMalloc((void **)&c->d_gather, cap_sub * (size_t)p.block_size * sizeof(int32_t)));
+    if (!c->d_gsrc) HIP_TRY(c, hipMalloc((void **)&c->d_gsrc, np_max * sizeof(long long)));
+    if (!c->d_gdst) HIP_TRY(c, hipMalloc((void **)&c->d_gdst, np_max * sizeof(long long)));
+    if (!c->d_srcoff) HIP_TRY(c, hipMalloc((void **)&c->d_srcoff, np_max * sizeof(long long)));
+    if (!c->d_glen) HIP_TRY(c, hipMalloc((void **)&c->d_glen, np_max * sizeof(int32_t)));
+    if (!c->d_order) HIP_TRY(c, hipMalloc((void **)&c->d_order, np_max * sizeof(int32_t)));
+    if (!c->d_fbytes) HIP_TRY(c, hipMalloc((void **)&c->d_fbytes, np_max * sizeof(int32_t)));
+    if (!c->d_fnum) HIP_TRY(c, hipMalloc((void **)&c->d_fnum, np_max * sizeof(uint32_t)));
+    if (!c->d_offsets) HIP_TRY(c, hipMalloc((void **)&c->d_offsets, (np_max + 1) * sizeof(long long)));
+
+    // ---- the blocks to the device, split_frame_v1 (vbs.c:36-83) there, its verdicts back ----
+    const size_t nvals = (size_t)nblocks * block_size * nch;
+    HIP_TRY(c, hipMemcpyAsync(c->d_pcm, pcm, nvals * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, fhip::launch_vbs_split(c->stream, c->d_pcm, nblocks, block_size, p.channels, c->d_opt, c->d_shift));
+    std::vector<int32_t> nf((size_t)nblocks), sz((size_t)nblocks * 8);
+    HIP_TRY(c, hipMemcpyAsync(nf.data(), c->d_opt, nf.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(sz.data(), c->d_shift, sz.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+
+    // ---- pieces in stream order; groups of equal length in order of first appearance ----
+    struct Piece { int block, n, group, k; long long pos; };
+    std::vector<Piece> pieces;
+    struct Group { int n, cnt; long long goff, fr_off, b_off; int slot0; int64_t stride, slot; };
+    std::vector<Group> groups;
+    pieces.reserve((size_t)nblocks * 2);
+    for (int b = 0; b < nblocks; b++) {
+        int f = nf[(size_t)b];
+        int one[1] = {block_size};
+        const int32_t *sizes = &sz[(size_t)b * 8];
+        if (f <= 1) { f = 1; sizes = one; }                          // vbs.c:100, encode.c:1001
+        long long pos = (long long)b * block_size;
+        for (int q = 0; q < f; q++) {
+            const int n = sizes[q];
+            if (n < 1 || n > block_size) return fail(c, FHIP_E_GENERIC, "bad piece size from the splitter");
+            int g = -1;
+            for (size_t j = 0; j < groups.size(); j++) if (groups[j].n == n) { g = (int)j; break; }
+            if (g < 0) { groups.push_back(Group{n, 0, 0, 0, 0, 0, 0, 0}); g = (int)groups.size() - 1; }
+            pieces.push_back(Piece{b, n, g, groups[(size_t)g].cnt++, pos});
+            pos += n;
+        }
+    }
+    const int np = (int)pieces.size();
+    long long goff = 0, fr_off = 0, b_off = 0;
+    int slot0 = 0;
+    for (auto &g : groups) {
+        g.stride = fhip_frame_stride(&p, g.n);
+        g.slot = (g.stride + 3) & ~(int64_t)3;
+        g.goff = goff; g.fr_off = fr_off; g.b_off = b_off; g.slot0 = slot0;
+        goff += (long long)g.cnt * g.n * (long long)nch;
+        fr_off += (long long)g.cnt * g.stride;
+        b_off += (long long)g.cnt * (long long)nch * g.slot;
+        slot0 += g.cnt;
+    }
+    if ((size_t)b_off > c->d_bits_bytes) {
+        if (c->d_bits) (void)hipFree(c->d_bits);
+        c->d_bits = nullptr; c->d_bits_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_bits, (size_t)b_off));
+        c->d_bits_bytes = (size_t)b_off;
+    }
+    if ((size_t)fr_off > c->d_frames_bytes) {
+        if (c->d_frames) (void)hipFree(c->d_frames);
+        c->d_frames = nullptr; c->d_frames_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_frames, (size_t)fr_off));
+        c->d_frames_bytes = (size_t)fr_off;
+    }
+    if ((size_t)fr_off > c->d_packed_bytes) {
+        if (c->d_packed) (void)hipFree(c->d_packed);
+        c->d_packed = nullptr; c->d_packed_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_packed, (size_t)fr_off));
+        c->d_packed_bytes = (size_t)fr_off;
+    }
+    std::vector<long long> gsrc((size_t)np), gdst((size_t)np), srcoff((size_t)np);
+    std::vector<int32_t> glen((size_t)np), order((size_t)np);
+    std::vector<uint32_t> fnum((size_t)np);
+    for (int i = 0; i < np; i++) {
+        const Piece &pc = pieces[(size_t)i];
+        const Group &g = groups[(size_t)pc.group];
+        const int slot = g.slot0 + pc.k;
+        gsrc[(size_t)i] = pc.pos * (long long)nch;
+        gdst[(size_t)i] = g.goff + (long long)pc.k * g.n * (long long)nch;
+        glen[(size_t)i] = pc.n * (int)nch;
+        order[(size_t)i] = slot;
+        srcoff[(size_t)slot] = g.fr_off + (long long)pc.k * g.stride;
+        // allow_vbs: a frame carries its first sample's number (encode.c:969-975)
+        fnum[(size_t)slot] = first_frame_number + (uint32_t)pc.pos;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_gsrc, gsrc.data(), (size_t)np * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_gdst, gdst.data(), (size_t)np * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_glen, glen.data(), (size_t)np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_order, order.data(), (size_t)np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_srcoff, srcoff.data(), (size_t)np * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_fnum, fnum.data(), (size_t)np * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, fhip::launch_gather_pieces(c->stream, c->d_pcm, c->d_gsrc, c->d_gdst, c->d_glen, np, c->d_gather));
+
+    // ---- one pass of the path per group, all on the device ----
+    for (const auto &g : groups) {
+        const FrameOut fo{c->d_frames + g.fr_off, g.stride, c->d_fbytes + g.slot0, 0, c->d_fnum + g.slot0};
+        rc = run_pipeline(c, c->d_gather + g.goff, g.cnt, g.n, c->d_info + (size_t)g.slot0 * nch, nullptr,
+                          c->d_bits + g.b_off, g.slot, nullptr, nullptr, fo, false);
+        if (rc != FHIP_OK) return rc;
+    }
+    HIP_TRY(c, fhip::launch_pack_frames_perm(c->stream, c->d_frames, c->d_srcoff, c->d_fbytes, c->d_order, np,
+                                             c->d_offsets, c->d_packed));
+    std::vector<int32_t> fb((size_t)np);
+    long long total = 0;
+    HIP_TRY(c, hipMemcpyAsync(fb.data(), c->d_fbytes, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&total, c->d_offsets + np, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    rc = fhip_sync(c);
+    if (rc != FHIP_OK) return rc;
+    if (total > out_cap) return fail(c, FHIP_E_INVALID, "output buffer too small for the batch's frames");
+    HIP_TRY(c, hipMemcpy(out, c->d_packed, (size_t)total, hipMemcpyDeviceToHost));
+
+    int32_t mx = 0;
+    for (int b = 0; b < nblocks; b++) { block_bytes[b] = 0; if (block_frames) block_frames[b] = 0; }
+    for (int i = 0; i < np; i++) {
+        const int32_t bytes = fb[(size_t)order[(size_t)i]];
+        if (bytes <= 0) return fail(c, FHIP_E_GENERIC, "a frame of the batch was not encoded");
+        block_bytes[pieces[(size_t)i].block] += bytes;
+        if (block_frames) block_frames[pieces[(size_t)i].block] += 1;
+        if (bytes > mx) mx = bytes;
+    }
+    if (max_frame_bytes) *max_frame_bytes = mx;
+    if (next_frame_number) *next_frame_number = first_frame_number + (uint32_t)((long long)nblocks * block_size);
     *out_bytes = total;
     return FHIP_OK;
 }

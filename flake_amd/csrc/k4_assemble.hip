@@ -469,7 +469,91 @@ void k_pack_frames(const uint8_t *__restrict__ frames, long long stride, const i
     if (tid < len - done) dst[done + tid] = src[done + tid];
 }
 
+// Ragged (VBS) batches, device-resident: pieces of one block-size group gathered into one
+// contiguous [nframes][n][ch] array (one workgroup per piece, 16-byte copies: every piece is a
+// multiple of block_size / 8 >= 16 sample-frames), and the frames of all groups packed in stream
+// order -- order[i] = slot of the i-th frame of the stream, src_off[slot] = where that slot's
+// frame lies.
+__global__ __launch_bounds__(NT)
+void k_gather_pieces(const int32_t *__restrict__ pcm, const long long *__restrict__ src,
+                     const long long *__restrict__ dst, const int32_t *__restrict__ len,
+                     int32_t *__restrict__ out)
+{
+    const int i = blockIdx.x;
+    const int4 *s4 = reinterpret_cast<const int4 *>(pcm + src[i]);
+    int4 *d4 = reinterpret_cast<int4 *>(out + dst[i]);
+    const int n4 = len[i] >> 2;
+    for (int q = threadIdx.x; q < n4; q += NT) d4[q] = s4[q];
+}
+
+__global__ __launch_bounds__(SCAN_NT)
+void k_frame_offsets_perm(const int32_t *__restrict__ fbytes, const int32_t *__restrict__ order,
+                          int nframes, long long *__restrict__ offsets)
+{
+    __shared__ long long s_part[SCAN_NT];
+    const int tid = threadIdx.x;
+    const int per = (nframes + SCAN_NT - 1) / SCAN_NT;
+    const int f0 = tid * per, f1 = min(f0 + per, nframes);
+    long long sum = 0;
+    for (int f = f0; f < f1; f++) sum += max(fbytes[order[f]], 0);
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < SCAN_NT; off <<= 1) {
+        const long long v = (tid >= off) ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    long long run = s_part[tid] - sum;
+    for (int f = f0; f < f1; f++) { offsets[f] = run; run += max(fbytes[order[f]], 0); }
+    if (tid == SCAN_NT - 1) offsets[nframes] = s_part[tid];
+}
+
+__global__ __launch_bounds__(NT)
+void k_pack_frames_perm(const uint8_t *__restrict__ frames, const long long *__restrict__ src_off,
+                        const int32_t *__restrict__ fbytes, const int32_t *__restrict__ order,
+                        const long long *__restrict__ offsets, uint8_t *__restrict__ packed)
+{
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int slot = order[f];
+    const int len = max(fbytes[slot], 0);
+    const uint8_t *src = frames + src_off[slot];                   // 4-byte aligned
+    uint8_t *dst = packed + offsets[f];
+    const int head = min((int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3), len);
+    if (tid < head) dst[tid] = src[tid];
+    const int ndw = (len - head) >> 2;
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst + head);
+    const int sh = head & 3;
+    for (int j = tid; j < ndw; j += NT) {
+        const uint32_t lo = s32[j + (head >> 2)];
+        const uint32_t hi = sh ? s32[j + (head >> 2) + 1] : 0u;
+        d32[j] = __builtin_amdgcn_alignbyte(hi, lo, sh);
+    }
+    const int done = head + 4 * ndw;
+    if (tid < len - done) dst[done + tid] = src[done + tid];
+}
+
 }  // namespace
+
+hipError_t launch_gather_pieces(hipStream_t st, const int32_t *pcm, const long long *src,
+                                const long long *dst, const int32_t *len, int npieces, int32_t *out)
+{
+    if (npieces == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_pieces, dim3(npieces), dim3(NT), 0, st, pcm, src, dst, len, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_frames_perm(hipStream_t st, const uint8_t *frames, const long long *src_off,
+                                   const int32_t *frame_bytes, const int32_t *order, int nframes,
+                                   long long *offsets, uint8_t *packed)
+{
+    if (nframes == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_frame_offsets_perm, dim3(1), dim3(SCAN_NT), 0, st, frame_bytes, order, nframes, offsets);
+    hipLaunchKernelGGL(k_pack_frames_perm, dim3(nframes), dim3(NT), 0, st, frames, src_off, frame_bytes,
+                       order, offsets, packed);
+    return hipGetLastError();
+}
 
 hipError_t launch_pack_frames(hipStream_t st, const uint8_t *frames, int64_t frame_stride,
                               const int32_t *frame_bytes, int nframes, long long *offsets,

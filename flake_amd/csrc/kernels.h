@@ -100,6 +100,16 @@ hipError_t launch_pack_frames(hipStream_t st, const uint8_t *frames, int64_t fra
                               const int32_t *frame_bytes, int nframes, long long *offsets,
                               uint8_t *packed);
 
+// Ragged (VBS) batches on the device: pieces copied into group-contiguous arrays (src / dst in
+// int32 units, len = ints per piece, a multiple of 4), and the frames of all groups packed in
+// stream order (order[i] = slot of the stream's i-th frame, src_off[slot] = byte offset of that
+// slot's frame in frames[], 4-byte aligned).
+hipError_t launch_gather_pieces(hipStream_t st, const int32_t *pcm, const long long *src,
+                                const long long *dst, const int32_t *len, int npieces, int32_t *out);
+hipError_t launch_pack_frames_perm(hipStream_t st, const uint8_t *frames, const long long *src_off,
+                                   const int32_t *frame_bytes, const int32_t *order, int nframes,
+                                   long long *offsets, uint8_t *packed);
+
 // K-vbs: split_frame_v1 (vbs.c:36-83) for nblocks blocks: nframes_out [nblocks],
 // sizes_out [nblocks][8].
 hipError_t launch_vbs_split(hipStream_t st, const int32_t *pcm, int nblocks, int block_size,

@@ -44,6 +44,8 @@ typedef struct host_ctx {
     int last_frame;
     int host_assembly;                    /* FLAKE_AMD_HOST_ASSEMBLY=1: build frames on the CPU */
     int host_vbs;                         /* FLAKE_AMD_HOST_VBS=1: split blocks on the CPU */
+    int vbs_host_gather;                  /* FLAKE_AMD_VBS_HOST_GATHER=1: the round-1 VBS path (pieces gathered
+                                             on the host, one upload / download per piece length) */
     int md5_off;                          /* FLAKE_AMD_MD5=0: STREAMINFO carries the all-zero "not computed" MD5 */
     int trace;                            /* FLAKE_AMD_TRACE=1: phase times of every batch on stderr */
     /* FLAKE_AMD_LOOKAHEAD=N: flake_encode_frame() queues up to N whole blocks and
@@ -368,6 +370,7 @@ FLAKE_AMD_API int flake_amd_encode_init(FlakeAmdContext *s)
     const char *eh = getenv("FLAKE_AMD_HOST_ASSEMBLY");
     c->host_assembly = eh && eh[0] == '1';
     { const char *ev = getenv("FLAKE_AMD_HOST_VBS"); c->host_vbs = ev && ev[0] == '1'; }
+    { const char *ev = getenv("FLAKE_AMD_VBS_HOST_GATHER"); c->vbs_host_gather = ev && ev[0] == '1'; }
     { const char *ev = getenv("FLAKE_AMD_MD5"); c->md5_off = ev && ev[0] == '0'; }
     { const char *ev = getenv("FLAKE_AMD_TRACE"); c->trace = ev && ev[0] == '1'; }
     c->max_batch = eb ? atoi(eb) : 1024;
@@ -745,6 +748,34 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
     int32_t *dev_nf = NULL, *dev_sizes = NULL;
     double t_begin = now_ms(), t_split = 0, t_gather = 0, t_gpu = 0, t_out = 0;
     int ngroups = 0;
+    if (vbs && !c->host_vbs && !c->host_assembly && !c->vbs_host_gather) {
+        /* the whole variable-block-size batch on the device: split, gather of the pieces, one pass
+         * of the path per piece length, frames packed in stream order, one download */
+        int64_t wrote = 0;
+        int32_t mx = 0;
+        uint32_t next = c->frame_count;
+        const int rc = fhip_encode_blocks_vbs_packed(c->hip, pcm, count, block_size, c->frame_count, out,
+                                                     (int64_t)cap, frame_sizes ? frame_sizes : c->fbytes, NULL,
+                                                     &wrote, &mx, &next);
+        free(pieces); free(scratch);
+        pieces = NULL; scratch = NULL;
+        if (rc != FHIP_OK) {
+            snprintf(c->err, sizeof c->err, "fhip_encode_blocks_vbs_packed: %s (%s)", fhip_strerror(rc),
+                     fhip_last_error(c->hip));
+            if (md5_running) pthread_join(md5_thread, NULL);
+            return -1;
+        }
+        if (mx > c->max_frame_size) c->max_frame_size = mx;        /* encode.c:967 */
+        c->frame_count = next;                                     /* encode.c:969-975 */
+        if (c->trace)
+            fprintf(stderr, "flake_amd batch: %d vbs blocks on the device, %.2f ms\n", count, now_ms() - t_begin);
+        if (!c->md5_off) {
+            if (md5_running) { pthread_join(md5_thread, NULL); md5_running = 0; }
+            else md5_worker(&job);
+            c->md5 = md5_next;
+        }
+        return (long long)wrote;
+    }
     if (vbs && !c->host_vbs) {
         /* split_frame_v1 on the device (K-vbs) for the whole batch */
         dev_nf = (int32_t *)malloc(sizeof(int32_t) * (size_t)count);

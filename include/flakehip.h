@@ -191,6 +191,22 @@ FHIP_API int fhip_encode_frames_packed(fhip_ctx *ctx, const fhip_batch *b, uint8
 FHIP_API int fhip_frames_packed_begin(fhip_ctx *ctx, const fhip_batch *b, int64_t *total_bytes);
 FHIP_API int fhip_frames_packed_fetch(fhip_ctx *ctx, uint8_t *out, int64_t out_cap);
 
+/* The same for a variable-block-size stream (encode_frame_vbs, vbs.c:85-119, per block):
+ * nblocks blocks of block_size samples in host memory -> every block split by split_frame_v1
+ * (vbs.c:36-83) on the device, the pieces encoded (one pass of the path per distinct piece
+ * length, the pieces gathered on the device), the frames packed in stream order and fetched.
+ * Frames are numbered by their first sample (encode.c:969-975: allow_vbs), starting at
+ * first_frame_number for the first sample of pcm.  block_bytes[b] = bytes of block b's frames
+ * (the return value of flake_encode_frame for that block); block_frames[b] (optional) = how many
+ * frames it became; *max_frame_bytes = the largest frame (encode.c:967); *next_frame_number =
+ * the number the next block's first frame takes.  The handle must have been created with
+ * variable_block_size and allow_vbs set and max_frames >= 8 * nblocks. */
+FHIP_API int fhip_encode_blocks_vbs_packed(fhip_ctx *ctx, const int32_t *pcm, int nblocks,
+                                           int block_size, uint32_t first_frame_number,
+                                           uint8_t *out, int64_t out_cap, int32_t *block_bytes,
+                                           int32_t *block_frames, int64_t *out_bytes,
+                                           int32_t *max_frame_bytes, uint32_t *next_frame_number);
+
 /* Optional hint for a caller that streams batch after batch through one handle
  * (flake.c:622-663 calls flake_encode_frame block after block): start the feeder
  * stage of the NEXT batch -- copy_samples + channel_decorrelation +

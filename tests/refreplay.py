@@ -464,3 +464,26 @@ def vbs_split(pcm, channels, block_size):
             sizes.append(0)
         sizes[-1] += n
     return sizes
+
+
+# ---------------------------------------------------------------------------
+# flake_encode_frame()'s block driver  encode.c:979-1008 + encode_frame_vbs vbs.c:85-119
+# ---------------------------------------------------------------------------
+def encode_block(ref, p, frame_count, pcm, block_size):
+    """One call of flake_encode_frame(): a VBS block becomes its pieces (when the splitter makes
+    more than one: vbs.c:100), each an encode_frame() with the running frame counter
+    (encode.c:969-975).  Returns (bytes, new frame_count, [piece sizes])."""
+    ch = p.channels
+    pcm = np.asarray(pcm, np.int32).reshape(block_size, ch)
+    sizes = [block_size]
+    if p.variable_block_size > 0 and block_size % 8 == 0 and block_size >= 128:      # encode.c:997-999, vbs.c:93
+        s = vbs_split(pcm, ch, block_size)
+        if len(s) > 1:
+            sizes = s
+    out, pos, fc = [], 0, frame_count
+    for n in sizes:
+        frame, _, _ = encode_frame(ref, p, fc, pcm[pos:pos + n], n)
+        out.append(frame)
+        fc += n if p.allow_vbs else 1
+        pos += n
+    return np.concatenate(out), fc, sizes

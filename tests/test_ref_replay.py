@@ -167,3 +167,29 @@ def test_vbs_split_rule(oracle):
         for i, pcm in enumerate(cases):
             nf, sizes = oracle.vbs_split(pcm, ch, bs)
             assert list(sizes) == refreplay.vbs_split(pcm, ch, bs), (ch, bs, i)
+
+
+@pytest.mark.parametrize("level", [9, 10])
+def test_vbs_block_driver(oracle, ref, level):
+    """flake_encode_frame() on variable-block-size streams (encode.c:979-1008, vbs.c:85-119): the
+    oracle's block loop against the replay's -- split rule, the pieces' frame numbers (sample
+    offsets), the single-piece fall-back to the whole block."""
+    p = flake_amd.level_params(level)
+    n = p.block_size
+    r = _rng(level)
+    blocks = [flake_amd.synth_pcm(1, n, 2, 16, first_frame=s)[0] for s in range(3)]
+    x = r.randint(-4, 5, (n, 2)).astype(np.int32)
+    x[n // 2:] = r.randint(-20000, 20000, (n - n // 2, 2))                    # splits
+    blocks.append(x)
+    y = flake_amd.synth_pcm(1, n, 2, 16, first_frame=40)[0].copy()
+    y[n // 8 * 3: n // 8 * 5] //= 64                                          # three pieces
+    blocks.append(y)
+    fc_o = fc_r = 0
+    nsplit = 0
+    for i, blk in enumerate(blocks):
+        rc, data, fc_o = oracle.encode_block(p, fc_o, blk, n, 8 * n * 2 * 4 + 4096)
+        exp, fc_r, sizes = refreplay.encode_block(ref, p, fc_r, blk, n)
+        nsplit += len(sizes) > 1
+        assert rc == len(exp) and fc_o == fc_r, (level, i, rc, len(exp), fc_o, fc_r)
+        assert (data == exp).all(), (level, i, int(np.nonzero(data != exp)[0][0]))
+    assert nsplit >= 2

@@ -603,6 +603,8 @@ int fhip_encode_subframes(fhip_ctx *c, const fhip_batch *b)
     if (nsub == 0) return FHIP_OK;
 
     double *d_autoc_out = b->autoc ? c->d_autoc : nullptr;
+    // a section that does not fit its slot leaves the slot untouched: what comes back for it is zeros
+    if (b->rice_bits) HIP_TRY(c, hipMemsetAsync(c->d_bits, 0, bits_bytes, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_pcm, b->pcm, nsub * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_info, 0, nsub * sizeof(fhip_subframe_info), c->stream));
     FrameOut fo{nullptr, 0, nullptr, 0};
@@ -949,6 +951,7 @@ int fhip_encode_residual(fhip_ctx *c, const int32_t *samples, int nsub, int n,
         HIP_TRY(c, fhip::launch_lpc(c->stream, c->d_autoc, nsub, p.max_prediction_order,
                                     p.lpc_precision, p.order_method, c->d_coefs, c->d_shift, c->d_opt, c->d_fin));
     }
+    if (rice_bits) HIP_TRY(c, hipMemsetAsync(c->d_bits, 0, bits_bytes, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_k0rec, c->d_info, ns * sizeof(fhip_subframe_info), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, fhip::launch_encode(c->stream, p, c->d_smp, nsub, n, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
                                    c->d_info, residual ? c->d_res : nullptr,
@@ -1009,6 +1012,7 @@ int fhip_calc_rice_params(fhip_ctx *c, const int32_t *residual, int nsub, int n,
     for (auto &s : seed) s.obits = bps;
     HIP_TRY(c, hipMemcpyAsync(c->d_smp, residual, ns * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_info, seed.data(), ns * sizeof(fhip_subframe_info), hipMemcpyHostToDevice, c->stream));
+    if (rice_bits) HIP_TRY(c, hipMemsetAsync(c->d_bits, 0, bits_bytes, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_k0rec, seed.data(), ns * sizeof(fhip_subframe_info), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, fhip::launch_encode(c->stream, p, c->d_smp, nsub, n, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
                                    c->d_info, nullptr, rice_bits ? c->d_bits : nullptr,

@@ -1000,14 +1000,19 @@ struct FastLds {
 // Emit window of the fast path, in words: a section of typical density fits one
 // window (n/2 words = 16 bits per sample, rounded up to a power of two); denser
 // sections take more passes.  Small blocks thus leave LDS for more workgroups.
-__host__ __device__ inline int fast_window_words(int n)
+// wide: 32 bits per sample up to 128 Kbit, for the instances that run four workgroups per CU
+// anyway (MODE 2 / 3) on samples wider than 16 bits -- a 24-bit section of ~19 bits per sample
+// then takes one pass instead of two.
+__host__ __device__ inline int fast_window_words(int n, bool wide = false)
 {
     int w = 256;
+    if (wide) { while (w < 2 * ENC_WWORDS && w < n) w <<= 1; return w; }
     while (w < ENC_WWORDS && 2 * w < n) w <<= 1;
     return w;
 }
+__host__ __device__ inline bool fast_wide_window(int mode, int bps) { return mode >= 2 && bps > 16; }
 
-__host__ __device__ inline size_t fast_lds_layout(int n, size_t img_doubles, size_t off[11])
+__host__ __device__ inline size_t fast_lds_layout(int n, size_t img_doubles, size_t off[11], bool wide = false)
 {
     size_t o = 0;
     off[0] = o; o += 8 * 512;                                   // sums
@@ -1021,7 +1026,7 @@ __host__ __device__ inline size_t fast_lds_layout(int n, size_t img_doubles, siz
     off[8] = o; o += 4 * 16;                                    // misc
     off[9] = o; o += 4 * 32;                                    // trial
     o = (o + 15) & ~(size_t)15;
-    off[10] = o; o += 4 * fast_window_words(n);                 // bits
+    off[10] = o; o += 4 * fast_window_words(n, wide);           // bits
     return o;
 }
 
@@ -1641,7 +1646,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     size_t off[12];
-    fast_lds_layout(n, SmpImg<C, T>::SIZE, off);
+    fast_lds_layout(n, SmpImg<C, T>::SIZE, off, fast_wide_window(MODE, P.bits_per_sample));
     FastCtx<C, T> e;
     e.l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
     e.l.coefd = reinterpret_cast<double *>(lds_raw + off[1]);
@@ -1756,7 +1761,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     // zeros in front: columns 0 .. COL0-1 of every row
     if (tid < SmpImg<C, T>::COL0 * C) l.smp[SmpImg<C, T>::at(tid / C, tid % C)] = 0;
     // the first emit window is cleared here, under the shadow of the loads above
-    const int wwords = fast_window_words(n);
+    const int wwords = fast_window_words(n, fast_wide_window(MODE, P.bits_per_sample));
     if (bits_out) for (int q = tid; q < wwords / 4; q += T) reinterpret_cast<uint4 *>(l.bits)[q] = make_uint4(0, 0, 0, 0);
     if (tid < 16) l.coefd[32 + tid] = 0.0;
     if (pre_row && tid < FHIP_MAX_ORDER) {
@@ -2943,7 +2948,8 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
         size_t lds = 0;
 #define LAUNCH_FAST2(CC, TT, MM)                                                             \
     do {                                                                                     \
-        lds = fast_lds_layout(n, (size_t)SmpImg<CC, TT>::SIZE, off);                         \
+        lds = fast_lds_layout(n, (size_t)SmpImg<CC, TT>::SIZE, off,                          \
+                              fast_wide_window(MM, p.bits_per_sample));                      \
         hipError_t er = hipFuncSetAttribute(                                                 \
             reinterpret_cast<const void *>(&k_encode_pow2<CC, TT, MM>),                      \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \

@@ -205,6 +205,8 @@ def other_configs(dev_index, steps):
         ("configs[3]: 8-channel 24-bit 192 kHz, n 4096, LPC-12 (MAX), 32768 subframes",
          P(5, channels=8, bits_per_sample=24, sample_rate=192000, order_method=flake_amd.OM_MAX,
            max_prediction_order=12), 4096),
+        ("configs[0] (the reference's CPU case) on the GPU: mono 16-bit, n 4096, fixed orders 0-4, "
+         "partition orders 0-3", P(2, channels=1, block_size=4096), 8192),
         ("level 8: stereo 16-bit, n 4096, LPC <= 12 LOG search, partition orders 0-6", P(8), 4096),
         ("level 2: stereo 16-bit, n 1152, fixed orders 0-4, partition orders 0-3", P(2),
          4096 * 4096 // 1152),

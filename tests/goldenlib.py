@@ -69,6 +69,15 @@ def ref_path_cases():
     r = np.random.RandomState(12)
     noise = r.randint(-32768, 32768, (2, 4096, 2)).astype(np.int32)
     out.append(("white_noise_verbatim_fallback", flake_amd.level_params(5), 4096, noise, 65535))
+    # the order-search kernel's instances beyond n = 4096 (512 and 1024 tiles) and its VALU one
+    for name, kw, n in (("search16_n16384", dict(order_method=flake_amd.OM_SEARCH, max_prediction_order=16,
+                                                   max_partition_order=8), 16384),
+                        ("level8_log32_n8192", dict(order_method=flake_amd.OM_LOG, max_prediction_order=32,
+                                                    max_partition_order=8), 8192),
+                        ("four_level_n2048_24bit", dict(order_method=flake_amd.OM_4LEVEL, max_prediction_order=12,
+                                                        bits_per_sample=24), 2048)):
+        p = flake_amd.level_params(5, block_size=n, **kw)
+        out.append((name, p, n, flake_amd.synth_pcm(1, n, 2, p.bits_per_sample, first_frame=21), 5))
     for seed in range(128):
         p, pcm, n, what = fuzz_case(seed)
         out.append((f"fuzz{seed}", p, n, pcm[:2], [0, 120, 127, 2047, 65530][seed % 5]))

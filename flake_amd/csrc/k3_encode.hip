@@ -2589,38 +2589,64 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                 }
                 const int xaddr = ((mi >> 2) * Img::S + Img::COL0) * 4 + (mi & 3);
                 uint32_t uor = 0;
-                auto epilogue = [&](const mfma_d4 &D, int tile) {
+                auto epilogue = [&](const mfma_d4 &D, int tile_) {
+                    const int tile = __builtin_amdgcn_readfirstlane(tile_);      // wave-uniform: scalar tests below
                     const uint32_t x = (uint32_t)l.smp[xaddr + 4 * tile];
+                    uint32_t u[4];
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const double z = __builtin_fma(D[r], inv[r], 6755399441055744.0);   // floor, see fir_lpc
                         const int32_t res = (int32_t)(x - (uint32_t)__double2loint(z));
-                        uint32_t u = zigzag32(res);
-                        if (tile < 2 && 16 * tile + mi < ordr[r]) u = 0u;        // rice.c:85-94
-                        uor |= u;
-                        u += dpp_u32<0x111>(u);
-                        u += dpp_u32<0x112>(u);
-                        u += dpp_u32<0x114>(u);
-                        u += dpp_u32<0x118>(u);
-                        if (mi == 15 && 4 * r + kq < grp_n) l.leaf[(4 * r + kq) * T + tile] = u;
+                        u[r] = zigzag32(res);
+                    }
+                    if (tile < 2) {                                               // rice.c:85-94: warm-up samples
+#pragma unroll
+                        for (int r = 0; r < 4; r++) if (16 * tile + mi < ordr[r]) u[r] = 0u;
+                    }
+                    uor |= (u[0] | u[1]) | (u[2] | u[3]);
+                    // four independent reductions side by side (a DPP operand wants two idle cycles
+                    // behind the instruction that wrote it: the other three chains fill them)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) u[r] += dpp_u32<0x111>(u[r]);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) u[r] += dpp_u32<0x112>(u[r]);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) u[r] += dpp_u32<0x114>(u[r]);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) u[r] += dpp_u32<0x118>(u[r]);
+                    if (mi == 15) {                  // rows past grp_n hold nothing anybody reads
+#pragma unroll
+                        for (int r = 0; r < 4; r++) l.leaf[(4 * r + kq) * T + tile] = u[r];
                     }
                 };
+                // the tap blocks of a group as straight-line code (1, 2, 4 or 8 of them: a block past
+                // the group's longest row multiplies zeros): all operand reads of a tile pair go out
+                // first, the products follow back to back
+                auto pairs = [&](auto kbc) {
+                    constexpr int KB = decltype(kbc)::value;
 #pragma unroll 1
-                for (int tp = 0; tp < 64; tp += 2) {
-                    const int t0 = wv * 64 + tp, t1 = t0 + 1;
-                    mfma_d4 D0 = {0.0, 0.0, 0.0, 0.0}, D1 = {0.0, 0.0, 0.0, 0.0};
+                    for (int tp = 0; tp < 64; tp += 2) {
+                        const int t0 = wv * 64 + tp, t1 = t0 + 1;
+                        int32_t x0[KB], x1[KB];
 #pragma unroll
-                    for (int kb = 0; kb < 8; kb++) {
-                        if (kb < kbmax) {
-                            const double b0 = (double)l.smp[baddr[kb] + 4 * t0];
-                            const double b1 = (double)l.smp[baddr[kb] + 4 * t1];
-                            D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb], b0, D0, 0, 0, 0);
-                            D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb], b1, D1, 0, 0, 0);
+                        for (int kb = 0; kb < KB; kb++) {
+                            x0[kb] = l.smp[baddr[kb] + 4 * t0];
+                            x1[kb] = l.smp[baddr[kb] + 4 * t1];
                         }
+                        mfma_d4 D0 = {0.0, 0.0, 0.0, 0.0}, D1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kb = 0; kb < KB; kb++) {
+                            D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb], (double)x0[kb], D0, 0, 0, 0);
+                            D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb], (double)x1[kb], D1, 0, 0, 0);
+                        }
+                        epilogue(D0, t0);
+                        epilogue(D1, t1);
                     }
-                    epilogue(D0, t0);
-                    epilogue(D1, t1);
-                }
+                };
+                if (kbmax <= 1) pairs(std::integral_constant<int, 1>{});
+                else if (kbmax <= 2) pairs(std::integral_constant<int, 2>{});
+                else if (kbmax <= 4) pairs(std::integral_constant<int, 4>{});
+                else pairs(std::integral_constant<int, 8>{});
                 // 16 folded values below 2^28 each sum inside 32 bits; otherwise the group's
                 // candidates take the VALU FIR and its 64-bit sums below
                 if (__any((uor >> 28) != 0u) && lane == 0) atomicOr(reinterpret_cast<uint32_t *>(&l.misc[2 + gpar]), 1u);

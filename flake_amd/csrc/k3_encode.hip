@@ -3084,7 +3084,10 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
     // many candidates known up front (SEARCH, 8-LEVEL) and tiles of 16 samples: the instance
     // whose FIRs run on the matrix pipe
     static const bool no_mfma = getenv("FHIP_NO_MFMA") != nullptr;          // measurements only
-    const bool mf = !no_mfma && fc == 16 &&
+    // ... where the rows are not 16-bit ones: on those the packed int16 dot products of the VALU
+    // instance are cheaper still (SEARCH 1-12, 8192 subframes: 412 against 522 us; on 24-bit
+    // samples 852 against 533)
+    const bool mf = !no_mfma && fc == 16 && !narrow_ok &&
                     ((p.order_method == 5 && p.max_prediction_order >= 5) || p.order_method == 4);
 #define LAUNCH_SRCH(CC, TT, MM)                                                              \
     do {                                                                                     \

@@ -575,9 +575,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             per_frame_bits = info_np["rice_nbits"].clip(min=0).astype(np.int64) \
                 .reshape(nframes, p.channels).sum(axis=1)
-            cpu = cpu_baseline(p, n, args.cpu_seconds, per_frame_bits)
+            try:
+                cpu = cpu_baseline(p, n, args.cpu_seconds, per_frame_bits)
+            except Exception as e:
+                cpu = {"error": repr(e)}
         if world == 1 and not args.no_other_configs:
-            others = other_configs(dev_index, args.other_steps)
+            try:
+                others = other_configs(dev_index, args.other_steps)
+            except Exception as e:                      # reported extras must not cost the headline line
+                others = [{"error": repr(e)}]
             try:
                 host = host_path()
             except Exception as e:                      # a reported extra, never fatal

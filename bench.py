@@ -45,6 +45,11 @@ def parse_args():
                     help="untimed steps before the warm-up until this much wall time has passed: "
                          "the clocks ramp for ~20 ms under this load whatever --warmup says")
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
+    ap.add_argument("--workload", choices=["configs[1]", "configs[3]"], default="configs[1]",
+                    help="configs[1] is the one BASELINE.json's metric is quoted on (the default "
+                         "and the only one the driver runs); configs[3] (8-channel 24-bit LPC-12, "
+                         "the config BASELINE.json shards over 1/2/4/8 GPUs) runs through the same "
+                         "timed region and sharding for a scaling run of that shape")
     ap.add_argument("--ahead", action="store_true",
                     help="hint the next batch's feeder stage ahead (fhip_prepare_ahead) so that it "
                          "runs beside the kernels in flight; measured SLOWER on MI355X (DESIGN.md 5: "
@@ -188,6 +193,26 @@ def cpu_baseline(params, n, budget_s, gpu_bits_per_frame=None):
                                         else bool(bits == int(gpu_bits_per_frame[:rf].sum()))),
         }
     return out
+
+
+def copy_bandwidth(dev, achieved_gbps, nbytes=1 << 30, reps=10):
+    """Device-to-device copy of `nbytes` on the current stream: bytes read + bytes written per
+    second, the rate a kernel that only moves data reaches on this box."""
+    import torch
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    src.zero_()
+    for _ in range(3):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    gbps = 2 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    return {"copy_GBps_measured": round(gbps, 1), "frac_of_copy": round(achieved_gbps / gbps, 4)}
 
 
 def other_configs(dev_index, steps):
@@ -413,8 +438,20 @@ def main():
             os.close(saved_fd)
 
     # ---- workload: BASELINE.json configs[1] --------------------------------
-    p = flake_amd.level_params(5, channels=2, bits_per_sample=16, sample_rate=44100,
-                               order_method=flake_amd.OM_MAX)
+    if args.workload == "configs[3]":
+        p = flake_amd.level_params(5, channels=8, bits_per_sample=24, sample_rate=192000,
+                                   order_method=flake_amd.OM_MAX, max_prediction_order=12)
+        metric = "Msamples/s encoded, 8-channel 24-bit 192k blocksize 4096 LPC-12"
+        workload = ("configs[3]: 8-channel 24-bit 192 kHz, blocksize 4096, LPC-12 (level-5 params, "
+                    "order method MAX, max order 12, partition orders 0-5), synthetic resonator PCM "
+                    "resident in HBM")
+    else:
+        p = flake_amd.level_params(5, channels=2, bits_per_sample=16, sample_rate=44100,
+                                   order_method=flake_amd.OM_MAX)
+        metric = "Msamples/s encoded, 16-bit stereo 44.1k blocksize 4096 LPC-8"
+        workload = ("configs[1]: stereo 16-bit 44.1 kHz, blocksize 4096, LPC max order 8 "
+                    "(level-5 params, order method MAX, partition orders 0-5, stereo "
+                    "estimate), synthetic resonator PCM resident in HBM")
     n = p.block_size
     nframes = args.frames
     nsub = nframes * p.channels
@@ -551,7 +588,7 @@ def main():
             traffic = None
             traffic_source = None
             tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tp):
+            if os.path.exists(tp) and args.workload == "configs[1]":     # counters taken on configs[1]
                 try:
                     tj = json.load(open(tp))
                     traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
@@ -572,6 +609,21 @@ def main():
                 "pipeline_achieved": round(alg_bytes / (dt / args.steps) / 1e9, 1),
                 "pipeline_frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
             }
+        if roofline is not None:
+            try:                             # the fraction of a *measured* copy too
+                roofline.update(copy_bandwidth(dev, achieved))
+            except Exception as e:
+                roofline["copy_GBps_measured"] = None
+                roofline["copy_error"] = repr(e)
+            try:                             # all HBM bytes the step's kernels moved (PMC) / step
+                if args.workload != "configs[1]":
+                    raise KeyError(args.workload)
+                tj = json.load(open(tp))
+                moved = sum(v["hbm_bytes_per_launch"] for k, v in tj.items() if not k.startswith("_"))
+                roofline["pipeline_traffic"] = moved
+                roofline["pipeline_traffic_GBps"] = round(moved / (dt / args.steps) / 1e9, 1)
+            except Exception:
+                roofline["pipeline_traffic"] = None
         if world == 1 and not args.no_cpu_baseline:
             per_frame_bits = info_np["rice_nbits"].clip(min=0).astype(np.int64) \
                 .reshape(nframes, p.channels).sum(axis=1)
@@ -579,7 +631,7 @@ def main():
                 cpu = cpu_baseline(p, n, args.cpu_seconds, per_frame_bits)
             except Exception as e:
                 cpu = {"error": repr(e)}
-        if world == 1 and not args.no_other_configs:
+        if world == 1 and not args.no_other_configs and args.workload == "configs[1]":
             try:
                 others = other_configs(dev_index, args.other_steps)
             except Exception as e:                      # reported extras must not cost the headline line
@@ -595,7 +647,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Msamples/s encoded, 16-bit stereo 44.1k blocksize 4096 LPC-8",
+            "metric": metric,
             "value": round(value, 2),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -608,9 +660,7 @@ def main():
             "dtype": "int64/f64",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: stereo 16-bit 44.1 kHz, blocksize 4096, LPC max order 8 "
-                            "(level-5 params, order method MAX, partition orders 0-5, stereo "
-                            "estimate), synthetic resonator PCM resident in HBM",
+                "workload": workload,
                 "frames_per_gpu": nframes,
                 "samples_per_step": samples_per_step,
                 "batches": ("two batches of this shard alternate; the next one's feeder stage is "

@@ -2221,16 +2221,23 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
 // bits[order] depends on nothing but the order, so the reference's sequential search is a
 // walk over a table.  This kernel fills the table -- FIR (optimize.c:70-122), fold, partition
 // sums, Rice parameter / partition-order search (rice.c:105-187) for every candidate order
-// the method can visit -- G candidates per round, so that the fixed phases of a search (the
-// barriers, the node pass, the level selection) are paid once per round instead of once per
-// candidate, and nothing of the emit's state (residuals, parameters, windows) is carried.
+// the method can visit -- G candidates per round: every wave runs the FIR and the fold of every
+// candidate over its part of the block, the T thread sums go to LDS as 32-bit leaves, and then
+// ONE WAVE PER CANDIDATE does the whole Rice search from them (wave_candidate_bits); nothing of
+// the emit's state (residuals, parameters, windows) is carried.  (Round 2 also had an instance
+// whose FIRs ran as fp64 matrix products, v_mfma_f64_16x16x4_f64 over 16 candidates x 16
+// samples, exact because every product and sum is an integer below 2^53: once the search
+// behind the FIR went wave-per-candidate in this instance too, the two measured the same --
+// SEARCH 1-32 on 24-bit samples 1.33 against 1.41 ms, 1-24: 1.30 against 0.98, 1-12: 0.54
+// against 0.43 -- and the matrix instance was dropped)
 // It then replays the method's decision on the table and leaves the winner the way K2 leaves
 // the single row of the MAX / EST methods: opt_order[s] and the compact row fin[s].  The lean
 // K3 instance (MODE 0 / 3) encodes that row -- the reference's own final call
 // (optimize.c:266-275) -- so est_bits, parameters and bits come from the same code as before.
 template <int G>
 struct SrchLds {
-    unsigned long long *sums;   // [G][512] heap order per candidate slot
+    unsigned long long *sums;   // [G][512] heap order per candidate slot; in leaf mode G per-wave heaps of 128
+                                // and behind them the G x T thread sums as 32-bit leaves
     unsigned long long *wtot;   // [G][16]  per-wave totals
     double *coefd;              // [G][32]  candidate rows as doubles, zero past the order
     int32_t *smp;               // SmpImg<C, T>
@@ -2239,16 +2246,17 @@ struct SrchLds {
     int32_t *pairs;             // [G][8]   taps as int16 pairs (packed FIR)
     int32_t *rowi;              // [G][4]   order index, shift, sum |coef|, spare
     uint32_t *trial;            // [32]     bits[order index], 0xFFFFFFFF = not evaluated
-    uint32_t *leaf;             // [16][T]  MFMA instance: finest-level sums of a group of 16 candidates
     int32_t *list;              // [32]     candidate order indices of this subframe
-    int32_t *misc;              // [16]
+    int32_t *misc;              // [32]: count, winner, two overflow flags, one "differs" word per wave (<= 16), ...
 };
 
 template <int G>
-__host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[12], int leaf_tiles = 0)
+__host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[12], int threads)
 {
     size_t o = 0;
-    off[0] = o; o += 8 * 512 * G;
+    // sums: G x 4 KB for the general way; leaf mode overlays G heaps of 1 KB and G x T leaves
+    const size_t general = 8 * 512 * (size_t)G, leafy = 8 * 128 * (size_t)G + 4 * (size_t)G * (size_t)threads;
+    off[0] = o; o += general > leafy ? general : leafy;
     off[1] = o; o += 8 * 16 * G;
     off[2] = o; o += 8 * 32 * G;
     off[3] = o; o += 4 * img_ints;
@@ -2259,30 +2267,14 @@ __host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[12
     off[7] = o; o += 4 * 4 * G;
     off[8] = o; o += 4 * 32;
     off[9] = o; o += 4 * 32;
-    off[10] = o; o += 4 * 16;
-    o = (o + 15) & ~(size_t)15;
-    // MFMA instance: leaf [16][tiles] u32.  A group either goes wave-per-candidate (the leaves
-    // plus one 1 KB heap per wave at the head of `sums`) or, after an overflow, through the
-    // rounds (all of `sums`, no leaves): the leaves overlay `sums` behind the heaps.
+    off[10] = o; o += 4 * 32;
     off[11] = 0;
-    if (leaf_tiles) {
-        const size_t heaps = 8 * 128 * (size_t)(leaf_tiles / 64);
-        off[11] = off[0] + heaps;
-        const size_t need = off[11] + 4 * 16 * (size_t)leaf_tiles;
-        // regions 1.. were laid out behind the G * 4 KB of sums: push everything behind the overlay
-        const size_t have = off[1];
-        if (need > have) {
-            const size_t shift = (need - have + 15) & ~(size_t)15;
-            for (int q = 1; q <= 10; q++) off[q] += shift;
-            o += shift;
-        }
-    }
     return (o + 15) & ~(size_t)15;
 }
 
 
-// rice.c:105-187 for ONE candidate by ONE wave, from the finest-level sums the MFMA phase of
-// k_order_search left in LDS (leaf[tile], tile = 16 samples): no barrier, no atomics.  A lane
+// rice.c:105-187 for ONE candidate by ONE wave, from the finest-level sums a round of
+// k_order_search left in LDS (leaf[t] = the sum of thread t's run): no barrier, no atomics.  A lane
 // takes T/64 consecutive leaves and owns the nodes above them down to level 6 (always seven
 // that can be asked for: four at level 8, two at 7, one at 6); levels 5..0 are 63 nodes built
 // through a small per-wave heap in LDS and evaluated one per lane.  Level totals: a wave
@@ -2388,9 +2380,8 @@ __device__ __forceinline__ uint32_t wave_candidate_bits(const uint32_t *__restri
     return bits;
 }
 
-typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-template <int C, int T, int G, bool MF>
+template <int C, int T, int G>
 __global__ __launch_bounds__(T, (T <= 256) ? 4 : (T <= 512) ? 2 : 1)
 void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                     const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
@@ -2401,11 +2392,14 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     using Img = SmpImg<C, T>;
     constexpr int LT = clog2(T);
     constexpr int NW = T / WAVE;
+#ifndef LOG_MERGE
+#define LOG_MERGE 1
+#endif
+    static_assert(T >= 256 && NW >= G, "leaf mode: wave m of the first G takes candidate m");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     size_t off[12];
-    srch_lds_layout<G>((size_t)Img::SIZE, off, MF ? T : 0);
+    srch_lds_layout<G>((size_t)Img::SIZE, off, T);
     SrchLds<G> l;
-    l.leaf = reinterpret_cast<uint32_t *>(lds_raw + off[11]);
     l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
     l.wtot = reinterpret_cast<unsigned long long *>(lds_raw + off[1]);
     l.coefd = reinterpret_cast<double *>(lds_raw + off[2]);
@@ -2473,7 +2467,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     }
     if (tid < Img::COL0 * C) l.smp[Img::at(tid / C, tid % C)] = 0;
     if (tid < 32) l.trial[tid] = 0xFFFFFFFFu;
-    if (tid < 2) l.misc[2 + tid] = 0;                  // MFMA instance: "a tile sum left 32 bits", per group parity
+    if (tid < 2) l.misc[24 + tid] = 0;                 // rounds: "a thread sum left 32 bits", per round parity
 
     const int omethod = P.order_method;
     const int min_order = P.min_prediction_order, max_order = P.max_prediction_order;
@@ -2522,158 +2516,50 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 
     for (int g0 = 0, round = 0;; g0 += G, round++) {
         int ng;
-        int lg_c[3] = {0, 0, 0};
+        uint32_t lg_pack = 0;             // the round's LOG candidates, five bits each, in visiting order
+        int lg_merged = 0;                // ... and the steps of optimize.c:247 they belong to
         if (constant) break;
         if (!is_log) {
             ng = min(G, nc - g0);
             if (ng <= 0) break;
         } else {
-            // the next step that has orders not yet evaluated: last - step, last, last + step
+            // The next steps' orders not yet evaluated (last - step, last, last + step).  What a step
+            // visits depends on the winner so far -- but often not at all: from order index 3 of
+            // 1..12 the walk visits 3, then 11, then 7 whoever wins.  So a round takes the first
+            // step that has candidates and then every following step whose candidate set is the
+            // same for EVERY order that could be the winner by then (the winner on entry or any
+            // candidate of the round), while they fit G.  The replay below then visits exactly the
+            // reference's candidates in the reference's order.  All scalar (uniform) arithmetic.
             ng = 0;
-            while (lg_step > 0) {
-                for (int i = lg_best - lg_step; i <= lg_best + lg_step; i += lg_step) {
-                    if (i < min_order - 1 || i >= max_order || ((lg_seen >> i) & 1u)) continue;
-                    lg_c[ng++] = i;
+            uint32_t poss = 1u << lg_best, seen = lg_seen;
+            int st = lg_step;
+            while (st > 0) {
+                uint32_t set0 = 0;
+                bool first = true, same = true;
+                for (uint32_t pm = poss; pm; pm &= pm - 1) {
+                    const int b = __builtin_ctz(pm);
+                    uint32_t sb = 0;
+                    for (int i = b - st; i <= b + st; i += st)
+                        if (i >= min_order - 1 && i < max_order && !((seen >> i) & 1u)) sb |= 1u << i;
+                    if (first) { set0 = sb; first = false; }
+                    else if (sb != set0) same = false;
                 }
-                if (ng) break;
-                lg_step >>= 1;
+                const int cnt = __builtin_popcount(set0);
+                if (!same || ng + cnt > G) break;          // (never on a round's first step: one winner, <= 3 orders)
+                if (ng > 0 && !LOG_MERGE) break;
+                for (uint32_t m = set0; m; m &= m - 1) lg_pack |= (uint32_t)__builtin_ctz(m) << (5 * ng++);
+                seen |= set0;
+                poss |= set0;
+                lg_merged++;
+                st >>= 1;
             }
-            if (ng == 0) break;
+            if (ng == 0) break;                            // every step consumed, nothing left to visit
         }
         const int par = round & 1;
-        if constexpr (MF) {
-            // ---- a group of 16 candidates: their FIRs as one matrix product per tile ----
-            // pred[m][i] = sum_j coef[m][j] x[i-1-j] for 16 candidate rows m and the 16 samples i
-            // of a tile IS a 16 x 16 x (4 per instruction) product: A = coefficients (zero past a
-            // row's order), B = the tile's Toeplitz window of samples.  As doubles everything is
-            // an exact integer below 2^53 (as in fir_lpc), so v_mfma_f64_16x16x4_f64 gives the
-            // reference's int64 sums bit for bit whatever its internal order -- and it runs on
-            // the matrix pipe, which this VALU-bound kernel leaves idle.  Lane l supplies
-            // A[m = l%16][k = l/16] and B[k = l/16][i = l%16] and receives D[m = 4r + l/16][i = l%16]
-            // in register r (layout checked on the hardware, tools/mfma_probe.hip).  The epilogue
-            // per register: floor(pred * 2^-shift) by the fma of fir_lpc, residual, fold
-            // (rice.c:122), warm-up zeroed, and the tile's sum by a DPP row reduction: the
-            // finest-level partition sum (a tile = 16 samples = one thread of the pyramid).
-            const int grp_n = is_log ? 0 : min(16, nc - (g0 & ~15));
-            if (grp_n >= 5 && (g0 & 15) == 0) {
-                const int gbase = g0;
-                const int mi = lane & 15, kq = lane >> 4;
-                const int gpar = (g0 >> 4) & 1;
-                if (tid == 0) l.misc[2 + (gpar ^ 1)] = 0;
-                const int candA = (mi < grp_n) ? l.list[gbase + mi] : -1;
-                double a[8];
-#pragma unroll
-                for (int kb = 0; kb < 8; kb++) {
-                    const int tap = 4 * kb + kq;
-                    a[kb] = (candA >= 0 && tap <= candA) ? (double)crow_base[candA * FHIP_MAX_ORDER + tap] : 0.0;
-                }
-                double inv[4];
-                int ordr[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int m = 4 * r + kq;
-                    const int cand = (m < grp_n) ? l.list[gbase + m] : 0;
-                    ordr[r] = (m < grp_n) ? cand + 1 : 0;
-                    inv[r] = __builtin_ldexp(1.0, -srow[cand]);
-                }
-                int omax = 0;
-                for (int j = 0; j < grp_n; j++) omax = max(omax, l.list[gbase + j] + 1);
-                const int kbmax = __builtin_amdgcn_readfirstlane((omax + 3) >> 2);
-                int baddr[8];
-#pragma unroll
-                for (int kb = 0; kb < 8; kb++) {
-                    const int d = mi - 1 - kq - 4 * kb;               // sample offset inside the tile, >= -32
-                    const int fd = (d + 32) / 16 - 2;                 // floor(d / 16)
-                    const int rr = d - 16 * fd;
-                    baddr[kb] = ((rr >> 2) * Img::S + fd + Img::COL0) * 4 + (rr & 3);
-                }
-                const int xaddr = ((mi >> 2) * Img::S + Img::COL0) * 4 + (mi & 3);
-                uint32_t uor = 0;
-                auto epilogue = [&](const mfma_d4 &D, int tile_) {
-                    const int tile = __builtin_amdgcn_readfirstlane(tile_);      // wave-uniform: scalar tests below
-                    const uint32_t x = (uint32_t)l.smp[xaddr + 4 * tile];
-                    uint32_t u[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const double z = __builtin_fma(D[r], inv[r], 6755399441055744.0);   // floor, see fir_lpc
-                        const int32_t res = (int32_t)(x - (uint32_t)__double2loint(z));
-                        u[r] = zigzag32(res);
-                    }
-                    if (tile < 2) {                                               // rice.c:85-94: warm-up samples
-#pragma unroll
-                        for (int r = 0; r < 4; r++) if (16 * tile + mi < ordr[r]) u[r] = 0u;
-                    }
-                    uor |= (u[0] | u[1]) | (u[2] | u[3]);
-                    // four independent reductions side by side (a DPP operand wants two idle cycles
-                    // behind the instruction that wrote it: the other three chains fill them)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) u[r] += dpp_u32<0x111>(u[r]);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) u[r] += dpp_u32<0x112>(u[r]);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) u[r] += dpp_u32<0x114>(u[r]);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) u[r] += dpp_u32<0x118>(u[r]);
-                    if (mi == 15) {                  // rows past grp_n hold nothing anybody reads
-#pragma unroll
-                        for (int r = 0; r < 4; r++) l.leaf[(4 * r + kq) * T + tile] = u[r];
-                    }
-                };
-                // the tap blocks of a group as straight-line code (1, 2, 4 or 8 of them: a block past
-                // the group's longest row multiplies zeros): all operand reads of a tile pair go out
-                // first, the products follow back to back
-                auto pairs = [&](auto kbc) {
-                    constexpr int KB = decltype(kbc)::value;
-#pragma unroll 1
-                    for (int tp = 0; tp < 64; tp += 2) {
-                        const int t0 = wv * 64 + tp, t1 = t0 + 1;
-                        int32_t x0[KB], x1[KB];
-#pragma unroll
-                        for (int kb = 0; kb < KB; kb++) {
-                            x0[kb] = l.smp[baddr[kb] + 4 * t0];
-                            x1[kb] = l.smp[baddr[kb] + 4 * t1];
-                        }
-                        mfma_d4 D0 = {0.0, 0.0, 0.0, 0.0}, D1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int kb = 0; kb < KB; kb++) {
-                            D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb], (double)x0[kb], D0, 0, 0, 0);
-                            D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb], (double)x1[kb], D1, 0, 0, 0);
-                        }
-                        epilogue(D0, t0);
-                        epilogue(D1, t1);
-                    }
-                };
-                if (kbmax <= 1) pairs(std::integral_constant<int, 1>{});
-                else if (kbmax <= 2) pairs(std::integral_constant<int, 2>{});
-                else if (kbmax <= 4) pairs(std::integral_constant<int, 4>{});
-                else pairs(std::integral_constant<int, 8>{});
-                // 16 folded values below 2^28 each sum inside 32 bits; otherwise the group's
-                // candidates take the VALU FIR and its 64-bit sums below
-                if (__any((uor >> 28) != 0u) && lane == 0) atomicOr(reinterpret_cast<uint32_t *>(&l.misc[2 + gpar]), 1u);
-            }
-            if (grp_n >= 5 && (g0 & 15) == 0) {
-                __syncthreads();
-                if (l.misc[2 + ((g0 >> 4) & 1)] == 0) {
-                    // a wave per candidate straight from the tile sums (no rounds for this group)
-                    for (int m = wv; m < grp_n; m += NW) {
-                        const int cand = l.list[g0 + m];
-                        const int ord = cand + 1;
-                        const uint32_t b = wave_candidate_bits<T>(
-                            l.leaf + m * T, l.sums + wv * 128, n, ord, clamp_porder(e.pmin_req, n, ord),
-                            clamp_porder(e.pmax_req, n, ord), e.obits, e.precision, lane);
-                        if (lane == 0) l.trial[cand] = b;
-                    }
-                    __syncthreads();                   // the leaves may be overwritten; bits[] is in place
-                    g0 += 16 - G;                      // (the loop adds G)
-                    continue;
-                }
-            }
-        }
         // ---- the round's rows: doubles, int16 pairs, sum |coef|, shift ----
         if (tid < G * 32) {
             const int g = tid >> 5, j = tid & 31;
-            const int cand = (g >= ng) ? 0 : is_log ? (g == 0 ? lg_c[0] : g == 1 ? lg_c[1] : lg_c[2])
-                                                    : l.list[g0 + g];
+            const int cand = (g >= ng) ? 0 : is_log ? (int)((lg_pack >> (5 * g)) & 31u) : l.list[g0 + g];
             const int ord = cand + 1;
             const int32_t cv = (g < ng && j < ord) ? crow_base[cand * FHIP_MAX_ORDER + j] : 0;
             l.coefd[g * 32 + j] = (double)cv;
@@ -2693,8 +2579,20 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         }
         if (tid < G * 12) l.lvl_bits[par * G * 12 + tid] = 0;
         if (tid < G) l.lvl_meth[par * G + tid] = 0;
+        if (tid == 0) l.misc[24 + (par ^ 1)] = 0;
         __syncthreads();
 
+        // The search behind the thread sums, two ways.  Leaf mode (T <= 512): the thread sums
+        // -- the finest partition sums there are, T of them -- go to LDS as 32-bit leaves and
+        // ONE WAVE PER CANDIDATE does rice.c:105-187 from them (wave_candidate_bits: no barrier,
+        // no atomics, a third of the instructions of the pyramid + node pass below, which every
+        // wave runs for every candidate).  A thread sum that leaves 32 bits (32-bit noise)
+        // flags the round, which is then run again the general way: 64-bit pyramid in every
+        // wave, one thread per (candidate, level, partition) node.
+        bool leaf_mode = true;
+        uint32_t *rleaf = reinterpret_cast<uint32_t *>(l.sums + G * 128);      // behind the G heaps
+#pragma unroll 1
+        for (int pass = 0; pass < 2; pass++) {
         // ---- per candidate: FIR, fold, thread sum, in-wave pyramid ----
 #pragma unroll 1
         for (int g = 0; g < ng; g++) {
@@ -2726,6 +2624,11 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 #pragma unroll
                 for (int o = 0; o < C; o++) v += zigzag32(r[o]);
             }
+            }
+            if (leaf_mode) {
+                rleaf[g * T + tid] = (uint32_t)v;
+                if (__any((v >> 32) != 0ull) && lane == 0) atomicOr(reinterpret_cast<uint32_t *>(&l.misc[24 + par]), 1u);
+                continue;
             }
             const int pmm = __builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 3]);
             const int pmin = pmm & 0xFF, pmax = pmm >> 8;
@@ -2760,6 +2663,17 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             if (lane == 0) l.wtot[g * 16 + wv] = v;
         }
         __syncthreads();
+        if (leaf_mode) {
+            if (l.misc[24 + par] != 0) { leaf_mode = false; continue; }      // workgroup-uniform
+            if (wv < ng) {
+                const int ord = l.rowi[wv * 4 + 0] + 1;
+                const int pmm = l.rowi[wv * 4 + 3];
+                const uint32_t b = wave_candidate_bits<T>(rleaf + wv * T, l.sums + wv * 128, n, ord, pmm & 0xFF,
+                                                          pmm >> 8, e.obits, e.precision, lane);
+                if (lane == 0) l.trial[ord - 1] = b;
+            }
+            break;
+        }
 
         // ---- one thread per (candidate, level, partition) node ----
         {
@@ -2826,18 +2740,26 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             bits += method + 4u;
             l.trial[ord - 1] = bits;
         }
-        // (the next round's row staging is ordered behind this round's FIR by the barrier
-        // above; its level words are the other parity's)
+        break;
+        }   // pass
+        // (general way: the next round's row staging is ordered behind this round's FIR by the
+        // barrier above, its level words are the other parity's; leaf mode: the rows, leaves and
+        // heaps are read until the last wave is through)
+        if (leaf_mode) __syncthreads();
         if (is_log) {
             // optimize.c:249-259: the step's orders in ascending order against the winner so far
-            __syncthreads();
-            for (int k = 0; k < ng; k++) {
-                const int i = lg_c[k];
-                const uint32_t cur = ((lg_seen >> lg_best) & 1u) ? l.trial[lg_best] : 0xFFFFFFFFu;
-                lg_seen |= 1u << i;
-                if (l.trial[i] < cur) lg_best = i;
+            if (!leaf_mode) __syncthreads();
+            for (int sidx = 0; sidx < lg_merged; sidx++) {
+                const int last = lg_best;
+                for (int i = last - lg_step; i <= last + lg_step; i += lg_step) {
+                    if (i < min_order - 1 || i >= max_order || ((lg_seen >> i) & 1u)) continue;
+                    const uint32_t cur = ((lg_seen >> lg_best) & 1u) ? l.trial[lg_best] : 0xFFFFFFFFu;
+                    lg_seen |= 1u << i;
+                    if (l.trial[i] < cur) lg_best = i;
+                }
+                lg_step >>= 1;
             }
-            lg_step >>= 1;
+            lg_best = __builtin_amdgcn_readfirstlane(lg_best);      // keeps the walk in scalar registers
         }
     }
     __syncthreads();
@@ -3081,29 +3003,21 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
     if (!order_search_supported(p, n) || !fast_geometry(p, n, &fc, &ft)) return hipErrorInvalidValue;
     constexpr int G = 4;
     size_t off[12];
-    // many candidates known up front (SEARCH, 8-LEVEL) and tiles of 16 samples: the instance
-    // whose FIRs run on the matrix pipe
-    static const bool no_mfma = getenv("FHIP_NO_MFMA") != nullptr;          // measurements only
-    // ... where the rows are not 16-bit ones: on those the packed int16 dot products of the VALU
-    // instance are cheaper still (SEARCH 1-12, 8192 subframes: 412 against 522 us; on 24-bit
-    // samples 852 against 533)
-    const bool mf = !no_mfma && fc == 16 && !narrow_ok &&
-                    ((p.order_method == 5 && p.max_prediction_order >= 5) || p.order_method == 4);
-#define LAUNCH_SRCH(CC, TT, MM)                                                              \
+#define LAUNCH_SRCH(CC, TT)                                                                  \
     do {                                                                                     \
-        const size_t lds = srch_lds_layout<G>((size_t)SmpImg<CC, TT>::SIZE, off, MM ? TT : 0); \
+        const size_t lds = srch_lds_layout<G>((size_t)SmpImg<CC, TT>::SIZE, off, TT);        \
         hipError_t er = hipFuncSetAttribute(                                                 \
-            reinterpret_cast<const void *>(&k_order_search<CC, TT, G, MM>),                  \
+            reinterpret_cast<const void *>(&k_order_search<CC, TT, G>),                      \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         if (er != hipSuccess) return er;                                                     \
-        hipLaunchKernelGGL((k_order_search<CC, TT, G, MM>), dim3(nsub), dim3(TT), lds, st, p, n, \
+        hipLaunchKernelGGL((k_order_search<CC, TT, G>), dim3(nsub), dim3(TT), lds, st, p, n, \
                            smp, coefs, shift, opt_order, fin, prep, narrow_ok ? 1 : 0);      \
     } while (0)
     switch (fc * 10000 + ft) {
-    case 160256: if (mf) LAUNCH_SRCH(16, 256, true); else LAUNCH_SRCH(16, 256, false); break;
-    case 160512: if (mf) LAUNCH_SRCH(16, 512, true); else LAUNCH_SRCH(16, 512, false); break;
-    case 161024: if (mf) LAUNCH_SRCH(16, 1024, true); else LAUNCH_SRCH(16, 1024, false); break;
-    case 80256: LAUNCH_SRCH(8, 256, false); break;
+    case 160256: LAUNCH_SRCH(16, 256); break;
+    case 160512: LAUNCH_SRCH(16, 512); break;
+    case 161024: LAUNCH_SRCH(16, 1024); break;
+    case 80256: LAUNCH_SRCH(8, 256); break;
     default: return hipErrorInvalidValue;
     }
 #undef LAUNCH_SRCH

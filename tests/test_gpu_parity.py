@@ -499,15 +499,30 @@ def test_orders_9_to_16_on_16bit_rows(oracle, n, order):
         check(oracle, p, pcm, n, f"order{order} n{n} om{om}")
 
 
+def test_log_walk_every_order_range(oracle):
+    """LOG (optimize.c:239-261) for every (min, max) prediction-order pair: the search kernel
+    merges consecutive steps of the walk into one round where their candidates do not depend on
+    the winner; the order chosen (and everything after it) must be the reference's."""
+    r = np.random.RandomState(77)
+    for lo in range(1, 33):
+        for hi in range(lo, 33):
+            n = 4096 if (lo + hi) % 5 == 0 else 2048
+            bps = 24 if (lo * 7 + hi) % 3 == 0 else 16
+            p = flake_amd.level_params(5, bits_per_sample=bps, block_size=n, order_method=flake_amd.OM_LOG,
+                                       min_prediction_order=lo, max_prediction_order=hi, max_partition_order=6)
+            pcm = flake_amd.synth_pcm(2, n, 2, bps, first_frame=int(r.randint(0, 1000)))
+            check(oracle, p, pcm, n, f"LOG {lo}..{hi} n={n} bps={bps}")
+
+
 @pytest.mark.parametrize("n", [4096, 8192, 16384, 2048])
 @pytest.mark.parametrize("om,mo", [(flake_amd.OM_SEARCH, 32), (flake_amd.OM_SEARCH, 9), (flake_amd.OM_8LEVEL, 32),
                                    (flake_amd.OM_4LEVEL, 12), (flake_amd.OM_2LEVEL, 8), (flake_amd.OM_LOG, 32)])
 def test_order_search_kernel(oracle, n, om, mo):
-    """k_order_search (the LEVEL / SEARCH / LOG walks over a table of candidates) and its two
-    instances: the MFMA one (FIR of 16 candidates per matrix product, a wave per candidate from
-    the tile sums) incl. its overflow fall-back to the VALU rounds -- 32-bit noise leaves tile
-    sums above 32 bits --, and the VALU one.  Mixed batch: resonator frames, full-scale 32-bit
-    noise, a constant frame, a frame whose first tile is an impulse (warm-up masking)."""
+    """k_order_search (the LEVEL / SEARCH / LOG walks over a table of candidates): rounds of up
+    to four candidates, a wave per candidate from the thread sums (leaf mode), incl. the
+    fall-back to the 64-bit pyramid and node pass of every wave -- 32-bit noise leaves thread
+    sums above 32 bits -- and LOG's merged steps.  Mixed batch: resonator frames, full-scale
+    32-bit noise, a constant frame, a frame whose first tile is an impulse (warm-up masking)."""
     for bps in (24, 32, 16):
         p = flake_amd.level_params(5, bits_per_sample=bps, block_size=n, order_method=om,
                                    min_prediction_order=1 if om != flake_amd.OM_8LEVEL else 3,

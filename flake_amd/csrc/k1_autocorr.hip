@@ -441,8 +441,15 @@ void k_autocorr_ps(const int32_t *__restrict__ smp, double *__restrict__ autoc,
 // therefore 6 x 3.9 + 8.5 = 32 cycles per step in isolation and 41 in the kernel
 // (four consumers and the producers share the LDS), of which the kernel's other
 // phases add 8 us (barriers, K2 tail).  Producers alone need 24 us per launch,
-// consumers alone 41: they overlap to 56.  Two waves per SIMD doing fp64 pull
-// the clock to ~1.3 GHz (power), so more fp64 waves per SIMD would not help.
+// consumers alone 41: they overlap to 56.  A second consumer wave per SIMD would not
+// help: a SIMD serves its waves oldest first and the LDS return blocks the SIMD's
+// vector issue, not just the reading wave's (ubench_walk, two waves per SIMD: 1.8x
+// the wall time of one; the clock stays at 2.1-2.4 GHz, tools/fp64_clock.hip).
+// Fatter groups were priced too: all even lags of order 8 in one wave (5 chains, one
+// stream) 49.8 cycles per step, all odd ones (4 chains, two streams) 43.5 -- 93 cycles
+// of SIMD time per 32 subframes and step against 32 + 3 x 25.7 = 109 for today's four
+// groups, but on two SIMDs: it pays only with 64 subframes per CU, which the LDS does
+// not hold at this tile size.
 // Requires n % AC_TILE == 0 (launch_autocorr falls back otherwise).
 constexpr int WT_SUB = 32;                           // subframes per workgroup
 #ifndef FHIP_WT_ROWS0

@@ -46,6 +46,46 @@ __global__ void walk(double *out, long long *cyc, double seed)
                 if (K > 1) cy[1] = a;
             }
         }
+    } else if (MODE == 5) {
+        // two operand streams (a lane of an odd-lag class: d[p] and the other parity's d[p-1],
+        // the higher odd lags from carried values), one stage ahead
+        constexpr int PS_CH = 8, NS = 8;
+        lds_cvd2 *rowb = (lds_cvd2 *)(buf + ((threadIdx.x + 17) & 63) * 70);
+#pragma unroll 1
+        for (int tile = 0; tile < STEPS / 64; tile++) {
+            double A[2][PS_CH], B[2][PS_CH];
+            auto fetch = [&](int set, int stage) {
+#pragma unroll
+                for (int u = 0; u < PS_CH; u += 2) {
+                    const dbl2 v = row[(stage * PS_CH + u) / 2];
+                    A[set][u] = v.x; A[set][u + 1] = v.y;
+                    const dbl2 w = rowb[(stage * PS_CH + u) / 2];
+                    B[set][u] = w.x; B[set][u + 1] = w.y;
+                }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int st = 0; st < NS; st++) {
+                if (st + 1 < NS) fetch((st + 1) & 1, st + 1);
+                if (st + 1 < NS) __builtin_amdgcn_s_waitcnt((3 << 14) | (8 << 8) | (7 << 4) | 0xF);
+                else __builtin_amdgcn_s_waitcnt((3 << 14) | (0 << 8) | (7 << 4) | 0xF);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PS_CH; u++) {
+                    const double a = A[st & 1][u], b = B[st & 1][u];
+                    double pr[K];
+                    pr[0] = a * b;
+#pragma unroll
+                    for (int j = 1; j < K; j++) pr[j] = a * cy[j];
+#pragma unroll
+                    for (int j = 0; j < K; j++) S[j] = S[j] + pr[j];
+#pragma unroll
+                    for (int j = K - 1; j >= 2; j--) cy[j] = cy[j - 1];
+                    if (K > 1) cy[1] = b;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     } else if (MODE == 3 || MODE == 4) {
         constexpr int PS_CH = 8, NS = 8, DEPTH = (MODE == 3) ? 2 : 1, NSET = DEPTH + 1;
 #pragma unroll 1
@@ -151,6 +191,20 @@ int main()
     run<2, 0>("regs, 1 wave/SIMD, chip", 256, 256);
     run<2, 1>("regs pipelined, 1 wave/SIMD, chip", 256, 256);
     run<3, 0>("regs, 2 waves/SIMD, chip", 256, 512);
+    // fatter lag classes: all even lags of order 8 / 12 (one stream), all odd lags (two streams)
+    run<5, 3>("LDS a-stream, K=5 (even lags of order 8)", 256, 256);
+    run<7, 3>("LDS a-stream, K=7 (even lags of order 12)", 256, 256);
+    run<4, 5>("LDS a+b streams, K=4 (odd lags of order 8)", 256, 256);
+    run<6, 5>("LDS a+b streams, K=6 (odd lags of order 12)", 256, 256);
+    run<2, 5>("LDS a+b streams, K=2 (today's groups)", 256, 256);
+    run<5, 3>("LDS a-stream, K=5, 2 waves/SIMD", 256, 512);
+    run<4, 5>("LDS a+b streams, K=4, 2 waves/SIMD", 256, 512);
+    // does a second wave on the SIMD fill the issue time the first one loses to its LDS reads?
+    // (waves are served oldest first: a per-wave cycle count says nothing here, wall time does)
+    run<3, 3>("LDS a-stream, 2 ahead, 2 waves/SIMD, chip", 256, 512);
+    run<3, 3>("LDS a-stream, 2 ahead, 2 waves/SIMD, 1 CU", 1, 512);
+    run<3, 3>("LDS a-stream, 2 ahead, 1 wave/SIMD, 1 CU", 1, 256);
+    run<3, 3>("LDS a-stream, 2 ahead, 3 waves/SIMD, chip", 256, 768);
     run<3, 0>("regs, 1 wave on the chip", 1, 64);
     run<3, 1>("regs pipelined, 1 wave on the chip", 1, 64);
     return 0;

@@ -2760,6 +2760,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                 lg_step >>= 1;
             }
             lg_best = __builtin_amdgcn_readfirstlane(lg_best);      // keeps the walk in scalar registers
+            lg_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg_seen);
         }
     }
     __syncthreads();

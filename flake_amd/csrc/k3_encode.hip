@@ -1630,13 +1630,17 @@ __device__ __forceinline__ void put_bits32(uint32_t *win, int nw, long long pos,
 // only (prediction_type FIXED: no LPC code, no fp64); MODE 2: everything --
 // FIXED / NONE prediction and the order-search methods.
 template <int C, int T, int MODE>
-// At least 4 waves per SIMD (<= 128 VGPRs).  The kernel is bound by vector-ALU
-// issue (PMC: ~910 VALU instructions per wave, > 80 % of the issue slots), so what
-// pays is fewer instructions, not more waves: MODE 0 needs 96 VGPRs and runs five
-// workgroups per CU (-3 %); forcing MODE 2 to 96 spills and is slower.
+// Waves per SIMD (the second launch bound; VGPR cap 4 -> 128, 5 -> 96).  The kernel is bound by
+// vector-ALU issue (PMC: ~850 VALU instructions per wave, > 80 % of the issue slots) with a
+// barrier after every phase, and a fifth workgroup per CU fills what the barriers leave idle:
+// the 256-thread instances with runs of 16 fit 96 VGPRs without scratch (the compiler takes 106
+// when allowed 128) and their LDS (31 KB at n = 4096) fits five times: configs[1] 63.1 -> 57.1 us
+// (round 2; round 1 had backed off to four at C >= 14 when the packed FIR first spilled).
+// Four where five would spill (the order-search instance MODE 2; runs of 18) or where the LDS
+// of a 512- / 1024-thread workgroup stops at four waves per SIMD anyway.
 // Geometry for n = 4096, measured: (C,T) = (16,256) 94 us, (8,512) 137, (4,1024)
 // 256, (32,128) 115 (206 VGPRs): cross-wave phases grow with T, serial ones with C.
-__global__ __launch_bounds__(T, (MODE == 2 || C >= 14) ? 4 : 5)   // VGPR cap per waves/SIMD: 4 -> 128, 5 -> 96
+__global__ __launch_bounds__(T, (MODE == 2 || C >= 18 || (C >= 14 && T > 256)) ? 4 : 5)
 void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ smp_all,
                    const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                    const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,

@@ -1000,9 +1000,10 @@ struct FastLds {
 // Emit window of the fast path, in words: a section of typical density fits one
 // window (n/2 words = 16 bits per sample, rounded up to a power of two); denser
 // sections take more passes.  Small blocks thus leave LDS for more workgroups.
-// wide: 32 bits per sample up to 128 Kbit, for the instances that run four workgroups per CU
-// anyway (MODE 2 / 3) on samples wider than 16 bits -- a 24-bit section of ~19 bits per sample
-// then takes one pass instead of two.
+// wide: 32 bits per sample up to 128 Kbit, for the instance that runs four workgroups per CU
+// anyway (MODE 2, VGPRs) on samples wider than 16 bits -- a 24-bit section of ~19 bits per sample
+// then takes one pass instead of two.  (MODE 3 had it too while it ran four waves per SIMD; at
+// five the 8 KB it costs are a workgroup per CU: configs[3] K3 420 -> 390 us without it.)
 __host__ __device__ inline int fast_window_words(int n, bool wide = false)
 {
     int w = 256;
@@ -1010,7 +1011,7 @@ __host__ __device__ inline int fast_window_words(int n, bool wide = false)
     while (w < ENC_WWORDS && 2 * w < n) w <<= 1;
     return w;
 }
-__host__ __device__ inline bool fast_wide_window(int mode, int bps) { return mode >= 2 && bps > 16; }
+__host__ __device__ inline bool fast_wide_window(int mode, int bps) { return mode == 2 && bps > 16; }
 
 __host__ __device__ inline size_t fast_lds_layout(int n, size_t img_doubles, size_t off[11], bool wide = false)
 {

@@ -2877,7 +2877,8 @@ bool fast_geometry(const fhip_params &p, int n, int *C, int *T)
 // no K1 at all) and a K3 fast-path geometry with runs of 8 or 16 samples.
 bool narrow_rows_ok(const fhip_params &p, int nsub, int n, bool lpc_path)
 {
-    static const bool off = getenv("FHIP_NO_NARROW") != nullptr;        // measurements only
+    // measurements only (the generic K3 forced onto a fast-path geometry reads int32 rows)
+    static const bool off = getenv("FHIP_NO_NARROW") != nullptr || getenv("FHIP_K3_GENERIC") != nullptr;
     if (off || p.channels != 2 || (n & 3) != 0 || n > 8192) return false;
     int fc = 0, ft = 0;
     if (!fast_geometry(p, n, &fc, &ft) || (fc % 8) != 0) return false;

@@ -162,8 +162,8 @@ void k_lpc(const double *__restrict__ autoc_all, int nsub, int max_order, int pr
         for (int j = 0; j < max_order; j++) f[j] = (j < levinson_order) ? src[j] : 0;
         f[32] = srow[levinson_order - 1];
         f[33] = levinson_order;
-        double *fd = reinterpret_cast<double *>(f + FIN_DBL);     // the first 8 as doubles (K3 reads them as scalars)
-        for (int j = 0; j < 8; j++) fd[j] = (j < levinson_order && j < max_order) ? (double)src[j] : 0.0;
+        double *fd = reinterpret_cast<double *>(f + FIN_DBL);     // the first 16 as doubles (K3 reads them as scalars)
+        for (int j = 0; j < 16; j++) fd[j] = (j < levinson_order && j < max_order) ? (double)src[j] : 0.0;
         int32_t cabs = 0, c8[8];
         for (int j = 0; j < 8; j++) c8[j] = (j < levinson_order && j < max_order) ? src[j] : 0;
         for (int j = 0; j < levinson_order; j++) cabs += (src[j] < 0) ? -src[j] : src[j];

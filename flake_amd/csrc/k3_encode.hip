@@ -1188,6 +1188,54 @@ __device__ __forceinline__ void fir_lpc_o8(const FastCtx<C, T> &e, int32_t (&r)[
     }
 }
 
+// Orders 9 .. 16 on a row known up front (MODE 3), the coefficients again as wave-uniform
+// doubles from K2's compact row (scalar loads; TAPS = 12 or 16 of them, zero past the order): no
+// coefficient reads from the LDS (one per tap and block of eight outputs in fir_lpc), and ONE
+// window of TAPS + 7 samples per block of eight outputs instead of one per eight taps.
+template <int C, int T, int TAPS>
+__device__ __forceinline__ void fir_lpc_o16(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
+                                            const double *__restrict__ cd)
+{
+    using Img = SmpImg<C, T>;
+    static_assert(Img::V4 && C % 8 == 0 && (TAPS == 12 || TAPS == 16), "fir_lpc_o16: runs of 8 or 16");
+    const double inv = __builtin_ldexp(1.0, -shift);
+    const int32_t *mine = e.l.smp + e.tid * Img::CS;
+    double cf[TAPS];
+#pragma unroll
+    for (int jj = 0; jj < TAPS; jj++) cf[jj] = cd[jj];
+#pragma unroll
+    for (int ob = 0; ob < C; ob += 8) {
+        __builtin_amdgcn_sched_barrier(0);
+        double acc[8];
+#pragma unroll
+        for (int o = 0; o < 8; o++) acc[o] = 0.0;
+        double W[TAPS + 8];                                // samples ob-TAPS .. ob+7 (the last one unused)
+#pragma unroll
+        for (int m4 = 0; m4 < TAPS + 8; m4 += 4) {
+            const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob - TAPS + m4));
+            W[m4] = (double)v.x; W[m4 + 1] = (double)v.y; W[m4 + 2] = (double)v.z; W[m4 + 3] = (double)v.w;
+        }
+#pragma unroll
+        for (int jj = 0; jj < TAPS; jj++)
+#pragma unroll
+            for (int o = 0; o < 8; o++)
+                acc[o] = __builtin_fma(cf[jj], W[o + TAPS - 1 - jj], acc[o]);      // tap jj+1: sample ob+o-(jj+1)
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+            const double z = __builtin_fma(acc[o], inv, 6755399441055744.0);   // floor under round-down, see fir_lpc
+            const uint32_t qlo = (uint32_t)__double2loint(z);
+            const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob + (o & ~3)));
+            const uint32_t x = (uint32_t)((o & 3) == 0 ? v.x : (o & 3) == 1 ? v.y : (o & 3) == 2 ? v.z : v.w);
+            r[ob + o] = (int32_t)(x - qlo);
+        }
+    }
+    if (e.i0 < order) {
+#pragma unroll
+        for (int o = 0; o < C; o++)
+            if (e.i0 + o < order) r[o] = mine[Img::off(o)];
+    }
+}
+
 template <int C, int T, int NP>
 __device__ __forceinline__ void fir_lpc_dotn(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
                                              const int32_t *__restrict__ cp);
@@ -1950,8 +1998,15 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                 } else if (pre_row && ord <= 8)
                     fir_lpc_o8<C, T>(e, r, ord, cshift,
                                      reinterpret_cast<const double *>(fin_all + (size_t)s * FIN_STRIDE + FIN_DBL));
-                else if constexpr (MODE != 0)
-                    fir_lpc<C, T>(e, r, ord, cshift);     // (MODE 0 is launched for maximum orders <= 8 only)
+                else if constexpr (MODE != 0) {
+                    bool wide_done = false;
+                    if constexpr (MODE == 3 && C % 8 == 0) {
+                        const double *cd = reinterpret_cast<const double *>(fin_all + (size_t)s * FIN_STRIDE + FIN_DBL);
+                        if (ord <= 12) { fir_lpc_o16<C, T, 12>(e, r, ord, cshift, cd); wide_done = true; }
+                        else if (ord <= 16) { fir_lpc_o16<C, T, 16>(e, r, ord, cshift, cd); wide_done = true; }
+                    }
+                    if (!wide_done) fir_lpc<C, T>(e, r, ord, cshift);     // (MODE 0 is launched for maximum orders <= 8 only)
+                }
                 STAMP(3);
                 b = rice_search_fast<C, T>(e, r, u, ord, true, &porder, &method, &umax_run);
                 STAMP(8);
@@ -2810,10 +2865,8 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         sa += __shfl_xor(sa, 4, WAVE); sa += __shfl_xor(sa, 8, WAVE);
         sa += __shfl_xor(sa, 16, WAVE);
         const int32_t nb = __shfl_xor(cv, 1, WAVE);
-        if (tid < 8) {
-            reinterpret_cast<double *>(f + FIN_DBL)[tid] = (double)cv;
-            if ((tid & 1) == 0) f[FIN_PAIRS + (tid >> 1)] = (nb & 0xFFFF) | (int32_t)((uint32_t)cv << 16);
-        }
+        if (tid < 16) reinterpret_cast<double *>(f + FIN_DBL)[tid] = (double)cv;
+        if (tid < 8 && (tid & 1) == 0) f[FIN_PAIRS + (tid >> 1)] = (nb & 0xFFFF) | (int32_t)((uint32_t)cv << 16);
         if (tid == 0) {
             f[32] = srow[best];
             f[33] = order;

@@ -56,9 +56,10 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
 // coefs [nsub][32][32], shift [nsub][32], opt_order [nsub].
 // fin [nsub][FIN_STRIDE]: for the MAX/EST order methods the one row the
 // reference quantises, compact: coefs[0..32), shift, order (prefetched by K3).
-constexpr int FIN_STRIDE = 56;      // int32 per row: 32 coefs, shift, order, sum|coef|, 1 spare,
-constexpr int FIN_DBL = 36;         // ... the first 8 coefficients once more as doubles,
-constexpr int FIN_PAIRS = 52;       // ... and as four int16 pairs (lo: tap 2j+2, hi: tap 2j+1)
+constexpr int FIN_STRIDE = 72;      // int32 per row: 32 coefs, shift, order, sum|coef|, 1 spare,
+constexpr int FIN_DBL = 36;         // ... the first 16 coefficients once more as doubles (zero past the order:
+                                    //     K3 reads them by scalar loads, they never touch a vector register),
+constexpr int FIN_PAIRS = 68;       // ... and the first 8 as four int16 pairs (lo: tap 2j+2, hi: tap 2j+1)
 hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_order,
                       int precision, int omethod, int32_t *coefs, int32_t *shift,
                       int32_t *opt_order, int32_t *fin);

@@ -37,7 +37,7 @@ __device__ __forceinline__ void quantize_row_reg(const double (&a)[MO], int orde
             fin_out[33] = order;
             double *fd = reinterpret_cast<double *>(fin_out + FIN_DBL);
 #pragma unroll
-            for (int j = 0; j < 8; j++) fd[j] = 0.0;
+            for (int j = 0; j < 16; j++) fd[j] = 0.0;
             fin_out[34] = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) fin_out[FIN_PAIRS + j] = 0;
@@ -69,12 +69,16 @@ __device__ __forceinline__ void quantize_row_reg(const double (&a)[MO], int orde
             if (j < 8) c8[j] = q;
             if (fin_out) {
                 fin_out[j] = q;
-                if (j < 8) reinterpret_cast<double *>(fin_out + FIN_DBL)[j] = (double)q;
+                if (j < 16) reinterpret_cast<double *>(fin_out + FIN_DBL)[j] = (double)q;
             }
         } else if (fin_out) {
             if (j < max_order) fin_out[j] = 0;
-            if (j < 8) reinterpret_cast<double *>(fin_out + FIN_DBL)[j] = 0.0;
+            if (j < 16) reinterpret_cast<double *>(fin_out + FIN_DBL)[j] = 0.0;
         }
+    }
+    if (fin_out) {
+#pragma unroll
+        for (int j = MO; j < 16; j++) reinterpret_cast<double *>(fin_out + FIN_DBL)[j] = 0.0;
     }
     *shift_out = sh;
     if (fin_out) {

@@ -80,6 +80,21 @@ def test_order_methods_on_edge_blocks(oracle, ref, om):
             assert_subframe(sf, res, rep, n, f"om{om} n{n} {k}")
 
 
+def test_log_walk_every_order_range(oracle, ref):
+    """LOG (optimize.c:239-261) for every (min, max) prediction-order pair: the walk the HIP
+    search kernel merges steps of (tests/test_gpu_parity.py, same name) must be the reference's."""
+    b = edge_blocks(1152, 16)
+    blocks = [b["sine_plus_noise"], b["decay"]]
+    for lo in range(1, 33):
+        for hi in range(lo, 33):
+            p = flake_amd.level_params(5, channels=1, order_method=flake_amd.OM_LOG, min_prediction_order=lo,
+                                       max_prediction_order=hi, max_partition_order=6)
+            smp = blocks[(lo + hi) & 1]
+            rc, sf, res = oracle.encode_residual(p, smp, 16)
+            rep = refreplay.encode_residual(ref, p, smp, 16)
+            assert_subframe(sf, res, rep, 1152, f"LOG {lo}..{hi}")
+
+
 def test_fixed_ranges_and_partition_ranges(oracle, ref):
     b = edge_blocks(1152, 16)
     blocks = [b[k] for k in ("sine_plus_noise", "white", "decay", "ramp", "small_noise")]

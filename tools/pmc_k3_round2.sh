@@ -1,0 +1,19 @@
+# SQ counters of the headline kernels (two passes; rocprofv3 --pmc with --kernel-trace only)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d gpurun_out/sq1 -- python3 bench.py --steps 3 --warmup 1 --settle-ms 0 --profile-steps 0 --no-cpu-baseline --no-other-configs > gpurun_out/sq1.log 2>&1; echo sq1 rc $?
+rocprofv3 --pmc SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU --kernel-trace --output-format csv -d gpurun_out/sq2 -- python3 bench.py --steps 3 --warmup 1 --settle-ms 0 --profile-steps 0 --no-cpu-baseline --no-other-configs > gpurun_out/sq2.log 2>&1; echo sq2 rc $?
+python tools/pmc_sum.py gpurun_out/sq1
+python - <<'PY'
+import csv,glob,collections,re
+f=glob.glob("gpurun_out/sq2/**/*_counter_collection.csv",recursive=True)[0]
+agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
+seen=set()
+for r in csv.DictReader(open(f)):
+    m=re.search(r"(k_\w+)",r["Kernel_Name"])
+    if not m: continue
+    agg[m.group(1)][r["Counter_Name"]]+=float(r["Counter_Value"])
+    if (r["Dispatch_Id"]) not in seen: seen.add(r["Dispatch_Id"]); n[m.group(1)]+=1
+for k,g in agg.items():
+    w=g["SQ_WAVES"] or 1
+    print(k, "x%d"%n[k], {c: round(v/w,1) for c,v in g.items() if c!="SQ_WAVES"})
+PY

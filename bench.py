@@ -487,7 +487,8 @@ def main():
     enc.set_stream(stream.cuda_stream)
     # gloo reduces host tensors; RCCL device tensors
     cdev = dev if (not use_dist or backend == "nccl") else torch.device("cpu")
-    stats = torch.zeros(3, dtype=torch.int64, device=cdev)
+    # the job's counters: a host tensor unless RCCL is going to reduce them
+    stats = torch.zeros(3, dtype=torch.int64, device=cdev if use_dist else torch.device("cpu"))
 
     ahead = args.ahead
     count = [0]
@@ -513,9 +514,12 @@ def main():
         (the same resident input every step: the totals do not change); the records of the step
         timed last are read back once more behind the closing fence and must say the same."""
         last = (count[0] - 1) % 2
-        stats[0] = nframes * steps
-        stats[1] = batch_bits[last] * ((steps + 1) // 2) + batch_bits[last ^ 1] * (steps // 2)
-        stats[2] = 1                                   # ranks_seen
+        # (one host tensor, one copy: element-wise writes into a device tensor would each be a
+        # kernel launch inside the timed region)
+        mine = torch.tensor([nframes * steps,
+                             batch_bits[last] * ((steps + 1) // 2) + batch_bits[last ^ 1] * (steps // 2),
+                             1], dtype=torch.int64)                       # [2]: ranks_seen
+        stats.copy_(mine)
         if use_dist:
             dist.all_reduce(stats)
 

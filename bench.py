@@ -602,12 +602,16 @@ def main():
             # figure belongs to the code state named in traffic_source, not to this run
             traffic = None
             traffic_source = None
+            traffic_current = None
             tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tp) and args.workload == "configs[1]":     # counters taken on configs[1]
                 try:
                     tj = json.load(open(tp))
                     traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
                     traffic_source = f"profiles/pmc_traffic.json, tag {tj.get('_tag')}"
+                    from flake_amd.srcid import kernel_sources_sha1
+                    # true when the counters were taken with exactly these kernel sources
+                    traffic_current = (tj.get("_src_sha1") == kernel_sources_sha1())
                 except Exception:
                     traffic = None
             roofline = {
@@ -615,6 +619,7 @@ def main():
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": traffic_source,
+                "traffic_current": traffic_current,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": {k: round(v, 4) for k, v in per.items()},
                 # with the next batch's k_prepare hinted ahead it runs on a stream of its own

@@ -15,7 +15,10 @@ f = avg(one(fetch, '*counter_collection.csv'), 'FETCH_SIZE')
 w = avg(one(write, '*counter_collection.csv'), 'WRITE_SIZE')
 names = {'k_prepare': 'k_prepare_stereo', 'k_autocorr': 'k_autocorr_wt', 'k_encode': 'k_encode_pow2'}
 old = json.load(open(f'{R}/profiles/pmc_traffic.json'))
-out = {"_note": old["_note"], "_calibration": old["_calibration"], "_tag": tag}
+sys.path.insert(0, R)
+from flake_amd.srcid import kernel_sources_sha1
+out = {"_note": old["_note"], "_calibration": old["_calibration"], "_tag": tag,
+       "_src_sha1": kernel_sources_sha1()}     # the kernel sources these counters were measured with
 for short, sym in names.items():
     fk = next((v for k, v in f.items() if sym in k), 0.0)
     wk = next((v for k, v in w.items() if sym in k), 0.0)

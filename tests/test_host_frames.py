@@ -81,6 +81,39 @@ def test_vbs_levels(oracle, decoder, level):
         assert len(bs) > 6 and (bs % (n // 8) == 0).all()
 
 
+@pytest.mark.parametrize("level,nblocks", [(10, 3072), (12, 2048)])
+def test_vbs_large_corpus_properties(oracle, decoder, level, nblocks):
+    """BASELINE configs[4] at a corpus size the oracle cannot follow in test time (33.5 M samples
+    at level 12): size-independent properties of the whole stream -- it decodes to the input
+    (independent decoder), STREAMINFO carries the input's MD5 (the sample count is the caller's to
+    fill in, as in libflake), every frame is a
+    multiple of n/8 samples, split blocks exist -- plus byte equality with the oracle's stream on
+    the corpus' first blocks encoded as a stream of their own (VBS frame numbers count samples
+    from the stream's start, so a prefix of the corpus is a stream the oracle can check)."""
+    with flake_amd.HostEncoder(level) as enc:
+        p = enc.params()
+        n = p.block_size
+        pcm = flake_amd.synth_pcm(nblocks, n, 2, 16)
+        for b in range(0, nblocks, 3):          # every third block: a quiet first part, loud rest
+            cut = (1 + b % 7) * n // 8
+            pcm[b, :cut] //= 64
+        pcm = pcm.reshape(-1, 2)
+        data, sizes = enc.encode_frames(pcm, n)
+        si = enc.streaminfo()
+        assert bytes(si.md5sum) == pcm_md5(pcm, 16)
+        assert sizes.sum() == data.size and si.max_frame_size >= sizes.max()
+        out, bs = decoder.decode(data, 2, 16, pcm.shape[0])
+        assert (out == pcm).all()
+        assert bs.sum() == pcm.shape[0] and (bs % (n // 8) == 0).all()
+        assert len(bs) > nblocks + nblocks // 6                 # the forced splits happened
+    npre = 6
+    with flake_amd.HostEncoder(level) as enc:
+        pre, psizes = enc.encode_frames(pcm[:npre * n], n)
+        exp, esizes = oracle_stream(oracle, enc.params(), pcm[:npre * n], n)
+        assert (psizes == esizes).all() and pre.tobytes() == exp.tobytes()
+    assert data[:pre.size].tobytes() == pre.tobytes()            # the corpus starts with that stream
+
+
 def test_verbatim_fallback_and_constant(oracle, decoder):
     r = _rng(4)
     n = 4096

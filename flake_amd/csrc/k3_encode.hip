@@ -2904,8 +2904,9 @@ bool fast_geometry(const fhip_params &p, int n, int *C, int *T)
         // 256 threads where the block allows (measured at 4608: (18,256) 84 us, (9,512) 100)
         c = 9; t = 1 << lg;
         if (t >= 512) { c = 18; t >>= 1; }
-    } else if (odd == 3) {                // 192, 384, 768, 1536, ...
+    } else if (odd == 3) {                // 192, 384, 768, 1536, 3072; 6144 (six eighths of an 8192 block)
         c = 3; t = 1 << lg;
+        if (t > 1024) { c = 6; t >>= 1; }
         if (t > 1024) { c = 0; }
     } else if ((odd == 5 || odd == 7) && (lg == 9 || lg == 10)) {
         // 2560, 3584, 5120, 7168: five or seven eighths of a 4096 / 8192 block, the pieces
@@ -3004,6 +3005,7 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
         case 30256: LAUNCH_FAST(3, 256); break;
         case 30512: LAUNCH_FAST(3, 512); break;
         case 31024: LAUNCH_FAST(3, 1024); break;
+        case 61024: LAUNCH_FAST(6, 1024); break;
         default: return hipErrorInvalidValue;
         }
 #undef LAUNCH_FAST

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "flakehip.h"
@@ -49,8 +50,9 @@ struct fhip_ctx {
     int32_t *d_glen = nullptr, *d_order = nullptr;
 
     // two internal streams for the split-batch overlap (run_pipeline)
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    static constexpr int NAUX = 4;       // (run_pipeline's split uses the first two, the VBS groups all)
+    hipStream_t aux[NAUX] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[NAUX] = {nullptr, nullptr, nullptr, nullptr};
     bool overlap = false;     // measured slower on C2 (K1 is chain-length bound): opt-in, FHIP_OVERLAP=1
 
     // fhip_prepare_ahead: K0 of the NEXT batch on its own stream while this batch's K1 runs.
@@ -408,7 +410,7 @@ int fhip_create(fhip_ctx **out, int device, const fhip_params *p, int max_frames
     const size_t n = (size_t)p->block_size;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    for (int h = 0; h < 2 && e == hipSuccess; h++) {
+    for (int h = 0; h < fhip_ctx::NAUX && e == hipSuccess; h++) {
         e = hipStreamCreateWithFlags(&c->aux[h], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[h], hipEventDisableTiming);
     }
@@ -452,7 +454,7 @@ void fhip_destroy(fhip_ctx *c)
                     c->d_packed, c->d_offsets, c->d_gather, c->d_gsrc, c->d_gdst, c->d_srcoff,
                     c->d_glen, c->d_order};
     for (void *b : bufs) if (b) (void)hipFree(b);
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < fhip_ctx::NAUX; h++) {
         if (c->aux[h]) { (void)hipStreamSynchronize(c->aux[h]); (void)hipStreamDestroy(c->aux[h]); }
         if (c->ev_join[h]) (void)hipEventDestroy(c->ev_join[h]);
     }
@@ -846,11 +848,50 @@ int fhip_encode_blocks_vbs_packed(fhip_ctx *c, const int32_t *pcm, int nblocks, 
     HIP_TRY(c, fhip::launch_gather_pieces(c->stream, c->d_pcm, c->d_gsrc, c->d_gdst, c->d_glen, np, c->d_gather));
 
     // ---- one pass of the path per group, all on the device ----
-    for (const auto &g : groups) {
+    // A group is a few hundred frames -- too few workgroups to fill the chip, and eight groups one
+    // behind the other pay eight times the latency of the path's six launches.  The groups touch
+    // disjoint ranges of every buffer (run_range's sub0), so they fan out over the handle's
+    // internal streams, the heavier ones first, each to the stream with least work queued
+    // (samples x candidates is not known here: samples), and join the caller's stream again.
+    static const bool vbs_serial = getenv("FHIP_VBS_SERIAL") != nullptr;          // measurements only
+    constexpr int NA = fhip_ctx::NAUX;
+    // (measured per 1024 blocks, levels 9 / 10 / 12: one stream 2.7 / 2.8 / 5.4 ms, two 2.1 / 2.3 / 4.7,
+    // three 2.0 / 2.2 / 4.2, four 2.2 / 2.1 / 4.3)
+    static const int vbs_streams = getenv("FHIP_VBS_STREAMS") ? std::max(2, std::min(NA, atoi(getenv("FHIP_VBS_STREAMS")))) : 3;
+    bool fan = !vbs_serial && !c->profiling && groups.size() > 1;
+    for (int h = 0; h < vbs_streams; h++) fan = fan && c->aux[h];
+    if (fan) {
+        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+        for (int h = 0; h < vbs_streams; h++) HIP_TRY(c, hipStreamWaitEvent(c->aux[h], c->ev_fork, 0));
+    }
+    std::vector<size_t> by_work(groups.size());
+    for (size_t j = 0; j < groups.size(); j++) by_work[j] = j;
+    if (fan)
+        std::stable_sort(by_work.begin(), by_work.end(), [&](size_t a, size_t b) {
+            return (long long)groups[a].cnt * groups[a].n > (long long)groups[b].cnt * groups[b].n; });
+    long long queued[NA] = {0};
+    for (size_t j : by_work) {
+        const auto &g = groups[j];
         const FrameOut fo{c->d_frames + g.fr_off, g.stride, c->d_fbytes + g.slot0, 0, c->d_fnum + g.slot0};
-        rc = run_pipeline(c, c->d_gather + g.goff, g.cnt, g.n, c->d_info + (size_t)g.slot0 * nch, nullptr,
-                          c->d_bits + g.b_off, g.slot, nullptr, nullptr, fo, false);
+        const size_t sub0 = (size_t)g.slot0 * nch;
+        if (fan) {
+            int h = 0;
+            for (int q = 1; q < vbs_streams; q++) if (queued[q] < queued[h]) h = q;
+            queued[h] += (long long)g.cnt * g.n;
+            rc = run_range(c, c->aux[h], false, c->d_gather + g.goff, g.cnt, g.n, c->d_info + sub0, nullptr,
+                           c->d_bits + g.b_off, g.slot, c->d_smp + g.goff, c->d_autoc + sub0 * FHIP_MAX_LAGS, sub0,
+                           fo, false);
+        } else {
+            rc = run_pipeline(c, c->d_gather + g.goff, g.cnt, g.n, c->d_info + sub0, nullptr,
+                              c->d_bits + g.b_off, g.slot, nullptr, nullptr, fo, false);
+        }
         if (rc != FHIP_OK) return rc;
+    }
+    if (fan) {
+        for (int h = 0; h < vbs_streams; h++) {
+            HIP_TRY(c, hipEventRecord(c->ev_join[h], c->aux[h]));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join[h], 0));
+        }
     }
     HIP_TRY(c, fhip::launch_pack_frames_perm(c->stream, c->d_frames, c->d_srcoff, c->d_fbytes, c->d_order, np,
                                              c->d_offsets, c->d_packed));

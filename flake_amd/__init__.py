@@ -118,6 +118,12 @@ class Batch(C.Structure):
     ]
 
 
+class VbsOut(C.Structure):
+    """``fhip_vbs_out`` (device pointers)"""
+    _fields_ = [("packed", C.c_void_p), ("packed_cap", C.c_int64), ("frame_bytes", C.c_void_p),
+                ("block_bytes", C.c_void_p), ("block_frames", C.c_void_p), ("totals", C.c_void_p)]
+
+
 class FlakeHipError(RuntimeError):
     def __init__(self, code: int, what: str, detail: str = ""):
         self.code = code
@@ -157,6 +163,7 @@ def load_library() -> C.CDLL:
         "fhip_frames_packed_fetch": (i, [vp, vp, i64]),
         "fhip_encode_blocks_vbs_packed": (i, [vp, vp, i, i, C.c_uint32, vp, i64, vp, vp, C.POINTER(i64),
                                               C.POINTER(i), C.POINTER(C.c_uint32)]),
+        "fhip_encode_blocks_vbs_dev": (i, [vp, vp, i, i, C.c_uint32, C.POINTER(VbsOut)]),
         "fhip_lpc_calc_coefs": (i, [vp, vp, i, i, i, i, i, vp, vp, vp, vp]),
         "fhip_encode_residual": (i, [vp, vp, i, i, vp, vp, vp, i64]),
         "fhip_prepare_frames": (i, [vp, vp, i, i, vp, vp]),
@@ -181,6 +188,7 @@ ABI_SYMBOLS = (
     "fhip_prepare_frames", "fhip_calc_rice_params", "fhip_vbs_split", "fhip_set_profiling",
     "fhip_get_kernel_times", "fhip_prepare_ahead", "fhip_encode_frames_packed",
     "fhip_frames_packed_begin", "fhip_frames_packed_fetch", "fhip_encode_blocks_vbs_packed",
+    "fhip_encode_blocks_vbs_dev",
 )
 
 
@@ -270,6 +278,16 @@ class Encoder:
                   _ptr(frame_bytes), first_frame_number, None)
         self._check(self.lib.fhip_encode_subframes_dev(self._h, C.byref(b)),
                     "fhip_encode_subframes_dev")
+
+    def encode_blocks_vbs_dev(self, pcm, nblocks: int, block_size: int, packed, packed_cap: int, totals,
+                              frame_bytes=None, block_bytes=None, block_frames=None,
+                              first_frame_number: int = 0) -> None:
+        """Device-resident variable-block-size batch (vbs.c:85-119 per block); async, no host sync."""
+        o = VbsOut(_ptr(packed), packed_cap, _ptr(frame_bytes), _ptr(block_bytes), _ptr(block_frames),
+                   _ptr(totals))
+        self._check(self.lib.fhip_encode_blocks_vbs_dev(self._h, _ptr(pcm), nblocks, block_size,
+                                                        first_frame_number, C.byref(o)),
+                    "fhip_encode_blocks_vbs_dev")
 
     def prepare_ahead(self, pcm, nframes: int, block_size: int) -> None:
         """Hint: start the feeder stage (K0) of the NEXT device-resident batch now, beside the

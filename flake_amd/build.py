@@ -23,7 +23,7 @@ HIP_SRCS = ["csrc/k0_prepare.hip", "csrc/k1_autocorr.hip", "csrc/k2_lpc.hip", "c
 HIP_HDRS = ["csrc/kernels.h", "csrc/device_util.h", "csrc/lpc_reg.h", "../include/flakehip.h"]
 HIP_DEPS = HIP_SRCS + HIP_HDRS
 HOST_SRCS = ["host/flake_host.c", "host/synth.c", "host/md5.c"]
-HOST_DEPS = HOST_SRCS + ["../include/flakehip.h", "../include/flake_amd.h"]
+HOST_DEPS = HOST_SRCS + ["host/host_internal.h", "../include/flakehip.h", "../include/flake_amd.h"]
 
 # -ffp-contract=off is load-bearing: the fp64 LPC stages must round after every
 # multiply and add to reproduce the reference bit for bit.

@@ -44,10 +44,12 @@ struct fhip_ctx {
     size_t d_packed_bytes = 0;
     long long *d_offsets = nullptr;   // [max_frames + 1]
     long long packed_ready = 0;       // bytes waiting in d_packed between _begin and _fetch
-    // fhip_encode_blocks_vbs_packed: group-contiguous copy of the pieces and the piece tables
-    int32_t *d_gather = nullptr;
-    long long *d_gsrc = nullptr, *d_gdst = nullptr, *d_srcoff = nullptr;
-    int32_t *d_glen = nullptr, *d_order = nullptr;
+    // variable-block-size batches (fhip_encode_blocks_vbs_dev): the piece tables k_vbs_plan leaves
+    size_t ws_frames = 0;             // frame capacity of the subframe-indexed workspaces (>= max_frames:
+                                      // a VBS handle has 20 slots per block, eight bins of fixed capacity)
+    long long *d_srcoff = nullptr, *d_frame_src = nullptr, *d_totals = nullptr;
+    int32_t *d_order = nullptr, *d_vcnt = nullptr, *d_first = nullptr;
+    int32_t *d_stream_bytes = nullptr, *d_blk_bytes = nullptr, *d_blk_frames = nullptr;
 
     // two internal streams for the split-batch overlap (run_pipeline)
     static constexpr int NAUX = 4;       // (run_pipeline's split uses the first two, the VBS groups all)
@@ -193,15 +195,23 @@ void drain_profile(fhip_ctx *c)
 // The four launches of one range of frames.  All pointers are device pointers
 // and already offset to the range; `prof` brackets each launch with events.
 struct FrameOut { uint8_t *frames; int64_t stride; int32_t *bytes; uint32_t first; const uint32_t *numbers = nullptr; };
+// One bin of a variable-block-size batch: its pieces lie where the caller's blocks lie (frame_src),
+// their number is on the device (dev_frames / dev_sub); nframes is then the bin's capacity and
+// hint_frames the count the host-side choices (which K1, 16-bit rows) are made for.
+struct Ragged { const long long *frame_src; const int32_t *dev_frames, *dev_sub; int hint_frames; };
 
 static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm, int nframes, int n,
                      fhip_subframe_info *info, int32_t *residual, uint8_t *bits,
                      int64_t slot_bytes, int32_t *smp, double *autoc, size_t sub0,
                      const FrameOut &fo, bool want_rows = false,
-                     const fhip_subframe_info *prepared = nullptr, bool prepared_narrow = false)
+                     const fhip_subframe_info *prepared = nullptr, bool prepared_narrow = false,
+                     const Ragged *rg = nullptr)
 {
     const fhip_params &p = c->p;
     const int nsub = nframes * p.channels;
+    const int nsub_hint = rg ? rg->hint_frames * p.channels : nsub;
+    const long long *frame_src = rg ? rg->frame_src : nullptr;
+    const int32_t *dev_frames = rg ? rg->dev_frames : nullptr, *dev_sub = rg ? rg->dev_sub : nullptr;
     const bool lpc_path = (p.prediction_type == 2) && (n > p.max_prediction_order) && n >= 5;
     int32_t *coefs = c->d_coefs + sub0 * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
     int32_t *shift = c->d_shift + sub0 * FHIP_MAX_ORDER;
@@ -215,32 +225,32 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
     // stereo batches in whole tiles: K0 only decides (ch_mode, wasted bits), the K1
     // producers apply that to the PCM they stream anyway and write smp
     // `prepared`: K0 of this batch already ran (fhip_prepare_ahead) into smp and these records
-    const bool fused = !prepared && lpc_path && fhip::autocorr_fuses_prepare(p, nsub, n);
+    const bool fused = !prepared && !rg && lpc_path && fhip::autocorr_fuses_prepare(p, nsub, n);
     // rows of 16-bit samples where every kernel of this batch reads them that way and
     // nobody outside asked for the int32 rows
     const bool narrow = prepared ? prepared_narrow
-                                 : (!fused && !want_rows && fhip::narrow_rows_ok(p, nsub, n, lpc_path));
+                                 : (!fused && !want_rows && fhip::narrow_rows_ok(p, nsub_hint, n, lpc_path));
     // K0's records never live in the caller's info[] (K3's pointers to the two do not alias)
     fhip_subframe_info *own_rec = c->d_k0rec + sub0;
     const fhip_subframe_info *k0rec = prepared ? prepared : own_rec;
     if (!prepared) {
         MaybeProf pr(c, prof, 0);
-        HIP_TRY(c, fhip::launch_prepare(st, p, pcm, nframes, n, smp, own_rec, fused, narrow));
+        HIP_TRY(c, fhip::launch_prepare(st, p, pcm, nframes, n, smp, own_rec, fused, narrow, frame_src, dev_frames));
     }
     if (lpc_path) {
         // K2 rides on K1's tail where K1 is the wave-typed kernel and the order fits registers
-        const bool lpc_tail = !fused && fhip::autocorr_does_lpc(nsub, n, p.max_prediction_order);
+        const bool lpc_tail = !fused && fhip::autocorr_does_lpc(nsub_hint, n, p.max_prediction_order);
         const fhip::autocorr_lpc_out lo{p.lpc_precision, p.order_method, coefs, shift, opt, fin};
         {
             MaybeProf pr(c, prof, 1);
             HIP_TRY(c, fhip::launch_autocorr(st, smp, nsub, n, p.max_prediction_order, autoc,
                                              fused ? pcm : nullptr, fused ? smp : nullptr, k0rec,
-                                             lpc_tail ? &lo : nullptr, narrow));
+                                             lpc_tail ? &lo : nullptr, narrow, dev_sub, nsub_hint));
         }
         if (!lpc_tail) {
             MaybeProf pr(c, prof, 2);
             HIP_TRY(c, fhip::launch_lpc(st, autoc, nsub, p.max_prediction_order, p.lpc_precision,
-                                        p.order_method, coefs, shift, opt, fin));
+                                        p.order_method, coefs, shift, opt, fin, dev_sub));
         }
     }
     if (c->ev_k1 && st == c->stream) {
@@ -252,18 +262,18 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
     const bool searched = lpc_path && fhip::order_search_supported(p, n);
     if (searched) {
         MaybeProf pr(c, prof, 5);
-        HIP_TRY(c, fhip::launch_order_search(st, p, smp, nsub, n, coefs, shift, opt, fin, k0rec, narrow));
+        HIP_TRY(c, fhip::launch_order_search(st, p, smp, nsub, n, coefs, shift, opt, fin, k0rec, narrow, dev_sub));
     }
     {
         MaybeProf pr(c, prof, 3);
         HIP_TRY(c, fhip::launch_encode(st, p, smp, nsub, n, coefs, shift, opt, fin, info, residual,
-                                       bits, slot_bytes, -1, 0, narrow, k0rec, searched));
+                                       bits, slot_bytes, -1, 0, narrow, k0rec, searched, dev_sub));
     }
     if (fo.frames) {
         MaybeProf pr(c, prof, 4);
         const uint32_t step = p.allow_vbs ? (uint32_t)n : 1u;
         HIP_TRY(c, fhip::launch_assemble(st, p, pcm, nframes, n, info, bits, slot_bytes, fo.frames,
-                                         fo.stride, fo.bytes, fo.first, step, fo.numbers));
+                                         fo.stride, fo.bytes, fo.first, step, fo.numbers, frame_src, dev_frames));
     }
     return FHIP_OK;
 }
@@ -406,7 +416,13 @@ int fhip_create(fhip_ctx **out, int device, const fhip_params *p, int max_frames
     c->max_frames = max_frames;
     for (int i = 0; i < 6; i++) c->ktimes.push_back({kKernelNames[i], 0.0, 0});
 
-    const size_t nsub = (size_t)max_frames * p->channels;
+    // subframe-indexed workspaces: a variable-block-size handle keeps eight bins of fixed capacity
+    // (pieces of k eighths: floor(8 / k) per block, 20 slots per block in all); the sample-indexed
+    // ones need no more than before (a bin's pieces never exceed its blocks' samples)
+    c->ws_frames = p->variable_block_size ? (size_t)20 * (((size_t)max_frames + 7) / 8) : (size_t)max_frames;
+    if (c->ws_frames < (size_t)max_frames) c->ws_frames = (size_t)max_frames;
+    const size_t nsub = c->ws_frames * p->channels;
+    const size_t nsmp = (size_t)max_frames * p->channels;
     const size_t n = (size_t)p->block_size;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
@@ -416,7 +432,7 @@ int fhip_create(fhip_ctx **out, int device, const fhip_params *p, int max_frames
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (const char *v = getenv("FHIP_OVERLAP")) c->overlap = (v[0] == '1');
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_smp, nsub * n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_smp, nsmp * n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_autoc, nsub * FHIP_MAX_LAGS * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_coefs, nsub * FHIP_MAX_ORDER * FHIP_MAX_ORDER * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_shift, nsub * FHIP_MAX_ORDER * sizeof(int32_t));
@@ -451,8 +467,8 @@ void fhip_destroy(fhip_ctx *c)
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
     void *bufs[] = {c->d_smp, c->d_autoc, c->d_coefs, c->d_shift, c->d_opt, c->d_fin, c->d_k0rec,
                     c->d_pcm, c->d_info, c->d_res, c->d_bits, c->d_frames, c->d_fbytes, c->d_fnum,
-                    c->d_packed, c->d_offsets, c->d_gather, c->d_gsrc, c->d_gdst, c->d_srcoff,
-                    c->d_glen, c->d_order};
+                    c->d_packed, c->d_offsets, c->d_srcoff, c->d_frame_src, c->d_totals, c->d_order,
+                    c->d_vcnt, c->d_first, c->d_stream_bytes, c->d_blk_bytes, c->d_blk_frames};
     for (void *b : bufs) if (b) (void)hipFree(b);
     for (int h = 0; h < fhip_ctx::NAUX; h++) {
         if (c->aux[h]) { (void)hipStreamSynchronize(c->aux[h]); (void)hipStreamDestroy(c->aux[h]); }
@@ -579,7 +595,7 @@ static int ensure_staging(fhip_ctx *c, size_t bits_bytes)
     const size_t nsub = (size_t)c->max_frames * c->p.channels;
     const size_t n = (size_t)c->p.block_size;
     if (!c->d_pcm) HIP_TRY(c, hipMalloc((void **)&c->d_pcm, nsub * n * sizeof(int32_t)));
-    if (!c->d_info) HIP_TRY(c, hipMalloc((void **)&c->d_info, nsub * sizeof(fhip_subframe_info)));
+    if (!c->d_info) HIP_TRY(c, hipMalloc((void **)&c->d_info, c->ws_frames * c->p.channels * sizeof(fhip_subframe_info)));
     if (!c->d_res) HIP_TRY(c, hipMalloc((void **)&c->d_res, nsub * n * sizeof(int32_t)));
     if (bits_bytes > c->d_bits_bytes) {
         if (c->d_bits) (void)hipFree(c->d_bits);
@@ -618,10 +634,10 @@ int fhip_encode_subframes(fhip_ctx *c, const fhip_batch *b)
             HIP_TRY(c, hipMalloc((void **)&c->d_frames, fb));
             c->d_frames_bytes = fb;
         }
-        if (!c->d_fbytes) HIP_TRY(c, hipMalloc((void **)&c->d_fbytes, (size_t)c->max_frames * sizeof(int32_t)));
+        if (!c->d_fbytes) HIP_TRY(c, hipMalloc((void **)&c->d_fbytes, c->ws_frames * sizeof(int32_t)));
         fo = FrameOut{c->d_frames, b->frame_stride, c->d_fbytes, b->first_frame_number, nullptr};
         if (b->frame_numbers) {
-            if (!c->d_fnum) HIP_TRY(c, hipMalloc((void **)&c->d_fnum, (size_t)c->max_frames * sizeof(uint32_t)));
+            if (!c->d_fnum) HIP_TRY(c, hipMalloc((void **)&c->d_fnum, c->ws_frames * sizeof(uint32_t)));
             HIP_TRY(c, hipMemcpyAsync(c->d_fnum, b->frame_numbers, (size_t)b->nframes * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
             fo.numbers = c->d_fnum;
         }
@@ -678,11 +694,11 @@ int fhip_frames_packed_begin(fhip_ctx *c, const fhip_batch *b, int64_t *total_by
         HIP_TRY(c, hipMalloc((void **)&c->d_packed, fb));
         c->d_packed_bytes = fb;
     }
-    if (!c->d_fbytes) HIP_TRY(c, hipMalloc((void **)&c->d_fbytes, (size_t)c->max_frames * sizeof(int32_t)));
+    if (!c->d_fbytes) HIP_TRY(c, hipMalloc((void **)&c->d_fbytes, c->ws_frames * sizeof(int32_t)));
     if (!c->d_offsets) HIP_TRY(c, hipMalloc((void **)&c->d_offsets, ((size_t)c->max_frames + 1) * sizeof(long long)));
     FrameOut fo{c->d_frames, stride, c->d_fbytes, b->first_frame_number, nullptr};
     if (b->frame_numbers) {
-        if (!c->d_fnum) HIP_TRY(c, hipMalloc((void **)&c->d_fnum, (size_t)c->max_frames * sizeof(uint32_t)));
+        if (!c->d_fnum) HIP_TRY(c, hipMalloc((void **)&c->d_fnum, c->ws_frames * sizeof(uint32_t)));
         HIP_TRY(c, hipMemcpyAsync(c->d_fnum, b->frame_numbers, (size_t)b->nframes * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         fo.numbers = c->d_fnum;
     }
@@ -730,12 +746,167 @@ int fhip_encode_frames_packed(fhip_ctx *c, const fhip_batch *b, uint8_t *out, in
     return FHIP_OK;
 }
 
-int fhip_encode_blocks_vbs_packed(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size,
-                                  uint32_t first_frame_number, uint8_t *out, int64_t out_cap,
-                                  int32_t *block_bytes, int32_t *block_frames, int64_t *out_bytes,
-                                  int32_t *max_frame_bytes, uint32_t *next_frame_number)
+// ---- variable block size: encode_frame_vbs (vbs.c:85-119) around encode_frame, batched --------
+//
+// Everything between the blocks' PCM and the packed stream stays on the device and on the
+// handle's stream; the host never learns how the blocks were split.  split_frame_v1 (k_vbs_split),
+// then k_vbs_plan: a piece is k eighths of its block, so there are eight bins of equal piece
+// length, each with a fixed range of frame slots (VbsBins: host arithmetic on nblocks alone) and a
+// count on the device.  The path runs once per bin -- grids sized for the bin's capacity, counts
+// read from the device, the pieces encoded where they lie in the caller's blocks (no gather) --
+// the bins fanned out over the handle's internal streams and joined again on every way out;
+// k_pack_frames_perm then packs the frames of all bins in stream order.
+namespace {
+
+int vbs_bins(const fhip_ctx *c, int nblocks, int block_size, fhip::VbsBins *vb, long long *frames_bytes,
+             long long *bits_bytes)
 {
-    if (!c || !pcm || !out || !out_bytes || !block_bytes) return fail(c, FHIP_E_INVALID, "null argument");
+    const fhip_params &p = c->p;
+    const long long nch = p.channels;
+    long long slot0 = 0, smp = 0, fr = 0, bt = 0;
+    for (int k = 0; k < 8; k++) {
+        const int n = (k + 1) * (block_size / 8);
+        vb->n[k] = n;
+        vb->cap[k] = (8 / (k + 1)) * nblocks;
+        vb->slot0[k] = (int)slot0;
+        vb->smp_off[k] = smp;
+        vb->stride[k] = fhip_frame_stride(&p, n);
+        vb->slot[k] = (vb->stride[k] + 3) & ~(long long)3;
+        vb->fr_off[k] = fr;
+        vb->bits_off[k] = bt;
+        slot0 += vb->cap[k];
+        smp += (long long)vb->cap[k] * n * nch;
+        fr += (long long)vb->cap[k] * vb->stride[k];
+        bt += (long long)vb->cap[k] * nch * vb->slot[k];
+    }
+    if ((size_t)slot0 > c->ws_frames || (size_t)smp > (size_t)c->max_frames * (size_t)nch * (size_t)p.block_size)
+        return FHIP_E_INVALID;
+    *frames_bytes = fr;
+    *bits_bytes = bt;
+    return FHIP_OK;
+}
+
+// joins the aux streams back into the caller's stream when the scope ends, however it ends
+struct FanJoin {
+    fhip_ctx *c; int nstreams; bool forked = false;
+    FanJoin(fhip_ctx *cc, int ns) : c(cc), nstreams(ns) {}
+    hipError_t fork()
+    {
+        hipError_t e = hipEventRecord(c->ev_fork, c->stream);
+        for (int h = 0; h < nstreams && e == hipSuccess; h++) e = hipStreamWaitEvent(c->aux[h], c->ev_fork, 0);
+        forked = true;                      // even partly: join whatever was reached
+        return e;
+    }
+    hipError_t join()
+    {
+        if (!forked) return hipSuccess;
+        forked = false;
+        hipError_t first = hipSuccess;
+        for (int h = 0; h < nstreams; h++) {
+            hipError_t e = hipEventRecord(c->ev_join[h], c->aux[h]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_join[h], 0);
+            if (e != hipSuccess) {              // last resort: nothing of the failed call stays in flight
+                (void)hipStreamSynchronize(c->aux[h]);
+                if (first == hipSuccess) first = e;
+            }
+        }
+        return first;
+    }
+    ~FanJoin() { (void)join(); }
+};
+
+struct VbsOut {
+    uint8_t *packed; long long cap;           // device
+    int32_t *stream_bytes, *block_bytes, *block_frames;   // device, optional
+    long long *totals;                        // device [4]
+};
+
+// pcm: DEVICE blocks.  Asynchronous on the handle's stream.
+int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, uint32_t first_frame_number,
+                 const VbsOut &o)
+{
+    const fhip_params &p = c->p;
+    const size_t nch = (size_t)p.channels;
+    fhip::VbsBins vb;
+    long long frames_bytes = 0, bits_bytes = 0;
+    if (vbs_bins(c, nblocks, block_size, &vb, &frames_bytes, &bits_bytes) != FHIP_OK)
+        return fail(c, FHIP_E_INVALID, "nblocks * 8 exceeds the handle's max_frames");
+    int rc = ensure_staging(c, 0);
+    if (rc != FHIP_OK) return rc;
+    const size_t slots = c->ws_frames, nstream = (size_t)c->max_frames;
+    if (!c->d_srcoff) HIP_TRY(c, hipMalloc((void **)&c->d_srcoff, slots * sizeof(long long)));
+    if (!c->d_frame_src) HIP_TRY(c, hipMalloc((void **)&c->d_frame_src, slots * sizeof(long long)));
+    if (!c->d_fbytes) HIP_TRY(c, hipMalloc((void **)&c->d_fbytes, slots * sizeof(int32_t)));
+    if (!c->d_fnum) HIP_TRY(c, hipMalloc((void **)&c->d_fnum, slots * sizeof(uint32_t)));
+    if (!c->d_order) HIP_TRY(c, hipMalloc((void **)&c->d_order, nstream * sizeof(int32_t)));
+    if (!c->d_offsets) HIP_TRY(c, hipMalloc((void **)&c->d_offsets, (nstream + 1) * sizeof(long long)));
+    if (!c->d_vcnt) HIP_TRY(c, hipMalloc((void **)&c->d_vcnt, fhip::VBS_CNT_WORDS * sizeof(int32_t)));
+    if (!c->d_first) HIP_TRY(c, hipMalloc((void **)&c->d_first, (nstream / 8 + 2) * sizeof(int32_t)));
+    if ((size_t)bits_bytes > c->d_bits_bytes) {
+        if (c->d_bits) (void)hipFree(c->d_bits);
+        c->d_bits = nullptr; c->d_bits_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_bits, (size_t)bits_bytes));
+        c->d_bits_bytes = (size_t)bits_bytes;
+    }
+    if ((size_t)frames_bytes > c->d_frames_bytes) {
+        if (c->d_frames) (void)hipFree(c->d_frames);
+        c->d_frames = nullptr; c->d_frames_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_frames, (size_t)frames_bytes));
+        c->d_frames_bytes = (size_t)frames_bytes;
+    }
+
+    // ---- split_frame_v1 (vbs.c:36-83) and the piece tables, on the device ----
+    // (d_opt / d_shift are free until a bin's K2 runs, which the plan precedes on this stream)
+    HIP_TRY(c, fhip::launch_vbs_split(c->stream, pcm, nblocks, block_size, p.channels, c->d_opt, c->d_shift));
+    HIP_TRY(c, fhip::launch_vbs_plan(c->stream, c->d_opt, c->d_shift, nblocks, block_size, p.channels,
+                                     first_frame_number, vb, c->d_vcnt, c->d_order, c->d_frame_src, c->d_srcoff,
+                                     c->d_fnum, c->d_first));
+
+    // ---- one pass of the path per bin ----
+    // A bin is a few hundred frames -- too few workgroups to fill the chip, and eight bins one
+    // behind the other pay eight times the latency of the path's launches: the bins touch disjoint
+    // ranges of every buffer and fan out over the handle's internal streams (measured per 1024
+    // blocks, levels 9 / 10 / 12: one stream 2.7 / 2.8 / 5.4 ms, two 2.1 / 2.3 / 4.7, three 2.0 / 2.2 /
+    // 4.2, four 2.2 / 2.1 / 4.3), longest pieces first, each to the stream with least capacity queued.
+    static const bool vbs_serial = getenv("FHIP_VBS_SERIAL") != nullptr;          // measurements only
+    constexpr int NA = fhip_ctx::NAUX;
+    static const int vbs_streams = getenv("FHIP_VBS_STREAMS") ? std::max(2, std::min(NA, atoi(getenv("FHIP_VBS_STREAMS")))) : 3;
+    bool fan = !vbs_serial && !c->profiling;
+    for (int h = 0; h < vbs_streams; h++) fan = fan && c->aux[h];
+    FanJoin fj(c, vbs_streams);
+    if (fan) HIP_TRY(c, fj.fork());
+    long long queued[NA] = {0};
+    for (int k = 7; k >= 0; k--) {
+        const int n = vb.n[k];
+        const size_t sub0 = (size_t)vb.slot0[k] * nch;
+        const FrameOut fo{c->d_frames + vb.fr_off[k], vb.stride[k], c->d_fbytes + vb.slot0[k], 0,
+                          c->d_fnum + vb.slot0[k]};
+        const Ragged rg{c->d_frame_src + vb.slot0[k], c->d_vcnt + fhip::VBS_CNT_FRAMES + k,
+                        c->d_vcnt + fhip::VBS_CNT_SUB + k, std::max(1, nblocks / 2)};
+        hipStream_t st = c->stream;
+        if (fan) {
+            int h = 0;
+            for (int q = 1; q < vbs_streams; q++) if (queued[q] < queued[h]) h = q;
+            queued[h] += (long long)vb.cap[k] * n;
+            st = c->aux[h];
+        }
+        rc = run_range(c, st, c->profiling && !fan, pcm, vb.cap[k], n, c->d_info + sub0, nullptr,
+                       c->d_bits + vb.bits_off[k], vb.slot[k], c->d_smp + vb.smp_off[k],
+                       c->d_autoc + sub0 * FHIP_MAX_LAGS, sub0, fo, false, nullptr, false, &rg);
+        if (rc != FHIP_OK) return rc;                       // (~FanJoin joins what was queued)
+    }
+    HIP_TRY(c, fj.join());
+    HIP_TRY(c, fhip::launch_pack_frames_perm(c->stream, c->d_frames, c->d_srcoff, c->d_fbytes, c->d_order,
+                                             8 * nblocks, c->d_vcnt + fhip::VBS_CNT_ALL, c->d_offsets,
+                                             o.packed, o.cap, o.stream_bytes, o.totals));
+    HIP_TRY(c, fhip::launch_vbs_block_bytes(c->stream, c->d_first, c->d_offsets, nblocks, o.block_bytes,
+                                            o.block_frames));
+    return FHIP_OK;
+}
+
+int vbs_check(fhip_ctx *c, const void *pcm, int nblocks, int block_size)
+{
+    if (!c || !pcm) return fail(c, FHIP_E_INVALID, "null argument");
     const fhip_params &p = c->p;
     if (!p.variable_block_size || !p.allow_vbs)
         return fail(c, FHIP_E_INVALID, "the handle's parameters have no variable block size");
@@ -743,179 +914,81 @@ int fhip_encode_blocks_vbs_packed(fhip_ctx *c, const int32_t *pcm, int nblocks, 
         return fail(c, FHIP_E_INVALID, "vbs needs block_size % 8 == 0 and >= 128 (vbs.c:93)");
     if (nblocks < 0 || (long long)nblocks * 8 > c->max_frames)
         return fail(c, FHIP_E_INVALID, "nblocks * 8 exceeds the handle's max_frames");
+    return FHIP_OK;
+}
+
+}  // namespace
+
+int fhip_encode_blocks_vbs_dev(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size,
+                               uint32_t first_frame_number, const fhip_vbs_out *out)
+{
+    int rc = vbs_check(c, pcm, nblocks, block_size);
+    if (rc != FHIP_OK) return rc;
+    if (!out || !out->packed || !out->totals || out->packed_cap < 0)
+        return fail(c, FHIP_E_INVALID, "null output argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (nblocks == 0) {
+        HIP_TRY(c, hipMemsetAsync(out->totals, 0, 4 * sizeof(int64_t), c->stream));
+        return FHIP_OK;
+    }
+    return vbs_dev_core(c, pcm, nblocks, block_size, first_frame_number,
+                        VbsOut{out->packed, (long long)out->packed_cap, out->frame_bytes, out->block_bytes,
+                               out->block_frames, reinterpret_cast<long long *>(out->totals)});
+}
+
+int fhip_encode_blocks_vbs_packed(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size,
+                                  uint32_t first_frame_number, uint8_t *out, int64_t out_cap,
+                                  int32_t *block_bytes, int32_t *block_frames, int64_t *out_bytes,
+                                  int32_t *max_frame_bytes, uint32_t *next_frame_number)
+{
+    int rc = vbs_check(c, pcm, nblocks, block_size);
+    if (rc != FHIP_OK) return rc;
+    if (!out || !out_bytes || !block_bytes) return fail(c, FHIP_E_INVALID, "null argument");
+    const fhip_params &p = c->p;
     *out_bytes = 0;
+    c->packed_ready = 0;                     // d_packed is about to be rewritten (and may move)
     if (max_frame_bytes) *max_frame_bytes = 0;
     if (next_frame_number) *next_frame_number = first_frame_number;
     if (nblocks == 0) return FHIP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t nch = (size_t)p.channels;
-    const size_t cap_sub = (size_t)c->max_frames * nch;
-    int rc = ensure_staging(c, 0);
+    rc = ensure_staging(c, 0);
     if (rc != FHIP_OK) return rc;
-    const size_t np_max = (size_t)c->max_frames;
-    if (!c->d_gather) HIP_TRY(c, hipMalloc((void **)&c->d_gather, cap_sub * (size_t)p.block_size * sizeof(int32_t)));
-    if (!c->d_gsrc) HIP_TRY(c, hipMalloc((void **)&c->d_gsrc, np_max * sizeof(long long)));
-    if (!c->d_gdst) HIP_TRY(c, hipMalloc((void **)&c->d_gdst, np_max * sizeof(long long)));
-    if (!c->d_srcoff) HIP_TRY(c, hipMalloc((void **)&c->d_srcoff, np_max * sizeof(long long)));
-    if (!c->d_glen) HIP_TRY(c, hipMalloc((void **)&c->d_glen, np_max * sizeof(int32_t)));
-    if (!c->d_order) HIP_TRY(c, hipMalloc((void **)&c->d_order, np_max * sizeof(int32_t)));
-    if (!c->d_fbytes) HIP_TRY(c, hipMalloc((void **)&c->d_fbytes, np_max * sizeof(int32_t)));
-    if (!c->d_fnum) HIP_TRY(c, hipMalloc((void **)&c->d_fnum, np_max * sizeof(uint32_t)));
-    if (!c->d_offsets) HIP_TRY(c, hipMalloc((void **)&c->d_offsets, (np_max + 1) * sizeof(long long)));
-
-    // ---- the blocks to the device, split_frame_v1 (vbs.c:36-83) there, its verdicts back ----
-    const size_t nvals = (size_t)nblocks * block_size * nch;
-    HIP_TRY(c, hipMemcpyAsync(c->d_pcm, pcm, nvals * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, fhip::launch_vbs_split(c->stream, c->d_pcm, nblocks, block_size, p.channels, c->d_opt, c->d_shift));
-    std::vector<int32_t> nf((size_t)nblocks), sz((size_t)nblocks * 8);
-    HIP_TRY(c, hipMemcpyAsync(nf.data(), c->d_opt, nf.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(sz.data(), c->d_shift, sz.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-
-    // ---- pieces in stream order; groups of equal length in order of first appearance ----
-    struct Piece { int block, n, group, k; long long pos; };
-    std::vector<Piece> pieces;
-    struct Group { int n, cnt; long long goff, fr_off, b_off; int slot0; int64_t stride, slot; };
-    std::vector<Group> groups;
-    pieces.reserve((size_t)nblocks * 2);
-    for (int b = 0; b < nblocks; b++) {
-        int f = nf[(size_t)b];
-        int one[1] = {block_size};
-        const int32_t *sizes = &sz[(size_t)b * 8];
-        if (f <= 1) { f = 1; sizes = one; }                          // vbs.c:100, encode.c:1001
-        long long pos = (long long)b * block_size;
-        for (int q = 0; q < f; q++) {
-            const int n = sizes[q];
-            if (n < 1 || n > block_size) return fail(c, FHIP_E_GENERIC, "bad piece size from the splitter");
-            int g = -1;
-            for (size_t j = 0; j < groups.size(); j++) if (groups[j].n == n) { g = (int)j; break; }
-            if (g < 0) { groups.push_back(Group{n, 0, 0, 0, 0, 0, 0, 0}); g = (int)groups.size() - 1; }
-            pieces.push_back(Piece{b, n, g, groups[(size_t)g].cnt++, pos});
-            pos += n;
-        }
-    }
-    const int np = (int)pieces.size();
-    long long goff = 0, fr_off = 0, b_off = 0;
-    int slot0 = 0;
-    for (auto &g : groups) {
-        g.stride = fhip_frame_stride(&p, g.n);
-        g.slot = (g.stride + 3) & ~(int64_t)3;
-        g.goff = goff; g.fr_off = fr_off; g.b_off = b_off; g.slot0 = slot0;
-        goff += (long long)g.cnt * g.n * (long long)nch;
-        fr_off += (long long)g.cnt * g.stride;
-        b_off += (long long)g.cnt * (long long)nch * g.slot;
-        slot0 += g.cnt;
-    }
-    if ((size_t)b_off > c->d_bits_bytes) {
-        if (c->d_bits) (void)hipFree(c->d_bits);
-        c->d_bits = nullptr; c->d_bits_bytes = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_bits, (size_t)b_off));
-        c->d_bits_bytes = (size_t)b_off;
-    }
-    if ((size_t)fr_off > c->d_frames_bytes) {
-        if (c->d_frames) (void)hipFree(c->d_frames);
-        c->d_frames = nullptr; c->d_frames_bytes = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_frames, (size_t)fr_off));
-        c->d_frames_bytes = (size_t)fr_off;
-    }
-    if ((size_t)fr_off > c->d_packed_bytes) {
+    fhip::VbsBins vb;
+    long long frames_bytes = 0, bits_bytes = 0;
+    if (vbs_bins(c, nblocks, block_size, &vb, &frames_bytes, &bits_bytes) != FHIP_OK)
+        return fail(c, FHIP_E_INVALID, "nblocks * 8 exceeds the handle's max_frames");
+    if ((size_t)frames_bytes > c->d_packed_bytes) {
         if (c->d_packed) (void)hipFree(c->d_packed);
         c->d_packed = nullptr; c->d_packed_bytes = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_packed, (size_t)fr_off));
-        c->d_packed_bytes = (size_t)fr_off;
+        HIP_TRY(c, hipMalloc((void **)&c->d_packed, (size_t)frames_bytes));
+        c->d_packed_bytes = (size_t)frames_bytes;
     }
-    std::vector<long long> gsrc((size_t)np), gdst((size_t)np), srcoff((size_t)np);
-    std::vector<int32_t> glen((size_t)np), order((size_t)np);
-    std::vector<uint32_t> fnum((size_t)np);
-    for (int i = 0; i < np; i++) {
-        const Piece &pc = pieces[(size_t)i];
-        const Group &g = groups[(size_t)pc.group];
-        const int slot = g.slot0 + pc.k;
-        gsrc[(size_t)i] = pc.pos * (long long)nch;
-        gdst[(size_t)i] = g.goff + (long long)pc.k * g.n * (long long)nch;
-        glen[(size_t)i] = pc.n * (int)nch;
-        order[(size_t)i] = slot;
-        srcoff[(size_t)slot] = g.fr_off + (long long)pc.k * g.stride;
-        // allow_vbs: a frame carries its first sample's number (encode.c:969-975)
-        fnum[(size_t)slot] = first_frame_number + (uint32_t)pc.pos;
-    }
-    HIP_TRY(c, hipMemcpyAsync(c->d_gsrc, gsrc.data(), (size_t)np * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_gdst, gdst.data(), (size_t)np * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_glen, glen.data(), (size_t)np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_order, order.data(), (size_t)np * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_srcoff, srcoff.data(), (size_t)np * sizeof(long long), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_fnum, fnum.data(), (size_t)np * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, fhip::launch_gather_pieces(c->stream, c->d_pcm, c->d_gsrc, c->d_gdst, c->d_glen, np, c->d_gather));
+    const size_t nb = (size_t)c->max_frames / 8 + 2;
+    if (!c->d_totals) HIP_TRY(c, hipMalloc((void **)&c->d_totals, 4 * sizeof(long long)));
+    if (!c->d_blk_bytes) HIP_TRY(c, hipMalloc((void **)&c->d_blk_bytes, nb * sizeof(int32_t)));
+    if (!c->d_blk_frames) HIP_TRY(c, hipMalloc((void **)&c->d_blk_frames, nb * sizeof(int32_t)));
 
-    // ---- one pass of the path per group, all on the device ----
-    // A group is a few hundred frames -- too few workgroups to fill the chip, and eight groups one
-    // behind the other pay eight times the latency of the path's six launches.  The groups touch
-    // disjoint ranges of every buffer (run_range's sub0), so they fan out over the handle's
-    // internal streams, the heavier ones first, each to the stream with least work queued
-    // (samples x candidates is not known here: samples), and join the caller's stream again.
-    static const bool vbs_serial = getenv("FHIP_VBS_SERIAL") != nullptr;          // measurements only
-    constexpr int NA = fhip_ctx::NAUX;
-    // (measured per 1024 blocks, levels 9 / 10 / 12: one stream 2.7 / 2.8 / 5.4 ms, two 2.1 / 2.3 / 4.7,
-    // three 2.0 / 2.2 / 4.2, four 2.2 / 2.1 / 4.3)
-    static const int vbs_streams = getenv("FHIP_VBS_STREAMS") ? std::max(2, std::min(NA, atoi(getenv("FHIP_VBS_STREAMS")))) : 3;
-    bool fan = !vbs_serial && !c->profiling && groups.size() > 1;
-    for (int h = 0; h < vbs_streams; h++) fan = fan && c->aux[h];
-    if (fan) {
-        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-        for (int h = 0; h < vbs_streams; h++) HIP_TRY(c, hipStreamWaitEvent(c->aux[h], c->ev_fork, 0));
-    }
-    std::vector<size_t> by_work(groups.size());
-    for (size_t j = 0; j < groups.size(); j++) by_work[j] = j;
-    if (fan)
-        std::stable_sort(by_work.begin(), by_work.end(), [&](size_t a, size_t b) {
-            return (long long)groups[a].cnt * groups[a].n > (long long)groups[b].cnt * groups[b].n; });
-    long long queued[NA] = {0};
-    for (size_t j : by_work) {
-        const auto &g = groups[j];
-        const FrameOut fo{c->d_frames + g.fr_off, g.stride, c->d_fbytes + g.slot0, 0, c->d_fnum + g.slot0};
-        const size_t sub0 = (size_t)g.slot0 * nch;
-        if (fan) {
-            int h = 0;
-            for (int q = 1; q < vbs_streams; q++) if (queued[q] < queued[h]) h = q;
-            queued[h] += (long long)g.cnt * g.n;
-            rc = run_range(c, c->aux[h], false, c->d_gather + g.goff, g.cnt, g.n, c->d_info + sub0, nullptr,
-                           c->d_bits + g.b_off, g.slot, c->d_smp + g.goff, c->d_autoc + sub0 * FHIP_MAX_LAGS, sub0,
-                           fo, false);
-        } else {
-            rc = run_pipeline(c, c->d_gather + g.goff, g.cnt, g.n, c->d_info + sub0, nullptr,
-                              c->d_bits + g.b_off, g.slot, nullptr, nullptr, fo, false);
-        }
-        if (rc != FHIP_OK) return rc;
-    }
-    if (fan) {
-        for (int h = 0; h < vbs_streams; h++) {
-            HIP_TRY(c, hipEventRecord(c->ev_join[h], c->aux[h]));
-            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join[h], 0));
-        }
-    }
-    HIP_TRY(c, fhip::launch_pack_frames_perm(c->stream, c->d_frames, c->d_srcoff, c->d_fbytes, c->d_order, np,
-                                             c->d_offsets, c->d_packed));
-    std::vector<int32_t> fb((size_t)np);
-    long long total = 0;
-    HIP_TRY(c, hipMemcpyAsync(fb.data(), c->d_fbytes, (size_t)np * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&total, c->d_offsets + np, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    // one upload, the batch on the device, one download of the stream's bytes
+    const size_t nvals = (size_t)nblocks * block_size * (size_t)p.channels;
+    HIP_TRY(c, hipMemcpyAsync(c->d_pcm, pcm, nvals * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    rc = vbs_dev_core(c, c->d_pcm, nblocks, block_size, first_frame_number,
+                      VbsOut{c->d_packed, (long long)c->d_packed_bytes, nullptr, c->d_blk_bytes,
+                             block_frames ? c->d_blk_frames : nullptr, c->d_totals});
+    if (rc != FHIP_OK) return rc;
+    long long totals[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(totals, c->d_totals, sizeof totals, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(block_bytes, c->d_blk_bytes, (size_t)nblocks * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (block_frames)
+        HIP_TRY(c, hipMemcpyAsync(block_frames, c->d_blk_frames, (size_t)nblocks * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     rc = fhip_sync(c);
     if (rc != FHIP_OK) return rc;
-    if (total > out_cap) return fail(c, FHIP_E_INVALID, "output buffer too small for the batch's frames");
-    HIP_TRY(c, hipMemcpy(out, c->d_packed, (size_t)total, hipMemcpyDeviceToHost));
-
-    int32_t mx = 0;
-    for (int b = 0; b < nblocks; b++) { block_bytes[b] = 0; if (block_frames) block_frames[b] = 0; }
-    for (int i = 0; i < np; i++) {
-        const int32_t bytes = fb[(size_t)order[(size_t)i]];
-        if (bytes <= 0) return fail(c, FHIP_E_GENERIC, "a frame of the batch was not encoded");
-        block_bytes[pieces[(size_t)i].block] += bytes;
-        if (block_frames) block_frames[pieces[(size_t)i].block] += 1;
-        if (bytes > mx) mx = bytes;
-    }
-    if (max_frame_bytes) *max_frame_bytes = mx;
+    if (totals[1] > out_cap) return fail(c, FHIP_E_INVALID, "output buffer too small for the batch's frames");
+    HIP_TRY(c, hipMemcpy(out, c->d_packed, (size_t)totals[1], hipMemcpyDeviceToHost));
+    for (int b = 0; b < nblocks; b++)
+        if (block_bytes[b] <= 0) return fail(c, FHIP_E_GENERIC, "a frame of the batch was not encoded");
+    if (max_frame_bytes) *max_frame_bytes = (int32_t)totals[2];
     if (next_frame_number) *next_frame_number = first_frame_number + (uint32_t)((long long)nblocks * block_size);
-    *out_bytes = total;
+    *out_bytes = totals[1];
     return FHIP_OK;
 }
 

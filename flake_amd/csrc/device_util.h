@@ -62,6 +62,15 @@ constexpr int WAVE = 64;
 // small device helpers
 // ---------------------------------------------------------------------------
 
+// How many units (frames or subframes) a launch really has: the host's number, or -- for the
+// ragged batches of a variable-block-size stream, whose piece counts only the device knows
+// (k_vbs_plan) -- the word at `dev`; the grid is then sized for the bin's capacity and
+// workgroups past the count leave at once.  Wave-uniform (a scalar load).
+__device__ __forceinline__ int dev_count(const int32_t *__restrict__ dev, int host)
+{
+    return dev ? __builtin_amdgcn_readfirstlane(*dev) : host;
+}
+
 __device__ __forceinline__ uint32_t zigzag32(int32_t x)
 {
     // rice.c:122 (search side) and bitio.h:128-129 (emit side): same map

@@ -17,9 +17,11 @@ namespace {
 template <bool RESIDENT>
 __global__ __launch_bounds__(NT)
 void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
-               fhip_subframe_info *__restrict__ info, int n, int nch, int bps, int estimate)
+               fhip_subframe_info *__restrict__ info, int n, int nch, int bps, int estimate,
+               const long long *__restrict__ frame_src, const int32_t *__restrict__ dev_frames)
 {
     extern __shared__ int32_t lds_i32[];
+    if (dev_frames && (int)blockIdx.x >= dev_count(dev_frames, 0)) return;
     __shared__ unsigned long long s_sum[4][4];
     __shared__ uint32_t s_or[4][2];
     __shared__ int s_mode;
@@ -28,7 +30,7 @@ void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
 
     if (nch == 2) {
         const int f = blockIdx.x;
-        const int32_t *src = pcm + (size_t)f * n * 2;
+        const int32_t *src = pcm + (frame_src ? (size_t)frame_src[f] : (size_t)f * n * 2);
         int32_t *L = lds_i32, *R = lds_i32 + n;
         const int2 *src2 = reinterpret_cast<const int2 *>(src);
         if (RESIDENT) {
@@ -141,13 +143,15 @@ void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
 // (L2), shifts and writes channel rows coalesced.
 __global__ __launch_bounds__(NT)
 void k_prepare_multi(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
-                     fhip_subframe_info *__restrict__ info, int n, int nch, int bps)
+                     fhip_subframe_info *__restrict__ info, int n, int nch, int bps,
+                     const long long *__restrict__ frame_src, const int32_t *__restrict__ dev_frames)
 {
     __shared__ int32_t s_tile[NT * (FHIP_MAX_CH + 1)];
     __shared__ uint32_t s_orr[4][FHIP_MAX_CH];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int f = blockIdx.x;
-    const int32_t *src = pcm + (size_t)f * n * nch;
+    if (dev_frames && f >= dev_count(dev_frames, 0)) return;
+    const int32_t *src = pcm + (frame_src ? (size_t)frame_src[f] : (size_t)f * n * nch);
     const int stride = nch + 1;
     const int total = n * nch;
 
@@ -216,13 +220,15 @@ constexpr int RT = 1024;       // threads per frame
 template <int NCH, int M>
 __global__ __launch_bounds__(RT)
 void k_prepare_multi_reg(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
-                         fhip_subframe_info *__restrict__ info, int n, int bps)
+                         fhip_subframe_info *__restrict__ info, int n, int bps,
+                         const long long *__restrict__ frame_src, const int32_t *__restrict__ dev_frames)
 {
     __shared__ uint32_t s_orr[RT / 64][8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int f = blockIdx.x;
+    if (dev_frames && f >= dev_count(dev_frames, 0)) return;
     const int quads = n >> 2;
-    const int32_t *src = pcm + (size_t)f * n * NCH;
+    const int32_t *src = pcm + (frame_src ? (size_t)frame_src[f] : (size_t)f * n * NCH);
     int32_t v[M][4 * NCH];                 // v[m][4*NCH]: element e = sample-frame (e / NCH), channel (e % NCH)
     uint32_t orv[NCH];
 #pragma unroll
@@ -302,11 +308,14 @@ __global__ __launch_bounds__(NT)
 // K3's staging; K3 resets the field) -- half the bytes written here and read there.
 void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
                       fhip_subframe_info *__restrict__ info, int n, int bps, int estimate,
-                      int allow_narrow, int nframes)
+                      int allow_narrow, int nframes, const long long *__restrict__ frame_src,
+                      const int32_t *__restrict__ dev_frames)
 {
     __shared__ unsigned long long s_sum[4][4];
     __shared__ uint32_t s_or[4][4];
     __shared__ int s_mode;
+    nframes = dev_count(dev_frames, nframes);
+    if ((int)blockIdx.x * (4 / WPF) >= nframes) return;          // (a ragged batch's grid is its bin's capacity)
 
     constexpr int TF = WAVE * WPF;                       // threads per frame
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -315,7 +324,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
     const int fq = blockIdx.x * (4 / WPF) + wv / WPF;
     const bool fvalid = fq < nframes;                    // a partial last workgroup computes a copy of the last frame
     const int f = min(fq, nframes - 1);
-    const int4 *src = reinterpret_cast<const int4 *>(pcm + (size_t)f * n * 2);
+    const int4 *src = reinterpret_cast<const int4 *>(pcm + (frame_src ? (size_t)frame_src[f] : (size_t)f * n * 2));
     const int nquads = n >> 2;
 
     int32_t L[M][4], R[M][4];
@@ -499,7 +508,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
 
 hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *pcm,
                           int nframes, int n, int32_t *smp, fhip_subframe_info *info, bool decide_only,
-                          bool allow_narrow)
+                          bool allow_narrow, const long long *frame_src, const int32_t *dev_frames)
 {
     const int nch = p.channels;
     if (nframes == 0) return hipSuccess;
@@ -507,7 +516,7 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
         const int est = p.stereo_method == 1 ? 1 : 0;
         const int quads = n >> 2;
         const int nar = (allow_narrow && !decide_only) ? 1 : 0;
-#define LAUNCH_PS(M_, W_, A_) hipLaunchKernelGGL((k_prepare_stereo<M_, W_, A_>), dim3((nframes + 4 / W_ - 1) / (4 / W_)), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est, nar, nframes)
+#define LAUNCH_PS(M_, W_, A_) hipLaunchKernelGGL((k_prepare_stereo<M_, W_, A_>), dim3((nframes + 4 / W_ - 1) / (4 / W_)), dim3(NT), 0, st, pcm, smp, info, n, p.bits_per_sample, est, nar, nframes, frame_src, dev_frames)
         if (decide_only) {
             if (quads <= NT) LAUNCH_PS(1, 4, false); else if (quads <= 2 * NT) LAUNCH_PS(2, 4, false); else LAUNCH_PS(4, 4, false);
         } else {
@@ -531,7 +540,7 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
         static const bool two_pass = getenv("FHIP_K0_MULTI_TWO_PASS") != nullptr;      // measurements only
         if (!two_pass && (n & 3) == 0 && n <= 8192 && n >= 256) {
             // the frame in registers: one read of the PCM
-#define LAUNCH_MR(C_, M_) hipLaunchKernelGGL((k_prepare_multi_reg<C_, M_>), dim3(nframes), dim3(RT), 0, st, pcm, smp, info, n, p.bits_per_sample)
+#define LAUNCH_MR(C_, M_) hipLaunchKernelGGL((k_prepare_multi_reg<C_, M_>), dim3(nframes), dim3(RT), 0, st, pcm, smp, info, n, p.bits_per_sample, frame_src, dev_frames)
 #define LAUNCH_MRC(C_) do { if (n <= 4 * RT) LAUNCH_MR(C_, 1); else LAUNCH_MR(C_, 2); } while (0)
             switch (nch) {
             case 1: LAUNCH_MRC(1); break;
@@ -547,7 +556,7 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
             return hipGetLastError();
         }
         hipLaunchKernelGGL(k_prepare_multi, dim3(nframes), dim3(NT), 0, st, pcm, smp, info, n, nch,
-                           p.bits_per_sample);
+                           p.bits_per_sample, frame_src, dev_frames);
         return hipGetLastError();
     }
     const int blocks = nframes;
@@ -556,14 +565,14 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
     if (lds > 150 * 1024) {
         // frames of more than ~19 k sample-frames: streamed from global memory
         hipLaunchKernelGGL(k_prepare<false>, dim3(blocks), dim3(NT), 0, st, pcm, smp, info, n, nch,
-                           p.bits_per_sample, p.stereo_method == 1 ? 1 : 0);
+                           p.bits_per_sample, p.stereo_method == 1 ? 1 : 0, frame_src, dev_frames);
         return hipGetLastError();
     }
     hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_prepare<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (er != hipSuccess) return er;
     hipLaunchKernelGGL(k_prepare<true>, dim3(blocks), dim3(NT), lds, st, pcm, smp, info, n, nch,
-                       p.bits_per_sample, p.stereo_method == 1 ? 1 : 0);
+                       p.bits_per_sample, p.stereo_method == 1 ? 1 : 0, frame_src, dev_frames);
     return hipGetLastError();
 }
 

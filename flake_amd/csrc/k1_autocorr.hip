@@ -51,9 +51,10 @@ __device__ __forceinline__ void wave_lds_fence()
 
 __global__ __launch_bounds__(AC_WAVES * WAVE)
 void k_autocorr(const int32_t *__restrict__ smp, double *__restrict__ autoc,
-                int nsub, int n, int maxlag, int G, int nl2, double c)
+                int nsub, int n, int maxlag, int G, int nl2, double c, const int32_t *__restrict__ dev_sub)
 {
     __shared__ double s_buf[AC_WAVES][AC_GMAX * AC_STRIDE];
+    nsub = dev_count(dev_sub, nsub);
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -242,9 +243,11 @@ constexpr int PS_CH = 8;                  // steps per software-pipeline stage
 
 __global__ __launch_bounds__(AC_WAVES * WAVE)
 void k_autocorr_ps(const int32_t *__restrict__ smp, double *__restrict__ autoc,
-                   int nsub, int n, int maxlag, int G, int lps, int ge, double c)
+                   int nsub, int n, int maxlag, int G, int lps, int ge, double c,
+                   const int32_t *__restrict__ dev_sub)
 {
     __shared__ double s_buf[AC_WAVES][PS_GMAX * PS_STRIDE];
+    nsub = dev_count(dev_sub, nsub);
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -516,7 +519,8 @@ __global__ __launch_bounds__(8 * WAVE)
 void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                    int nsub, int n, int maxlag, wt_groups grp, double c,
                    const int32_t *__restrict__ pcm, int32_t *__restrict__ smp_out,
-                   const fhip_subframe_info *__restrict__ info, wt_lpc_args lpc, int narrow_ok)
+                   const fhip_subframe_info *__restrict__ info, wt_lpc_args lpc, int narrow_ok,
+                   const int32_t *__restrict__ dev_sub)
 {
     extern __shared__ __attribute__((aligned(16))) double wt_lds[];
     double *acbuf = wt_lds + WT_NBUF * WT_BUF;          // [32][FHIP_MAX_LAGS], LPCMO > 0 only
@@ -524,6 +528,8 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int sub0 = blockIdx.x * WT_SUB;
+    nsub = dev_count(dev_sub, nsub);
+    if (sub0 >= nsub) return;                           // (a ragged batch's grid is its bin's capacity)
     const int half = n >> 1;
     const int ntiles = n / AC_TILE;
     const int ntiles_pad = ((ntiles + WT_AHEAD - 1) / WT_AHEAD) * WT_AHEAD;   // the producers' unroll
@@ -927,12 +933,15 @@ bool autocorr_fuses_prepare(const fhip_params &p, int nsub, int n)
 hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                            int max_order, double *autoc, const int32_t *pcm_fused,
                            int32_t *smp_out, const fhip_subframe_info *info,
-                           const autocorr_lpc_out *lpc_out, bool narrow_ok)
+                           const autocorr_lpc_out *lpc_out, bool narrow_ok, const int32_t *dev_sub,
+                           int nsub_hint)
 {
     if (nsub == 0) return hipSuccess;
     // the window constant is computed on the host exactly as lpc.c:34 does
     const double c = (2.0 / (n - 1.0)) - 1.0;
-    const ac_choice ch = pick_autocorr(nsub, n, max_order);
+    // (nsub_hint: the count the kernel choice is made for when the real one is only known on the
+    // device; the caller made its other choices -- K2 as the tail, 16-bit rows -- with the same)
+    const ac_choice ch = pick_autocorr(nsub_hint > 0 ? nsub_hint : nsub, n, max_order);
     const int ne = ch.ne, no = ch.no, Gp = ch.Gp, lps = ch.lps, ge = ch.ge, nl2 = ch.nl2;
     int G = ch.G;
     const bool use_wt = ch.kernel == 2, use_ps = ch.kernel == 1;
@@ -964,7 +973,7 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all); \
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_autocorr_wt<N_, F_, L_>), dim3(blocks), dim3(8 * WAVE), lds_all, st, smp, \
-                           autoc, nsub, n, max_order, gr, c, pcm_fused, smp_out, info, la, narrow_ok ? 1 : 0); \
+                           autoc, nsub, n, max_order, gr, c, pcm_fused, smp_out, info, la, narrow_ok ? 1 : 0, dev_sub); \
     } while (0)
 #define LAUNCH_WT(N_)                                                                        \
     case N_:                                                                                 \
@@ -1000,7 +1009,7 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
         const int per_block = Gp * AC_WAVES;
         const int blocks = (nsub + per_block - 1) / per_block;
         hipLaunchKernelGGL(k_autocorr_ps, dim3(blocks), dim3(AC_WAVES * WAVE), 0, st, smp, autoc,
-                           nsub, n, max_order, Gp, lps, ge, c);
+                           nsub, n, max_order, Gp, lps, ge, c, dev_sub);
         return hipGetLastError();
     }
     // spread over all CUs when the batch is small: fewer subframes per wave
@@ -1010,7 +1019,7 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
     const int per_block = G * AC_WAVES;
     const int blocks = (nsub + per_block - 1) / per_block;
     hipLaunchKernelGGL(k_autocorr, dim3(blocks), dim3(AC_WAVES * WAVE), 0, st, smp, autoc,
-                       nsub, n, max_order, G, nl2, c);
+                       nsub, n, max_order, G, nl2, c, dev_sub);
     return hipGetLastError();
 }
 

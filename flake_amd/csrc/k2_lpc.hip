@@ -63,11 +63,12 @@ constexpr int LPC_DBL = 33 + 32 + 32;
 __global__ __launch_bounds__(LPC_NT)
 void k_lpc(const double *__restrict__ autoc_all, int nsub, int max_order, int precision,
            int omethod, int32_t *__restrict__ coefs, int32_t *__restrict__ shift,
-           int32_t *__restrict__ opt_order, int32_t *__restrict__ fin)
+           int32_t *__restrict__ opt_order, int32_t *__restrict__ fin, const int32_t *__restrict__ dev_sub)
 {
     __shared__ double s_mem[LPC_DBL * LPC_NT];
     const int lane = threadIdx.x;
     const int s = blockIdx.x * LPC_NT + lane;
+    nsub = dev_count(dev_sub, nsub);
     if (s >= nsub) return;
 
     LaneArr R0{s_mem + lane};
@@ -175,9 +176,10 @@ template <int MO>
 __global__ __launch_bounds__(LPC_NT)
 void k_lpc_reg(const double *__restrict__ autoc_all, int nsub, int max_order, int precision,
                int omethod, int32_t *__restrict__ coefs, int32_t *__restrict__ shift,
-               int32_t *__restrict__ opt_order, int32_t *__restrict__ fin)
+               int32_t *__restrict__ opt_order, int32_t *__restrict__ fin, const int32_t *__restrict__ dev_sub)
 {
     const int s = blockIdx.x * LPC_NT + threadIdx.x;
+    nsub = dev_count(dev_sub, nsub);
     if (s >= nsub) return;
     double ac[MO + 1];
 #pragma unroll
@@ -238,13 +240,15 @@ __device__ __forceinline__ void quantize_row_lds(const double *__restrict__ a, i
 __global__ __launch_bounds__(LR_NT)
 void k_lpc_rows(const double *__restrict__ autoc_all, int nsub, int max_order, int precision,
                 int32_t *__restrict__ coefs, int32_t *__restrict__ shift,
-                int32_t *__restrict__ opt_order)
+                int32_t *__restrict__ opt_order, const int32_t *__restrict__ dev_sub)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *rows = reinterpret_cast<double *>(lds_raw);              // [LR_SUB][LR_STRIDE]
     constexpr int MO = FHIP_MAX_ORDER;
     const int tid = threadIdx.x;
     const int s0 = blockIdx.x * LR_SUB;
+    nsub = dev_count(dev_sub, nsub);
+    if (s0 >= nsub) return;
 
     if (tid < LR_SUB && s0 + tid < nsub) {
         const int s = s0 + tid;
@@ -306,16 +310,16 @@ void k_lpc_rows(const double *__restrict__ autoc_all, int nsub, int max_order, i
 
 hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_order,
                       int precision, int omethod, int32_t *coefs, int32_t *shift,
-                      int32_t *opt_order, int32_t *fin)
+                      int32_t *opt_order, int32_t *fin, const int32_t *dev_sub)
 {
     if (nsub == 0) return hipSuccess;
     const int blocks = (nsub + LPC_NT - 1) / LPC_NT;
     if (max_order <= 8)
         hipLaunchKernelGGL(k_lpc_reg<8>, dim3(blocks), dim3(LPC_NT), 0, st, autoc, nsub, max_order,
-                           precision, omethod, coefs, shift, opt_order, fin);
+                           precision, omethod, coefs, shift, opt_order, fin, dev_sub);
     else if (max_order <= 12)
         hipLaunchKernelGGL(k_lpc_reg<12>, dim3(blocks), dim3(LPC_NT), 0, st, autoc, nsub, max_order,
-                           precision, omethod, coefs, shift, opt_order, fin);
+                           precision, omethod, coefs, shift, opt_order, fin, dev_sub);
     else if (omethod >= 2 && getenv("FHIP_K2_ONE_LANE") == nullptr) {
         // every row wanted (lpc.c:249-254): Levinson in registers, rows quantised side by side
         const size_t lds = (size_t)LR_SUB * LR_STRIDE * sizeof(double);
@@ -323,10 +327,10 @@ hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_ord
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (er != hipSuccess) return er;
         hipLaunchKernelGGL(k_lpc_rows, dim3((nsub + LR_SUB - 1) / LR_SUB), dim3(LR_NT), lds, st, autoc, nsub,
-                           max_order, precision, coefs, shift, opt_order);
+                           max_order, precision, coefs, shift, opt_order, dev_sub);
     } else
         hipLaunchKernelGGL(k_lpc, dim3(blocks), dim3(LPC_NT), 0, st, autoc, nsub, max_order,
-                           precision, omethod, coefs, shift, opt_order, fin);
+                           precision, omethod, coefs, shift, opt_order, fin, dev_sub);
     return hipGetLastError();
 }
 

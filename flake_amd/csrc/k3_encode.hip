@@ -269,8 +269,9 @@ void k_encode(fhip_params P, int n, const int32_t *__restrict__ smp_all,
               const int32_t *__restrict__ opt_all, fhip_subframe_info *__restrict__ info,
               const fhip_subframe_info *__restrict__ prep,
               int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
-              int raw_order, int raw_lpc)
+              int raw_order, int raw_lpc, const int32_t *__restrict__ dev_sub)
 {
+    if (dev_sub && (int)blockIdx.x >= dev_count(dev_sub, 0)) return;
     // raw_order >= 0: the input already IS a residual; only calc_rice_params_*
     // (rice.c:173-187) with that prediction order and the emit run.
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -622,9 +623,10 @@ void k_encode_big(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                   const int32_t *__restrict__ opt_all, fhip_subframe_info *__restrict__ info,
                   const fhip_subframe_info *__restrict__ prep,
                   int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
-                  int raw_order, int raw_lpc)
+                  int raw_order, int raw_lpc, const int32_t *__restrict__ dev_sub)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (dev_sub && (int)blockIdx.x >= dev_count(dev_sub, 0)) return;
     size_t off[10];
     enc_lds_layout(0, off);                              // no sample image
     EncCtx e;
@@ -1695,9 +1697,10 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                    const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,
                    fhip_subframe_info *__restrict__ info, const fhip_subframe_info *__restrict__ prep,
                    int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
-                   int narrow_ok)
+                   int narrow_ok, const int32_t *__restrict__ dev_sub)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (dev_sub && (int)blockIdx.x >= dev_count(dev_sub, 0)) return;      // (a ragged batch's grid is its bin's capacity)
     size_t off[12];
     fast_lds_layout(n, SmpImg<C, T>::SIZE, off, fast_wide_window(MODE, P.bits_per_sample));
     FastCtx<C, T> e;
@@ -2446,9 +2449,11 @@ __global__ __launch_bounds__(T, (T <= 256) ? 4 : (T <= 512) ? 2 : 1)
 void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                     const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                     int32_t *__restrict__ opt_all, int32_t *__restrict__ fin_all,
-                    const fhip_subframe_info *__restrict__ prep, int narrow_ok)
+                    const fhip_subframe_info *__restrict__ prep, int narrow_ok,
+                    const int32_t *__restrict__ dev_sub)
 {
     static_assert(C % 8 == 0 && T >= 64 && (T & (T - 1)) == 0, "k_order_search: runs of 8 or 16");
+    if (dev_sub && (int)blockIdx.x >= dev_count(dev_sub, 0)) return;
     using Img = SmpImg<C, T>;
     constexpr int LT = clog2(T);
     constexpr int NW = T / WAVE;
@@ -2802,13 +2807,13 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         }
         break;
         }   // pass
-        // (general way: the next round's row staging is ordered behind this round's FIR by the
-        // barrier above, its level words are the other parity's; leaf mode: the rows, leaves and
-        // heaps are read until the last wave is through)
-        if (leaf_mode) __syncthreads();
+        // The round's rows (l.rowi), leaves, heaps and level words are read until the last wave is
+        // through -- in the general way too: its per-candidate block above reads l.rowi after the
+        // node pass's barrier, and the next round's row staging would overwrite it (one barrier per
+        // round; the general way is the rare fall-back).
+        __syncthreads();
         if (is_log) {
             // optimize.c:249-259: the step's orders in ascending order against the winner so far
-            if (!leaf_mode) __syncthreads();
             for (int sidx = 0; sidx < lg_merged; sidx++) {
                 const int last = lg_best;
                 for (int i = last - lg_step; i <= last + lg_step; i += lg_step) {
@@ -2946,7 +2951,7 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
                          fhip_subframe_info *info,
                          int32_t *residual, uint8_t *bits, int64_t slot_bytes,
                          int raw_order, int raw_lpc, bool narrow_ok, const fhip_subframe_info *prep,
-                         bool order_known)
+                         bool order_known, const int32_t *dev_sub)
 {
     if (nsub == 0) return hipSuccess;
     if (!prep || prep == info) return hipErrorInvalidValue;      // K3 reads K0's records beside the ones it writes
@@ -2965,7 +2970,7 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_encode_pow2<CC, TT, MM>), dim3(nsub), dim3(TT), lds, st, p, n, \
                            nsub, smp, coefs, shift, opt_order, fin, info, prep, residual,    \
-                           bits, (long long)slot_bytes, narrow_ok ? 1 : 0);                  \
+                           bits, (long long)slot_bytes, narrow_ok ? 1 : 0, dev_sub);         \
     } while (0)
         // one quantised row known up front (MAX / EST): the lean instance
         // ... or chosen by the order-search kernel, which leaves the same compact row
@@ -3017,7 +3022,7 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
     if (n > FHIP_MAX_RESIDENT_BLOCK) {
         hipLaunchKernelGGL(k_encode_big, dim3(nsub), dim3(NT), lds, st, p, n, smp, coefs, shift,
                            opt_order, info, prep, residual, bits, (long long)slot_bytes, raw_order,
-                           raw_lpc);
+                           raw_lpc, dev_sub);
         return hipGetLastError();
     }
     const int chunk = (n + NT - 1) / NT;
@@ -3030,7 +3035,7 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
         hipLaunchKernelGGL(k_encode<CC>, dim3(nsub), dim3(NT), lds, st, p, n, smp, coefs,    \
                            shift, opt_order, info, prep, residual, bits,                     \
                            (long long)slot_bytes,                                            \
-                           raw_order, raw_lpc);                                              \
+                           raw_order, raw_lpc, dev_sub);                                     \
     } while (0)
     if (chunk <= 16) LAUNCH_ENC(16);
     else if (chunk <= 32) LAUNCH_ENC(32);
@@ -3058,7 +3063,7 @@ bool order_search_supported(const fhip_params &p, int n)
 hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32_t *smp, int nsub,
                                int n, const int32_t *coefs, const int32_t *shift,
                                int32_t *opt_order, int32_t *fin, const fhip_subframe_info *prep,
-                               bool narrow_ok)
+                               bool narrow_ok, const int32_t *dev_sub)
 {
     if (nsub == 0) return hipSuccess;
     int fc = 0, ft = 0;
@@ -3073,7 +3078,7 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_order_search<CC, TT, G>), dim3(nsub), dim3(TT), lds, st, p, n, \
-                           smp, coefs, shift, opt_order, fin, prep, narrow_ok ? 1 : 0);      \
+                           smp, coefs, shift, opt_order, fin, prep, narrow_ok ? 1 : 0, dev_sub); \
     } while (0)
     switch (fc * 10000 + ft) {
     case 160256: LAUNCH_SRCH(16, 256); break;

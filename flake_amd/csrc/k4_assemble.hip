@@ -78,8 +78,10 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
                 long long slot_bytes, uint8_t *__restrict__ frames, long long frame_stride,
                 int32_t *__restrict__ frame_bytes, uint32_t number_base, uint32_t number_step,
                 const uint32_t *__restrict__ numbers,
-                int sr_code0, int sr_code1, int bps_code, int verbatim_size)
+                int sr_code0, int sr_code1, int bps_code, int verbatim_size,
+                const long long *__restrict__ frame_src, const int32_t *__restrict__ dev_frames)
 {
+    if (dev_frames && (int)blockIdx.x >= dev_count(dev_frames, 0)) return;      // (a ragged batch's grid is its bin's capacity)
     __shared__ uint8_t s_hdr[32];
     __shared__ uint8_t s_prefix[FHIP_MAX_CH][ASM_PREFIX_BYTES];
     __shared__ AsmSeg s_seg[ASM_MAX_SEG];
@@ -93,7 +95,7 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
     const int f = blockIdx.x;
     const int nch = P.channels;
     const fhip_subframe_info *fi = info + (size_t)f * nch;
-    const int32_t *pcm_frame = pcm + (size_t)f * n * nch;
+    const int32_t *pcm_frame = pcm + (frame_src ? (size_t)frame_src[f] : (size_t)f * n * nch);
     uint8_t *out = frames + (size_t)f * frame_stride;
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
 
@@ -387,7 +389,7 @@ hipError_t launch_assemble(hipStream_t st, const fhip_params &p, const int32_t *
                            int n, const fhip_subframe_info *info, const uint8_t *rice,
                            int64_t slot_bytes, uint8_t *frames, int64_t frame_stride,
                            int32_t *frame_bytes, uint32_t number_base, uint32_t number_step,
-                           const uint32_t *numbers)
+                           const uint32_t *numbers, const long long *frame_src, const int32_t *dev_frames)
 {
     if (nframes == 0) return hipSuccess;
     // sample-rate / bit-depth codes of flake_encode_init() (encode.c:400-438)
@@ -408,7 +410,7 @@ hipError_t launch_assemble(hipStream_t st, const fhip_params &p, const int32_t *
                                         : 16 + ((n * p.channels * bps + 7) >> 3);
     hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(NT), 0, st, p, n, pcm, info, rice,
                        (long long)slot_bytes, frames, (long long)frame_stride, frame_bytes,
-                       number_base, number_step, numbers, sr0, sr1, bpsc, vsize);
+                       number_base, number_step, numbers, sr0, sr1, bpsc, vsize, frame_src, dev_frames);
     return hipGetLastError();
 }
 
@@ -469,31 +471,103 @@ void k_pack_frames(const uint8_t *__restrict__ frames, long long stride, const i
     if (tid < len - done) dst[done + tid] = src[done + tid];
 }
 
-// Ragged (VBS) batches, device-resident: pieces of one block-size group gathered into one
-// contiguous [nframes][n][ch] array (one workgroup per piece, 16-byte copies: every piece is a
-// multiple of block_size / 8 >= 16 sample-frames), and the frames of all groups packed in stream
-// order -- order[i] = slot of the i-th frame of the stream, src_off[slot] = where that slot's
-// frame lies.
-__global__ __launch_bounds__(NT)
-void k_gather_pieces(const int32_t *__restrict__ pcm, const long long *__restrict__ src,
-                     const long long *__restrict__ dst, const int32_t *__restrict__ len,
-                     int32_t *__restrict__ out)
+// ---------------------------------------------------------------------------
+// Ragged (VBS) batches, device-resident  (vbs.c:85-119 + encode.c:996-1004, batched)
+// ---------------------------------------------------------------------------
+// split_frame_v1's verdicts stay on the device.  A piece is k eighths of its block, k = 1 .. 8, so
+// there are eight BINS of equal piece length; bin k-1 owns a fixed range of frame slots sized for
+// the most pieces it can get (floor(8 / k) per block: VbsBins, host constants), and only the
+// number of pieces that really fell into it -- cnt[] -- lives on the device.  The path's kernels
+// run once per bin on a grid sized for the bin's capacity and read their count from cnt[]
+// (dev_count); the frames of all bins are then packed in stream order.
+//
+// k_vbs_plan (one workgroup): from nframes[b] / sizes[b][8] of k_vbs_split
+//   cnt[0..7]   frames per bin          cnt[8..15]  subframes per bin       cnt[16]  frames in all
+//   order[i]    slot of the stream's i-th frame (stream order = block order, pieces in order)
+//   per slot:   frame_src (offset of the piece's PCM in int32 units), src_off (byte offset of the
+//               slot's frame in frames[]), numbers (its first sample: encode.c:969-975, allow_vbs)
+//   first[b]    stream index of block b's first frame (first[nblocks] = frames in all)
+// A block the splitter left whole (nframes <= 1) is one piece of eight eighths (vbs.c:100,
+// encode.c:1001).
+constexpr int PLAN_NT = 1024;
+
+__global__ __launch_bounds__(PLAN_NT)
+void k_vbs_plan(const int32_t *__restrict__ nfr, const int32_t *__restrict__ sizes, int nblocks,
+                int block_size, int nch, uint32_t first_number, VbsBins bins,
+                int32_t *__restrict__ cnt, int32_t *__restrict__ order, long long *__restrict__ frame_src,
+                long long *__restrict__ src_off, uint32_t *__restrict__ numbers, int32_t *__restrict__ first)
 {
-    const int i = blockIdx.x;
-    const int4 *s4 = reinterpret_cast<const int4 *>(pcm + src[i]);
-    int4 *d4 = reinterpret_cast<int4 *>(out + dst[i]);
-    const int n4 = len[i] >> 2;
-    for (int q = threadIdx.x; q < n4; q += NT) d4[q] = s4[q];
+    __shared__ int32_t s_scan[9][PLAN_NT];
+    const int tid = threadIdx.x;
+    const int per = (nblocks + PLAN_NT - 1) / PLAN_NT;
+    const int b0 = min(tid * per, nblocks), b1 = min(b0 + per, nblocks);
+    const int eighth = block_size / 8;
+    int c[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) c[k] = 0;
+    for (int b = b0; b < b1; b++) {
+        const int f = nfr[b];
+        if (f <= 1) { c[7]++; c[8]++; continue; }
+        for (int q = 0; q < f; q++) {
+            const int k = sizes[(size_t)b * 8 + q] / eighth - 1;
+#pragma unroll
+            for (int z = 0; z < 8; z++) c[z] += (z == k);
+            c[8]++;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) s_scan[k][tid] = c[k];
+    __syncthreads();
+    for (int off = 1; off < PLAN_NT; off <<= 1) {                 // Hillis-Steele, nine rows at once
+        int v[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) v[k] = (tid >= off) ? s_scan[k][tid - off] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 9; k++) s_scan[k][tid] += v[k];
+        __syncthreads();
+    }
+    int run[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) run[k] = s_scan[k][tid] - c[k];    // exclusive
+    if (tid == PLAN_NT - 1) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { cnt[k] = s_scan[k][tid]; cnt[8 + k] = s_scan[k][tid] * nch; }
+        cnt[16] = s_scan[8][tid];
+        first[nblocks] = s_scan[8][tid];
+    }
+    for (int b = b0; b < b1; b++) {
+        int f = nfr[b];
+        first[b] = run[8];
+        const bool whole = f <= 1;
+        if (whole) f = 1;
+        long long pos = (long long)b * block_size;
+        for (int q = 0; q < f; q++) {
+            const int len = whole ? block_size : sizes[(size_t)b * 8 + q];
+            const int k = len / eighth - 1;
+            int j = 0;
+#pragma unroll
+            for (int z = 0; z < 8; z++) if (z == k) { j = run[z]; run[z]++; }
+            const int slot = bins.slot0[k] + j;
+            order[run[8]++] = slot;
+            frame_src[slot] = pos * nch;
+            src_off[slot] = bins.fr_off[k] + (long long)j * bins.stride[k];
+            numbers[slot] = first_number + (uint32_t)pos;
+            pos += len;
+        }
+    }
 }
 
 __global__ __launch_bounds__(SCAN_NT)
 void k_frame_offsets_perm(const int32_t *__restrict__ fbytes, const int32_t *__restrict__ order,
-                          int nframes, long long *__restrict__ offsets)
+                          const int32_t *__restrict__ dev_frames, long long *__restrict__ offsets,
+                          long long cap, long long *__restrict__ totals)
 {
     __shared__ long long s_part[SCAN_NT];
     const int tid = threadIdx.x;
+    const int nframes = dev_count(dev_frames, 0);
     const int per = (nframes + SCAN_NT - 1) / SCAN_NT;
-    const int f0 = tid * per, f1 = min(f0 + per, nframes);
+    const int f0 = min(tid * per, nframes), f1 = min(f0 + per, nframes);
     long long sum = 0;
     for (int f = f0; f < f1; f++) sum += max(fbytes[order[f]], 0);
     s_part[tid] = sum;
@@ -506,17 +580,32 @@ void k_frame_offsets_perm(const int32_t *__restrict__ fbytes, const int32_t *__r
     }
     long long run = s_part[tid] - sum;
     for (int f = f0; f < f1; f++) { offsets[f] = run; run += max(fbytes[order[f]], 0); }
-    if (tid == SCAN_NT - 1) offsets[nframes] = s_part[tid];
+    if (tid == SCAN_NT - 1) {
+        offsets[nframes] = s_part[tid];
+        // totals: frames, bytes, largest frame (k_pack_frames_perm), 1 = the stream does not fit `cap`
+        totals[0] = nframes;
+        totals[1] = s_part[tid];
+        totals[2] = 0;
+        totals[3] = (s_part[tid] > cap) ? 1 : 0;
+    }
 }
 
 __global__ __launch_bounds__(NT)
 void k_pack_frames_perm(const uint8_t *__restrict__ frames, const long long *__restrict__ src_off,
                         const int32_t *__restrict__ fbytes, const int32_t *__restrict__ order,
-                        const long long *__restrict__ offsets, uint8_t *__restrict__ packed)
+                        const long long *__restrict__ offsets, uint8_t *__restrict__ packed,
+                        const int32_t *__restrict__ dev_frames, long long cap,
+                        int32_t *__restrict__ stream_bytes, long long *__restrict__ totals)
 {
     const int f = blockIdx.x, tid = threadIdx.x;
+    if (f >= dev_count(dev_frames, 0)) return;
     const int slot = order[f];
     const int len = max(fbytes[slot], 0);
+    if (tid == 0) {
+        if (stream_bytes) stream_bytes[f] = fbytes[slot];           // the frame sizes in stream order
+        atomicMax(reinterpret_cast<unsigned long long *>(&totals[2]), (unsigned long long)len);   // encode.c:967
+    }
+    if (offsets[f] + len > cap) return;                             // the caller's buffer ends here (totals[3])
     const uint8_t *src = frames + src_off[slot];                   // 4-byte aligned
     uint8_t *dst = packed + offsets[f];
     const int head = min((int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3), len);
@@ -534,24 +623,50 @@ void k_pack_frames_perm(const uint8_t *__restrict__ frames, const long long *__r
     if (tid < len - done) dst[done + tid] = src[done + tid];
 }
 
+// bytes and frames of every block (what flake_encode_frame returns for it, vbs.c:104-116)
+__global__ __launch_bounds__(NT)
+void k_vbs_block_bytes(const int32_t *__restrict__ first, const long long *__restrict__ offsets, int nblocks,
+                       int32_t *__restrict__ block_bytes, int32_t *__restrict__ block_frames)
+{
+    const int b = blockIdx.x * NT + threadIdx.x;
+    if (b >= nblocks) return;
+    const int i0 = first[b], i1 = first[b + 1];
+    if (block_bytes) block_bytes[b] = (int32_t)(offsets[i1] - offsets[i0]);
+    if (block_frames) block_frames[b] = i1 - i0;
+}
+
 }  // namespace
 
-hipError_t launch_gather_pieces(hipStream_t st, const int32_t *pcm, const long long *src,
-                                const long long *dst, const int32_t *len, int npieces, int32_t *out)
+hipError_t launch_vbs_plan(hipStream_t st, const int32_t *nfr, const int32_t *sizes, int nblocks,
+                           int block_size, int nch, uint32_t first_number, const VbsBins &bins,
+                           int32_t *cnt, int32_t *order, long long *frame_src, long long *src_off,
+                           uint32_t *numbers, int32_t *first)
 {
-    if (npieces == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_gather_pieces, dim3(npieces), dim3(NT), 0, st, pcm, src, dst, len, out);
+    if (nblocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_vbs_plan, dim3(1), dim3(PLAN_NT), 0, st, nfr, sizes, nblocks, block_size, nch,
+                       first_number, bins, cnt, order, frame_src, src_off, numbers, first);
     return hipGetLastError();
 }
 
 hipError_t launch_pack_frames_perm(hipStream_t st, const uint8_t *frames, const long long *src_off,
-                                   const int32_t *frame_bytes, const int32_t *order, int nframes,
-                                   long long *offsets, uint8_t *packed)
+                                   const int32_t *frame_bytes, const int32_t *order, int max_frames,
+                                   const int32_t *dev_frames, long long *offsets, uint8_t *packed,
+                                   long long cap, int32_t *stream_bytes, long long *totals)
 {
-    if (nframes == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_frame_offsets_perm, dim3(1), dim3(SCAN_NT), 0, st, frame_bytes, order, nframes, offsets);
-    hipLaunchKernelGGL(k_pack_frames_perm, dim3(nframes), dim3(NT), 0, st, frames, src_off, frame_bytes,
-                       order, offsets, packed);
+    if (max_frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_frame_offsets_perm, dim3(1), dim3(SCAN_NT), 0, st, frame_bytes, order, dev_frames,
+                       offsets, cap, totals);
+    hipLaunchKernelGGL(k_pack_frames_perm, dim3(max_frames), dim3(NT), 0, st, frames, src_off, frame_bytes,
+                       order, offsets, packed, dev_frames, cap, stream_bytes, totals);
+    return hipGetLastError();
+}
+
+hipError_t launch_vbs_block_bytes(hipStream_t st, const int32_t *first, const long long *offsets, int nblocks,
+                                  int32_t *block_bytes, int32_t *block_frames)
+{
+    if (nblocks == 0 || (!block_bytes && !block_frames)) return hipSuccess;
+    hipLaunchKernelGGL(k_vbs_block_bytes, dim3((nblocks + NT - 1) / NT), dim3(NT), 0, st, first, offsets,
+                       nblocks, block_bytes, block_frames);
     return hipGetLastError();
 }
 

@@ -25,9 +25,15 @@ struct EncodeArgs {
 // decide_only: write obits / wasted / ch_mode to info[] and leave smp to the fused K1.
 // allow_narrow: a channel whose samples all fit 16 bits is stored as int16[n] at the
 // start of its row and flagged in info.reserved (see narrow_rows_ok).
+// frame_src (optional): frame f's PCM starts at pcm + frame_src[f] (int32 units) instead of
+// pcm + f*n*ch -- the pieces of a variable-block-size batch are encoded where they lie.
+// dev_frames / dev_sub (optional, every launch_* below): the launch's real frame / subframe count
+// lives on the device; nframes / nsub then size the grid (the bin's capacity) and workgroups past
+// the count leave at once (device_util.h: dev_count).
 hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *pcm,
                           int nframes, int n, int32_t *smp, fhip_subframe_info *info,
-                          bool decide_only = false, bool allow_narrow = false);
+                          bool decide_only = false, bool allow_narrow = false,
+                          const long long *frame_src = nullptr, const int32_t *dev_frames = nullptr);
 
 // True when K0, K1 and K3 all handle 16-bit sample rows for such a batch; the
 // caller then passes allow_narrow / narrow_ok to the three launches of the batch.
@@ -50,7 +56,8 @@ bool autocorr_is_wave_typed(int nsub, int n, int max_order);
 hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                            int max_order, double *autoc, const int32_t *pcm_fused = nullptr,
                            int32_t *smp_out = nullptr, const fhip_subframe_info *info = nullptr,
-                           const autocorr_lpc_out *lpc_out = nullptr, bool narrow_ok = false);
+                           const autocorr_lpc_out *lpc_out = nullptr, bool narrow_ok = false,
+                           const int32_t *dev_sub = nullptr, int nsub_hint = 0);
 
 // K2: compute_lpc_coefs / _est + quantize_lpc_coefs (lpc.c:77-257).
 // coefs [nsub][32][32], shift [nsub][32], opt_order [nsub].
@@ -62,7 +69,7 @@ constexpr int FIN_DBL = 36;         // ... the first 16 coefficients once more a
 constexpr int FIN_PAIRS = 68;       // ... and the first 8 as four int16 pairs (lo: tap 2j+2, hi: tap 2j+1)
 hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_order,
                       int precision, int omethod, int32_t *coefs, int32_t *shift,
-                      int32_t *opt_order, int32_t *fin);
+                      int32_t *opt_order, int32_t *fin, const int32_t *dev_sub = nullptr);
 
 // prep: the records K0 filled (obits, wasted, ch_mode, the 16-bit-row flag) -- the handle's
 // own buffer, never info[] itself (the kernels' pointers to the two are __restrict__); K3
@@ -75,7 +82,8 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
                          fhip_subframe_info *info,
                          int32_t *residual, uint8_t *bits, int64_t slot_bytes,
                          int raw_order = -1, int raw_lpc = 0, bool narrow_ok = false,
-                         const fhip_subframe_info *prep = nullptr, bool order_known = false);
+                         const fhip_subframe_info *prep = nullptr, bool order_known = false,
+                         const int32_t *dev_sub = nullptr);
 
 // K3-S: the LPC order searches (order methods 2..6, optimize.c:201-261) for block sizes it
 // supports: bits[order] for every order the method can visit, the method's walk over that
@@ -85,7 +93,7 @@ bool order_search_supported(const fhip_params &p, int n);
 hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32_t *smp, int nsub,
                                int n, const int32_t *coefs, const int32_t *shift,
                                int32_t *opt_order, int32_t *fin, const fhip_subframe_info *prep,
-                               bool narrow_ok);
+                               bool narrow_ok, const int32_t *dev_sub = nullptr);
 
 // K4: whole frames on the device (encode.c:718-764, :800-917, :949-964):
 // frames [nframes][frame_stride] bytes, frame_bytes [nframes].
@@ -93,7 +101,8 @@ hipError_t launch_assemble(hipStream_t st, const fhip_params &p, const int32_t *
                            int n, const fhip_subframe_info *info, const uint8_t *rice,
                            int64_t slot_bytes, uint8_t *frames, int64_t frame_stride,
                            int32_t *frame_bytes, uint32_t number_base, uint32_t number_step,
-                           const uint32_t *numbers = nullptr);
+                           const uint32_t *numbers = nullptr, const long long *frame_src = nullptr,
+                           const int32_t *dev_frames = nullptr);
 
 // K4-P: offsets[f] = exclusive scan of frame_bytes (offsets[nframes] = total) and the frames
 // copied back to back into packed[] -- the stream order flake_encode_frame's callers write.
@@ -101,15 +110,35 @@ hipError_t launch_pack_frames(hipStream_t st, const uint8_t *frames, int64_t fra
                               const int32_t *frame_bytes, int nframes, long long *offsets,
                               uint8_t *packed);
 
-// Ragged (VBS) batches on the device: pieces copied into group-contiguous arrays (src / dst in
-// int32 units, len = ints per piece, a multiple of 4), and the frames of all groups packed in
-// stream order (order[i] = slot of the stream's i-th frame, src_off[slot] = byte offset of that
-// slot's frame in frames[], 4-byte aligned).
-hipError_t launch_gather_pieces(hipStream_t st, const int32_t *pcm, const long long *src,
-                                const long long *dst, const int32_t *len, int npieces, int32_t *out);
+// Ragged (VBS) batches on the device (k4_assemble.hip).  A piece is k eighths of its block: eight
+// bins of equal piece length, bin k-1 with a fixed range of frame slots for the most pieces it
+// can get (floor(8 / k) per block).  Host constants per bin:
+struct VbsBins {
+    int n[8];                 // piece length k * block_size / 8
+    int cap[8];               // frame slots: floor(8 / k) * nblocks
+    int slot0[8];             // first frame slot (subframe-indexed workspaces: slot0 * channels)
+    long long smp_off[8];     // first sample of the bin's rows in smp[] (int32 units)
+    long long stride[8];      // fhip_frame_stride of the piece length
+    long long fr_off[8];      // byte offset of the bin's frames in frames[]
+    long long slot[8];        // residual-section slot bytes of the piece length
+    long long bits_off[8];    // byte offset of the bin's sections in rice_bits[]
+};
+// CNT_*: layout of the device-side counts k_vbs_plan leaves (int32[24])
+constexpr int VBS_CNT_FRAMES = 0, VBS_CNT_SUB = 8, VBS_CNT_ALL = 16, VBS_CNT_WORDS = 24;
+hipError_t launch_vbs_plan(hipStream_t st, const int32_t *nfr, const int32_t *sizes, int nblocks,
+                           int block_size, int nch, uint32_t first_number, const VbsBins &bins,
+                           int32_t *cnt, int32_t *order, long long *frame_src, long long *src_off,
+                           uint32_t *numbers, int32_t *first);
+// The frames of all bins packed in stream order: order[i] = slot of the stream's i-th frame,
+// src_off[slot] = byte offset of that slot's frame in frames[] (4-byte aligned), *dev_frames of them
+// (<= max_frames); offsets[i] / offsets[count] as in launch_pack_frames; stream_bytes[i] (optional)
+// = size of the stream's i-th frame; totals[4] = {frames, bytes, largest frame, stream > cap}.
 hipError_t launch_pack_frames_perm(hipStream_t st, const uint8_t *frames, const long long *src_off,
-                                   const int32_t *frame_bytes, const int32_t *order, int nframes,
-                                   long long *offsets, uint8_t *packed);
+                                   const int32_t *frame_bytes, const int32_t *order, int max_frames,
+                                   const int32_t *dev_frames, long long *offsets, uint8_t *packed,
+                                   long long cap, int32_t *stream_bytes, long long *totals);
+hipError_t launch_vbs_block_bytes(hipStream_t st, const int32_t *first, const long long *offsets, int nblocks,
+                                  int32_t *block_bytes, int32_t *block_frames);
 
 // K-vbs: split_frame_v1 (vbs.c:36-83) for nblocks blocks: nframes_out [nblocks],
 // sizes_out [nblocks][8].

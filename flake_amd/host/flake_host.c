@@ -36,6 +36,8 @@ typedef struct host_ctx {
     fhip_ctx *hip2;                       /* second handle: chunks of a large batch alternate between two
                                              host threads so that uploads, kernels and downloads overlap */
     int chunk_frames;                     /* FLAKE_AMD_CHUNK (default 1024); 0 = one handle, one pass */
+    int hip2_state;                       /* 0 not created yet, 1 created, -1 not wanted or creation failed */
+    int device;
     fhip_params hp;
     int max_batch;                        /* blocks per GPU batch */
     int sr_code[2], bps_code, ch_code;
@@ -389,9 +391,9 @@ FLAKE_AMD_API int flake_amd_encode_init(FlakeAmdContext *s)
         const char *ec = getenv("FLAKE_AMD_CHUNK");
         c->chunk_frames = ec ? atoi(ec) : 1024;
         if (c->chunk_frames < 0) c->chunk_frames = 0;
-        if (c->chunk_frames > 0 && c->max_batch >= 2 * c->chunk_frames && !c->host_assembly &&
-            fhip_create(&c->hip2, ed ? atoi(ed) : 0, hp, c->chunk_frames) != FHIP_OK)
-            c->hip2 = NULL;                                        /* fine: one handle, one pass */
+        /* (the second handle and its workspaces are created by the first batch that qualifies) */
+        c->hip2_state = (c->chunk_frames > 0 && c->max_batch >= 2 * c->chunk_frames && !c->host_assembly) ? 0 : -1;
+        c->device = ed ? atoi(ed) : 0;
     }
     c->slot = (frame_verbatim_size(c, s->params.block_size) + 3) & ~3;
     const size_t nsub = (size_t)max_frames * (size_t)s->channels;
@@ -665,6 +667,9 @@ static void *chunk_worker(void *arg)
         while (!j->sy->failed && k > 0 && j->sy->end[k - 1] < 0) pthread_cond_wait(&j->sy->cv, &j->sy->mu);
         const long long start = (k > 0) ? j->sy->end[k - 1] : 0;
         if (rc != FHIP_OK || j->sy->failed || start + total > j->cap) {
+            if (rc == FHIP_OK && !j->sy->failed)
+                snprintf(c->err, sizeof c->err, "output buffer too small: chunk %d ends at byte %lld of %lld",
+                         k, start + (long long)total, j->cap);
             j->sy->failed = 1;
             j->sy->end[k] = 0;
             pthread_cond_broadcast(&j->sy->cv);
@@ -696,7 +701,8 @@ static long long run_chunked(host_ctx *c, const int32_t *pcm, int np, int n, int
     const int nchunks = (np + chunk - 1) / chunk;
     chunk_sync sy;
     long long *end = (long long *)malloc(sizeof(long long) * (size_t)nchunks);
-    if (!end) return -1;
+    if (!end) { snprintf(c->err, sizeof c->err, "chunked batch: out of host memory"); return -1; }
+    c->err[0] = 0;
     for (int k = 0; k < nchunks; k++) end[k] = -1;
     pthread_mutex_init(&sy.mu, NULL);
     pthread_cond_init(&sy.cv, NULL);
@@ -719,8 +725,9 @@ static long long run_chunked(host_ctx *c, const int32_t *pcm, int np, int n, int
     }
     long long total = -1;
     if (!sy.failed && ja.rc == FHIP_OK && (!have_b || jb.rc == FHIP_OK)) total = end[nchunks - 1];
-    else snprintf(c->err, sizeof c->err, "chunked batch failed: %s / %s", fhip_last_error(c->hip),
-                  c->hip2 ? fhip_last_error(c->hip2) : "");
+    else if (!c->err[0])
+        snprintf(c->err, sizeof c->err, "chunked batch failed: %s (%s) / %s (%s)", fhip_strerror(ja.rc),
+                 fhip_last_error(c->hip), have_b ? fhip_strerror(jb.rc) : "-", c->hip2 ? fhip_last_error(c->hip2) : "");
     pthread_mutex_destroy(&sy.mu);
     pthread_cond_destroy(&sy.cv);
     free(end);
@@ -837,6 +844,9 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
             for (int i = 0; i < np; i++) c->fnum[i] = num_of[i];
             b.frame_numbers = c->fnum;
             int64_t wrote = 0;
+            if (c->hip2_state == 0 && c->chunk_frames > 0 && np >= 2 * c->chunk_frames)
+                c->hip2_state = (fhip_create(&c->hip2, c->device, &c->hp, c->chunk_frames) == FHIP_OK) ? 1 : -1;
+            if (c->hip2_state < 0) c->hip2 = NULL;                 /* fine: one handle, one pass */
             if (c->hip2 && c->chunk_frames > 0 && np >= 2 * c->chunk_frames) {
                 wrote = run_chunked(c, pieces[0].pcm, np, pieces[0].n, nch, out, cap);
                 if (wrote < 0) goto out;

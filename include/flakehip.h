@@ -193,8 +193,8 @@ FHIP_API int fhip_frames_packed_fetch(fhip_ctx *ctx, uint8_t *out, int64_t out_c
 
 /* The same for a variable-block-size stream (encode_frame_vbs, vbs.c:85-119, per block):
  * nblocks blocks of block_size samples in host memory -> every block split by split_frame_v1
- * (vbs.c:36-83) on the device, the pieces encoded (one pass of the path per distinct piece
- * length, the pieces gathered on the device), the frames packed in stream order and fetched.
+ * (vbs.c:36-83) on the device, the pieces encoded (one pass of the path per piece length,
+ * fhip_encode_blocks_vbs_dev below), the frames packed in stream order and fetched.
  * Frames are numbered by their first sample (encode.c:969-975: allow_vbs), starting at
  * first_frame_number for the first sample of pcm.  block_bytes[b] = bytes of block b's frames
  * (the return value of flake_encode_frame for that block); block_frames[b] (optional) = how many
@@ -206,6 +206,32 @@ FHIP_API int fhip_encode_blocks_vbs_packed(fhip_ctx *ctx, const int32_t *pcm, in
                                            uint8_t *out, int64_t out_cap, int32_t *block_bytes,
                                            int32_t *block_frames, int64_t *out_bytes,
                                            int32_t *max_frame_bytes, uint32_t *next_frame_number);
+
+/* The same with the blocks and the stream DEVICE-RESIDENT, and no host synchronisation inside:
+ * pcm (device) -> split_frame_v1 per block, the piece tables (a piece is k eighths of its block:
+ * eight bins of equal length, counted and scanned on the device), the path once per bin with the
+ * pieces encoded where they lie, the frames packed in stream order into out->packed (device).
+ * Asynchronous on the handle's stream; the host learns nothing about the split unless it reads
+ * the outputs back.  All pointers in fhip_vbs_out are device pointers:
+ *   packed        the frames back to back (vbs.c:104-116 for every block, concatenated)
+ *   packed_cap    its size in bytes; a stream that does not fit sets totals[3] and frames past
+ *                 the end are not written
+ *   frame_bytes   optional [8 * nblocks]: size of the stream's i-th frame, i < totals[0]
+ *   block_bytes   optional [nblocks]: bytes of block b's frames (flake_encode_frame's return value)
+ *   block_frames  optional [nblocks]: frames block b became (1 = left whole, vbs.c:100)
+ *   totals        [4] int64: frames, bytes, largest frame (encode.c:967), 1 if the stream was cut
+ * Frame numbers as in fhip_encode_blocks_vbs_packed.  The handle: variable_block_size and
+ * allow_vbs set, max_frames >= 8 * nblocks. */
+typedef struct fhip_vbs_out {
+    uint8_t  *packed;
+    int64_t   packed_cap;
+    int32_t  *frame_bytes;
+    int32_t  *block_bytes;
+    int32_t  *block_frames;
+    int64_t  *totals;
+} fhip_vbs_out;
+FHIP_API int fhip_encode_blocks_vbs_dev(fhip_ctx *ctx, const int32_t *pcm, int nblocks, int block_size,
+                                        uint32_t first_frame_number, const fhip_vbs_out *out);
 
 /* Optional hint for a caller that streams batch after batch through one handle
  * (flake.c:622-663 calls flake_encode_frame block after block): start the feeder

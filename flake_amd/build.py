@@ -18,9 +18,9 @@ PKG = os.path.join(ROOT, "flake_amd")
 LIB = os.path.join(PKG, "lib")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-HIP_SRCS = ["csrc/k0_prepare.hip", "csrc/k1_autocorr.hip", "csrc/k2_lpc.hip", "csrc/k3_encode.hip",
+HIP_SRCS = ["csrc/k0_prepare.hip", "csrc/k1_autocorr.hip", "csrc/k2_lpc.hip", "csrc/k3_encode.hip", "csrc/k3s_search.hip",
             "csrc/k4_assemble.hip", "csrc/api.hip"]
-HIP_HDRS = ["csrc/kernels.h", "csrc/device_util.h", "csrc/lpc_reg.h", "../include/flakehip.h"]
+HIP_HDRS = ["csrc/kernels.h", "csrc/device_util.h", "csrc/lpc_reg.h", "csrc/k3_common.h", "../include/flakehip.h"]
 HIP_DEPS = HIP_SRCS + HIP_HDRS
 HOST_SRCS = ["host/flake_host.c", "host/synth.c", "host/md5.c"]
 HOST_DEPS = HOST_SRCS + ["host/host_internal.h", "../include/flakehip.h", "../include/flake_amd.h"]

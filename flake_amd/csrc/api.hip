@@ -874,28 +874,133 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
     bool fan = !vbs_serial && !c->profiling;
     for (int h = 0; h < vbs_streams; h++) fan = fan && c->aux[h];
     FanJoin fj(c, vbs_streams);
-    if (fan) HIP_TRY(c, fj.fork());
+    const int hint_frames = std::max(1, nblocks / 2);
+    const int32_t *cnt_frames = c->d_vcnt + fhip::VBS_CNT_FRAMES, *cnt_sub = c->d_vcnt + fhip::VBS_CNT_SUB;
+    struct MaybeProf {
+        Prof *p;
+        MaybeProf(fhip_ctx *cc, bool on, int i) : p(on ? new Prof(cc, i) : nullptr) {}
+        ~MaybeProf() { delete p; }
+    };
+    // the stream a bin's launches go to: the one with least capacity queued
     long long queued[NA] = {0};
-    for (int k = 7; k >= 0; k--) {
-        const int n = vb.n[k];
-        const size_t sub0 = (size_t)vb.slot0[k] * nch;
-        const FrameOut fo{c->d_frames + vb.fr_off[k], vb.stride[k], c->d_fbytes + vb.slot0[k], 0,
-                          c->d_fnum + vb.slot0[k]};
-        const Ragged rg{c->d_frame_src + vb.slot0[k], c->d_vcnt + fhip::VBS_CNT_FRAMES + k,
-                        c->d_vcnt + fhip::VBS_CNT_SUB + k, std::max(1, nblocks / 2)};
-        hipStream_t st = c->stream;
-        if (fan) {
-            int h = 0;
-            for (int q = 1; q < vbs_streams; q++) if (queued[q] < queued[h]) h = q;
-            queued[h] += (long long)vb.cap[k] * n;
-            st = c->aux[h];
+    auto pick_stream = [&](int k) -> hipStream_t {
+        if (!fan) return c->stream;
+        int h = 0;
+        for (int q = 1; q < vbs_streams; q++) if (queued[q] < queued[h]) h = q;
+        queued[h] += (long long)vb.cap[k] * vb.n[k];
+        return c->aux[h];
+    };
+
+    // K1, K2 and K4 do not depend on the piece length: ONE launch each over all bins (kernels.h:
+    // MultiBin) where every bin is whole K1 tiles; K0, the order search and K3 run per bin
+    const bool lpc_path = p.prediction_type == 2;
+    if (lpc_path && fhip::autocorr_bins_supported(p.max_prediction_order, vb.n, 8)) {
+        const bool prof = c->profiling;
+        bool narrow[8];
+        // ---- K0 per bin ----
+        if (fan) HIP_TRY(c, fj.fork());
+        for (int k = 7; k >= 0; k--) {
+            const size_t sub0 = (size_t)vb.slot0[k] * nch;
+            narrow[k] = fhip::narrow_rows_ok(p, hint_frames * (int)nch, vb.n[k], true, true);
+            MaybeProf pr(c, prof, 0);
+            HIP_TRY(c, fhip::launch_prepare(pick_stream(k), p, pcm, vb.cap[k], vb.n[k], c->d_smp + vb.smp_off[k],
+                                            c->d_k0rec + sub0, false, narrow[k], c->d_frame_src + vb.slot0[k],
+                                            cnt_frames + k));
         }
-        rc = run_range(c, st, c->profiling && !fan, pcm, vb.cap[k], n, c->d_info + sub0, nullptr,
-                       c->d_bits + vb.bits_off[k], vb.slot[k], c->d_smp + vb.smp_off[k],
-                       c->d_autoc + sub0 * FHIP_MAX_LAGS, sub0, fo, false, nullptr, false, &rg);
-        if (rc != FHIP_OK) return rc;                       // (~FanJoin joins what was queued)
+        HIP_TRY(c, fj.join());
+        // ---- K1 (+ K2) over all bins, longest chains first ----
+        const bool lpc_tail = p.max_prediction_order <= 12 && getenv("FHIP_NO_LPC_TAIL") == nullptr;
+        fhip::MultiBin m1{};
+        m1.nbins = 8;
+        m1.cnt = cnt_sub;
+        int wg = 0;
+        for (int j = 0; j < 8; j++) {
+            const int k = 7 - j;
+            m1.cnt_ix[j] = k;
+            m1.wg0[j] = wg;
+            wg += (vb.cap[k] * (int)nch + 31) / 32;
+            m1.n[j] = vb.n[k];
+            m1.unit0[j] = vb.slot0[k] * (int)nch;
+            m1.cap[j] = vb.cap[k] * (int)nch;
+            m1.narrow[j] = narrow[k] ? 1 : 0;
+            m1.smp_off[j] = vb.smp_off[k];
+            m1.c[j] = (2.0 / (vb.n[k] - 1.0)) - 1.0;                  // lpc.c:34, on the host as launch_autocorr does
+        }
+        m1.wg0[8] = wg;
+        const fhip::autocorr_lpc_out lo{p.lpc_precision, p.order_method, c->d_coefs, c->d_shift, c->d_opt, c->d_fin};
+        {
+            MaybeProf pr(c, prof, 1);
+            HIP_TRY(c, fhip::launch_autocorr_bins(c->stream, m1, c->d_smp, p.max_prediction_order, c->d_autoc,
+                                                  c->d_k0rec, lpc_tail ? &lo : nullptr));
+        }
+        fhip::MultiBin m2{};                                          // bins in slot order: K2, K4
+        m2.nbins = 8;
+        for (int k = 0; k < 8; k++) {
+            m2.cnt_ix[k] = k;
+            m2.wg0[k] = vb.slot0[k];
+            m2.n[k] = vb.n[k];
+            m2.cap[k] = vb.cap[k];
+            m2.unit0[k] = vb.slot0[k];
+            m2.stride[k] = vb.stride[k]; m2.fr_off[k] = vb.fr_off[k];
+            m2.slot[k] = vb.slot[k]; m2.bits_off[k] = vb.bits_off[k];
+            const int bps = p.bits_per_sample;
+            m2.vsize[k] = (p.channels == 2) ? 16 + ((vb.n[k] * (bps + bps + 1) + 7) >> 3)
+                                            : 16 + ((vb.n[k] * p.channels * bps + 7) >> 3);
+        }
+        m2.wg0[8] = vb.slot0[7] + vb.cap[7];
+        if (!lpc_tail) {
+            fhip::MultiBin mk = m2;                                   // K2's units are subframes
+            mk.cnt = cnt_sub;
+            for (int k = 0; k < 8; k++) { mk.unit0[k] = vb.slot0[k] * (int)nch; mk.cap[k] = vb.cap[k] * (int)nch; }
+            MaybeProf pr(c, prof, 2);
+            HIP_TRY(c, fhip::launch_lpc_bins(c->stream, mk, c->d_autoc, p.max_prediction_order, p.lpc_precision,
+                                             p.order_method, c->d_coefs, c->d_shift, c->d_opt, c->d_fin));
+        }
+        // ---- order search + K3 per bin ----
+        if (fan) HIP_TRY(c, fj.fork());
+        for (int q = 0; q < NA; q++) queued[q] = 0;
+        for (int k = 7; k >= 0; k--) {
+            const int n = vb.n[k];
+            const size_t sub0 = (size_t)vb.slot0[k] * nch;
+            const int nsub_cap = vb.cap[k] * (int)nch;
+            hipStream_t st = pick_stream(k);
+            int32_t *coefs = c->d_coefs + sub0 * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
+            int32_t *shift = c->d_shift + sub0 * FHIP_MAX_ORDER;
+            int32_t *opt = c->d_opt + sub0, *fin = c->d_fin + sub0 * fhip::FIN_STRIDE;
+            const bool searched = fhip::order_search_supported(p, n);
+            if (searched) {
+                MaybeProf pr(c, prof, 5);
+                HIP_TRY(c, fhip::launch_order_search(st, p, c->d_smp + vb.smp_off[k], nsub_cap, n, coefs, shift, opt,
+                                                     fin, c->d_k0rec + sub0, narrow[k], cnt_sub + k));
+            }
+            MaybeProf pr(c, prof, 3);
+            HIP_TRY(c, fhip::launch_encode(st, p, c->d_smp + vb.smp_off[k], nsub_cap, n, coefs, shift, opt, fin,
+                                           c->d_info + sub0, nullptr, c->d_bits + vb.bits_off[k], vb.slot[k], -1, 0,
+                                           narrow[k], c->d_k0rec + sub0, searched, cnt_sub + k));
+        }
+        HIP_TRY(c, fj.join());
+        // ---- K4 over all bins ----
+        m2.cnt = cnt_frames;
+        {
+            MaybeProf pr(c, prof, 4);
+            HIP_TRY(c, fhip::launch_assemble_bins(c->stream, p, m2, pcm, c->d_info, c->d_bits, c->d_frames, c->d_fbytes,
+                                                  c->d_fnum, c->d_frame_src));
+        }
+    } else {
+        if (fan) HIP_TRY(c, fj.fork());
+        for (int k = 7; k >= 0; k--) {
+            const int n = vb.n[k];
+            const size_t sub0 = (size_t)vb.slot0[k] * nch;
+            const FrameOut fo{c->d_frames + vb.fr_off[k], vb.stride[k], c->d_fbytes + vb.slot0[k], 0,
+                              c->d_fnum + vb.slot0[k]};
+            const Ragged rg{c->d_frame_src + vb.slot0[k], cnt_frames + k, cnt_sub + k, hint_frames};
+            rc = run_range(c, pick_stream(k), c->profiling && !fan, pcm, vb.cap[k], n, c->d_info + sub0, nullptr,
+                           c->d_bits + vb.bits_off[k], vb.slot[k], c->d_smp + vb.smp_off[k],
+                           c->d_autoc + sub0 * FHIP_MAX_LAGS, sub0, fo, false, nullptr, false, &rg);
+            if (rc != FHIP_OK) return rc;                       // (~FanJoin joins what was queued)
+        }
+        HIP_TRY(c, fj.join());
     }
-    HIP_TRY(c, fj.join());
     HIP_TRY(c, fhip::launch_pack_frames_perm(c->stream, c->d_frames, c->d_srcoff, c->d_fbytes, c->d_order,
                                              8 * nblocks, c->d_vcnt + fhip::VBS_CNT_ALL, c->d_offsets,
                                              o.packed, o.cap, o.stream_bytes, o.totals));

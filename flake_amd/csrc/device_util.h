@@ -71,6 +71,25 @@ __device__ __forceinline__ int dev_count(const int32_t *__restrict__ dev, int ho
     return dev ? __builtin_amdgcn_readfirstlane(*dev) : host;
 }
 
+// kernels.h MultiBin: is unit s (an index into the handle's unit-indexed workspaces) a live unit of
+// its bin?  (per lane)
+__device__ __forceinline__ bool bin_unit_live(const MultiBin &mb, int s)
+{
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < 8; q++) if (q < mb.nbins && s >= mb.unit0[q]) k = q;
+    return s - mb.unit0[k] < mb.cnt[mb.cnt_ix[k]];
+}
+
+// kernels.h MultiBin: which bin a workgroup belongs to (wave-uniform)
+__device__ __forceinline__ int find_bin(const MultiBin &mb, int blk)
+{
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < 8; q++) if (q < mb.nbins && blk >= mb.wg0[q]) k = q;
+    return k;
+}
+
 __device__ __forceinline__ uint32_t zigzag32(int32_t x)
 {
     // rice.c:122 (search side) and bitio.h:128-129 (emit side): same map

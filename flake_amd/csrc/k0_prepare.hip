@@ -131,6 +131,7 @@ void k_prepare(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
             o->obits = obits[tid];
             o->wasted = wasted[tid];
             o->ch_mode = mode;
+            o->reserved = 0;               // no 16-bit rows, magnitude not known (see k_prepare_stereo)
         }
     }
 }
@@ -203,6 +204,7 @@ void k_prepare_multi(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
                 oi->obits = bps - w;
                 oi->wasted = w;
                 oi->ch_mode = FHIP_CH_NOT_STEREO;
+                oi->reserved = 0;
             }
         }
     }
@@ -496,7 +498,9 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
         o->obits = obits[tid];
         o->wasted = wasted[tid];
         o->ch_mode = mode;
-        o->reserved = narrow[tid] ? 1 + magbits[tid] : 0;     // 1..16: narrow row, |x| <= 2^(reserved-1)
+        // low byte 1..16: narrow row, |x| < 2^(low byte - 1); bits 8..15: 1 + magbits whatever the row's
+        // width (the order-search kernel's packed FIR asks for it on int32 rows too)
+        o->reserved = (narrow[tid] ? 1 + magbits[tid] : 0) | ((1 + magbits[tid]) << 8);
     }
 }
 

@@ -520,15 +520,35 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                    int nsub, int n, int maxlag, wt_groups grp, double c,
                    const int32_t *__restrict__ pcm, int32_t *__restrict__ smp_out,
                    const fhip_subframe_info *__restrict__ info, wt_lpc_args lpc, int narrow_ok,
-                   const int32_t *__restrict__ dev_sub)
+                   const int32_t *__restrict__ dev_sub, MultiBin mb)
 {
     extern __shared__ __attribute__((aligned(16))) double wt_lds[];
     double *acbuf = wt_lds + WT_NBUF * WT_BUF;          // [32][FHIP_MAX_LAGS], LPCMO > 0 only
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int sub0 = blockIdx.x * WT_SUB;
-    nsub = dev_count(dev_sub, nsub);
+    int blk = blockIdx.x;
+    if (mb.nbins) {
+        // every bin of a ragged batch in one launch (kernels.h: MultiBin): this workgroup's bin,
+        // its block size and window constant, its rows and its range of the subframe-indexed arrays
+        const int k = find_bin(mb, blk);
+        blk -= mb.wg0[k];
+        n = mb.n[k];
+        c = mb.c[k];
+        narrow_ok = mb.narrow[k];
+        nsub = __builtin_amdgcn_readfirstlane(mb.cnt[mb.cnt_ix[k]]);
+        const size_t u0 = (size_t)mb.unit0[k];
+        smp += mb.smp_off[k];
+        autoc += u0 * FHIP_MAX_LAGS;
+        info += u0;
+        lpc.coefs += u0 * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
+        lpc.shift += u0 * FHIP_MAX_ORDER;
+        lpc.opt_order += u0;
+        lpc.fin += u0 * FIN_STRIDE;
+    } else {
+        nsub = dev_count(dev_sub, nsub);
+    }
+    const int sub0 = blk * WT_SUB;
     if (sub0 >= nsub) return;                           // (a ragged batch's grid is its bin's capacity)
     const int half = n >> 1;
     const int ntiles = n / AC_TILE;
@@ -572,7 +592,7 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                 } else {
                     const int sub = min(sub0 + q0 + r, nsub - 1);
                     rowb[r] = uni64((unsigned long long)(smp + (size_t)sub * n));
-                    nar[r] = narrow_ok ? __builtin_amdgcn_readfirstlane(info[sub].reserved) : 0;
+                    nar[r] = narrow_ok ? (__builtin_amdgcn_readfirstlane(info[sub].reserved) & 0xFF) : 0;
                 }
             }
             typedef typename std::conditional<FUSED, int4, int2>::type ld_t;
@@ -693,7 +713,7 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
         const int q0w = (wv == 4) ? 0 : WT_ROWS0 + (wv - 5) * WT_ROWS1;
         const int nrw = (wv == 4) ? WT_ROWS0 : WT_ROWS1;
         bool alln = !FUSED && narrow_ok != 0;
-        for (int r = 0; alln && r < nrw; r++) alln = info[min(sub0 + q0w + r, nsub - 1)].reserved != 0;
+        for (int r = 0; alln && r < nrw; r++) alln = (info[min(sub0 + q0w + r, nsub - 1)].reserved & 0xFF) != 0;
         alln = __builtin_amdgcn_readfirstlane((int)alln) != 0;
         if (wv == 4) {
             if (alln) produce(std::integral_constant<int, WT_ROWS0>{}, q0w, std::true_type{});
@@ -930,6 +950,82 @@ bool autocorr_fuses_prepare(const fhip_params &p, int nsub, int n)
     return pick_autocorr(nsub, n, p.max_prediction_order).kernel == 2;
 }
 
+bool autocorr_bins_supported(int max_order, const int *n, int nbins)
+{
+    static const bool off = getenv("FHIP_NO_MULTIBIN") != nullptr;      // measurements only
+    if (off || nbins < 1 || nbins > 8 || max_order < 1 || max_order > FHIP_MAX_ORDER) return false;
+    for (int k = 0; k < nbins; k++) if (n[k] < AC_TILE || (n[k] % AC_TILE) != 0 || n[k] <= max_order) return false;
+    return true;
+}
+
+// K1 (wave-typed kernel, K2 as its tail where the order fits registers) for all bins of a ragged
+// batch in one launch: the launch lasts as long as the longest chain walk, not the sum of eight.
+hipError_t launch_autocorr_bins(hipStream_t st, const MultiBin &mb, const int32_t *smp, int max_order,
+                                double *autoc, const fhip_subframe_info *info,
+                                const autocorr_lpc_out *lpc_out)
+{
+    if (!autocorr_bins_supported(max_order, mb.n, mb.nbins)) return hipErrorInvalidValue;
+    const int ne = max_order / 2 + 1, no = (max_order + 1) / 2;
+    const int e0 = (ne + 1) / 2, e1 = ne - e0, o0 = (no + 1) / 2, o1 = no - o0;
+    wt_groups gr;
+    gr.l0[0] = 0;          gr.nch[0] = e0;
+    gr.l0[1] = 2 * e0;     gr.nch[1] = e1;
+    gr.l0[2] = 1;          gr.nch[2] = o0;
+    gr.l0[3] = 1 + 2 * o0; gr.nch[3] = o1;
+    const int nch = e0;
+    const int blocks = mb.wg0[mb.nbins];
+    if (blocks == 0) return hipSuccess;
+    wt_lpc_args la{};
+    int lpcmo = 0;
+    if (lpc_out) {
+        if (max_order > 12) return hipErrorInvalidValue;
+        la.precision = lpc_out->precision; la.omethod = lpc_out->omethod;
+        la.coefs = lpc_out->coefs; la.shift = lpc_out->shift; la.opt_order = lpc_out->opt_order;
+        la.fin = lpc_out->fin;
+        lpcmo = (max_order <= 8) ? 8 : 12;
+    }
+    const size_t lds = sizeof(double) * (size_t)WT_NBUF * WT_BUF +
+                       (lpcmo ? sizeof(double) * (size_t)WT_SUB * FHIP_MAX_LAGS : 0);
+#define LAUNCH_WTB(N_, L_)                                                                   \
+    do {                                                                                     \
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_autocorr_wt<N_, false, L_>), \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (er != hipSuccess) return er;                                                     \
+        hipLaunchKernelGGL((k_autocorr_wt<N_, false, L_>), dim3(blocks), dim3(8 * WAVE), lds, st, smp, \
+                           autoc, 0, 0, max_order, gr, 0.0, (const int32_t *)nullptr, (int32_t *)nullptr, info, la, 0, \
+                           (const int32_t *)nullptr, mb);                                    \
+    } while (0)
+    if (lpcmo == 8) {
+        switch (nch) {
+        case 1: LAUNCH_WTB(1, 8); break;
+        case 2: LAUNCH_WTB(2, 8); break;
+        case 3: LAUNCH_WTB(3, 8); break;
+        default: return hipErrorInvalidValue;
+        }
+    } else if (lpcmo == 12) {
+        switch (nch) {
+        case 3: LAUNCH_WTB(3, 12); break;
+        case 4: LAUNCH_WTB(4, 12); break;
+        default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (nch) {
+        case 1: LAUNCH_WTB(1, 0); break;
+        case 2: LAUNCH_WTB(2, 0); break;
+        case 3: LAUNCH_WTB(3, 0); break;
+        case 4: LAUNCH_WTB(4, 0); break;
+        case 5: LAUNCH_WTB(5, 0); break;
+        case 6: LAUNCH_WTB(6, 0); break;
+        case 7: LAUNCH_WTB(7, 0); break;
+        case 8: LAUNCH_WTB(8, 0); break;
+        case 9: LAUNCH_WTB(9, 0); break;
+        default: return hipErrorInvalidValue;
+        }
+    }
+#undef LAUNCH_WTB
+    return hipGetLastError();
+}
+
 hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                            int max_order, double *autoc, const int32_t *pcm_fused,
                            int32_t *smp_out, const fhip_subframe_info *info,
@@ -973,7 +1069,7 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all); \
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_autocorr_wt<N_, F_, L_>), dim3(blocks), dim3(8 * WAVE), lds_all, st, smp, \
-                           autoc, nsub, n, max_order, gr, c, pcm_fused, smp_out, info, la, narrow_ok ? 1 : 0, dev_sub); \
+                           autoc, nsub, n, max_order, gr, c, pcm_fused, smp_out, info, la, narrow_ok ? 1 : 0, dev_sub, MultiBin{}); \
     } while (0)
 #define LAUNCH_WT(N_)                                                                        \
     case N_:                                                                                 \

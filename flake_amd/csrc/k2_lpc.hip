@@ -63,13 +63,14 @@ constexpr int LPC_DBL = 33 + 32 + 32;
 __global__ __launch_bounds__(LPC_NT)
 void k_lpc(const double *__restrict__ autoc_all, int nsub, int max_order, int precision,
            int omethod, int32_t *__restrict__ coefs, int32_t *__restrict__ shift,
-           int32_t *__restrict__ opt_order, int32_t *__restrict__ fin, const int32_t *__restrict__ dev_sub)
+           int32_t *__restrict__ opt_order, int32_t *__restrict__ fin, const int32_t *__restrict__ dev_sub,
+           MultiBin mb)
 {
     __shared__ double s_mem[LPC_DBL * LPC_NT];
     const int lane = threadIdx.x;
     const int s = blockIdx.x * LPC_NT + lane;
-    nsub = dev_count(dev_sub, nsub);
-    if (s >= nsub) return;
+    if (mb.nbins) { if (s >= nsub || !bin_unit_live(mb, s)) return; }       // every bin of a ragged batch at once
+    else { nsub = dev_count(dev_sub, nsub); if (s >= nsub) return; }
 
     LaneArr R0{s_mem + lane};
     LaneArr R1{s_mem + 33 * LPC_NT + lane};
@@ -176,11 +177,12 @@ template <int MO>
 __global__ __launch_bounds__(LPC_NT)
 void k_lpc_reg(const double *__restrict__ autoc_all, int nsub, int max_order, int precision,
                int omethod, int32_t *__restrict__ coefs, int32_t *__restrict__ shift,
-               int32_t *__restrict__ opt_order, int32_t *__restrict__ fin, const int32_t *__restrict__ dev_sub)
+               int32_t *__restrict__ opt_order, int32_t *__restrict__ fin, const int32_t *__restrict__ dev_sub,
+               MultiBin mb)
 {
     const int s = blockIdx.x * LPC_NT + threadIdx.x;
-    nsub = dev_count(dev_sub, nsub);
-    if (s >= nsub) return;
+    if (mb.nbins) { if (s >= nsub || !bin_unit_live(mb, s)) return; }
+    else { nsub = dev_count(dev_sub, nsub); if (s >= nsub) return; }
     double ac[MO + 1];
 #pragma unroll
     for (int i = 0; i <= MO; i++) ac[i] = (i <= max_order) ? autoc_all[(size_t)s * FHIP_MAX_LAGS + i] : 0.0;
@@ -240,17 +242,20 @@ __device__ __forceinline__ void quantize_row_lds(const double *__restrict__ a, i
 __global__ __launch_bounds__(LR_NT)
 void k_lpc_rows(const double *__restrict__ autoc_all, int nsub, int max_order, int precision,
                 int32_t *__restrict__ coefs, int32_t *__restrict__ shift,
-                int32_t *__restrict__ opt_order, const int32_t *__restrict__ dev_sub)
+                int32_t *__restrict__ opt_order, const int32_t *__restrict__ dev_sub, MultiBin mb)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *rows = reinterpret_cast<double *>(lds_raw);              // [LR_SUB][LR_STRIDE]
     constexpr int MO = FHIP_MAX_ORDER;
     const int tid = threadIdx.x;
     const int s0 = blockIdx.x * LR_SUB;
-    nsub = dev_count(dev_sub, nsub);
+    if (!mb.nbins) nsub = dev_count(dev_sub, nsub);
     if (s0 >= nsub) return;
+    // (every bin of a ragged batch at once: nsub is the workspaces' capacity, a unit is live
+    // when its bin's count says so)
+    auto live = [&](int s) { return s < nsub && (!mb.nbins || bin_unit_live(mb, s)); };
 
-    if (tid < LR_SUB && s0 + tid < nsub) {
+    if (tid < LR_SUB && live(s0 + tid)) {
         const int s = s0 + tid;
         double ac[MO + 1];
 #pragma unroll
@@ -299,7 +304,7 @@ void k_lpc_rows(const double *__restrict__ autoc_all, int nsub, int max_order, i
     for (int item = tid; item < LR_SUB * MO; item += LR_NT) {
         const int sub = item >> 5, row = item & 31;
         const int s = s0 + sub;
-        if (s >= nsub || row >= max_order) continue;
+        if (!live(s) || row >= max_order) continue;
         quantize_row_lds(rows + sub * LR_STRIDE + row * (row + 1) / 2, row + 1, precision,
                          coefs + ((size_t)s * FHIP_MAX_ORDER + row) * FHIP_MAX_ORDER,
                          shift + (size_t)s * FHIP_MAX_ORDER + row);
@@ -308,18 +313,41 @@ void k_lpc_rows(const double *__restrict__ autoc_all, int nsub, int max_order, i
 
 }  // namespace
 
+static hipError_t launch_lpc_any(hipStream_t st, const double *autoc, int nsub, int max_order,
+                                 int precision, int omethod, int32_t *coefs, int32_t *shift,
+                                 int32_t *opt_order, int32_t *fin, const int32_t *dev_sub, const MultiBin &mb);
+
 hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_order,
                       int precision, int omethod, int32_t *coefs, int32_t *shift,
                       int32_t *opt_order, int32_t *fin, const int32_t *dev_sub)
+{
+    return launch_lpc_any(st, autoc, nsub, max_order, precision, omethod, coefs, shift, opt_order, fin, dev_sub,
+                          MultiBin{});
+}
+
+// K2 for every bin of a ragged batch at once (the recursion does not depend on the block size):
+// the grid covers the workspaces' whole unit range, a unit is live when its bin's count says so.
+hipError_t launch_lpc_bins(hipStream_t st, const MultiBin &mb, const double *autoc, int max_order,
+                           int precision, int omethod, int32_t *coefs, int32_t *shift,
+                           int32_t *opt_order, int32_t *fin)
+{
+    if (mb.nbins < 1) return hipErrorInvalidValue;
+    const int units = mb.unit0[mb.nbins - 1] + mb.cap[mb.nbins - 1];
+    return launch_lpc_any(st, autoc, units, max_order, precision, omethod, coefs, shift, opt_order, fin, nullptr, mb);
+}
+
+static hipError_t launch_lpc_any(hipStream_t st, const double *autoc, int nsub, int max_order,
+                                 int precision, int omethod, int32_t *coefs, int32_t *shift,
+                                 int32_t *opt_order, int32_t *fin, const int32_t *dev_sub, const MultiBin &mb)
 {
     if (nsub == 0) return hipSuccess;
     const int blocks = (nsub + LPC_NT - 1) / LPC_NT;
     if (max_order <= 8)
         hipLaunchKernelGGL(k_lpc_reg<8>, dim3(blocks), dim3(LPC_NT), 0, st, autoc, nsub, max_order,
-                           precision, omethod, coefs, shift, opt_order, fin, dev_sub);
+                           precision, omethod, coefs, shift, opt_order, fin, dev_sub, mb);
     else if (max_order <= 12)
         hipLaunchKernelGGL(k_lpc_reg<12>, dim3(blocks), dim3(LPC_NT), 0, st, autoc, nsub, max_order,
-                           precision, omethod, coefs, shift, opt_order, fin, dev_sub);
+                           precision, omethod, coefs, shift, opt_order, fin, dev_sub, mb);
     else if (omethod >= 2 && getenv("FHIP_K2_ONE_LANE") == nullptr) {
         // every row wanted (lpc.c:249-254): Levinson in registers, rows quantised side by side
         const size_t lds = (size_t)LR_SUB * LR_STRIDE * sizeof(double);
@@ -327,10 +355,10 @@ hipError_t launch_lpc(hipStream_t st, const double *autoc, int nsub, int max_ord
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (er != hipSuccess) return er;
         hipLaunchKernelGGL(k_lpc_rows, dim3((nsub + LR_SUB - 1) / LR_SUB), dim3(LR_NT), lds, st, autoc, nsub,
-                           max_order, precision, coefs, shift, opt_order, dev_sub);
+                           max_order, precision, coefs, shift, opt_order, dev_sub, mb);
     } else
         hipLaunchKernelGGL(k_lpc, dim3(blocks), dim3(LPC_NT), 0, st, autoc, nsub, max_order,
-                           precision, omethod, coefs, shift, opt_order, fin, dev_sub);
+                           precision, omethod, coefs, shift, opt_order, fin, dev_sub, mb);
     return hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 // bitio.h:120-141): k_encode<C> for any block size, k_encode_pow2<C,T,MODE> for
 // n = C*T.
 #include "device_util.h"
+#include "k3_common.h"
 
 #ifdef FHIP_STAMPS
 FHIP_DEFINE_STAMP_READER(fhip_debug_read_stamps_k3)      // slots 0..39 (tools/stamps.py)
@@ -41,7 +42,6 @@ struct EncLds {
     unsigned long long *scan;           // [8]
     uint32_t *bits;                     // [ENC_WWORDS] emit window
 };
-constexpr int ENC_WWORDS = 2048;        // 64 Kbit emit window
 enum { M_PORDER = 0, M_METHOD = 1, M_BITS = 2, M_FLAG = 3 };
 
 __device__ __forceinline__ int padidx(int i) { return i + (i >> 4); }
@@ -70,15 +70,6 @@ struct EncCtx {
     int pmin_req, pmax_req;
 };
 
-
-// rice.c:148-155 limit_max_partition_order
-__device__ __forceinline__ int clamp_porder(int porder, int n, int order)
-{
-    int lim = ilog2_dev((uint32_t)(n ^ (n - 1)));
-    porder = min(porder, lim);
-    if (order > 0) porder = min(porder, ilog2_dev((uint32_t)(n / order)));
-    return porder;
-}
 
 // Rice search over the residuals held in r[] (rice.c:105-187).  Leaves the
 // per-node parameters in l.kpar, the chosen order/method in l.misc and
@@ -951,351 +942,6 @@ void k_encode_big(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 //   * partition sums are a wave shuffle pyramid (thread = finest level);
 //   * the best Rice parameter comes from a closed form, with the reference's
 //     31-step scan only where its modular arithmetic can bite (see rice_k_fast).
-constexpr int HIST = 32;                 // zeroed samples in front of the block
-
-// The block sits in LDS transposed: thread t's run of C samples is column t.
-//  * C % 4 != 0: sample i (>= -HIST) is at row (i mod C), column (i div C) + COL0 of
-//    a [C][S] int32 image; lanes of a wave touch consecutive words.
-//  * C % 4 == 0 (V4): the rows are groups of four samples, [C/4][S] of int4 -- a
-//    thread stages its run with C/4 16-byte stores and the FIR fetches its window
-//    with 16-byte loads (a quarter of the LDS instructions; lanes touch
-//    consecutive 16-byte slots, conflict-free).
-// Either way every sample a thread needs at offset c from its run start is at the
-// thread's base + a compile-time offset: the window loads carry no address
-// arithmetic.  (An fp64 image saves the int->double conversions but its 33 KB cost
-// a workgroup per CU: measured 108 vs 96 us.)
-template <int C, int T>
-struct SmpImg {
-    static constexpr bool V4 = (C % 4 == 0);
-    static constexpr int CS = V4 ? 4 : 1;             // int32 per column step
-    // columns of zeros in front: the FIR looks back 32 samples in tap blocks
-    // of 16 (C | 16) or 36 in tap blocks of 9 (C = 3, 9, 18)
-    static constexpr int COL0 = (16 % C == 0) ? HIST / C : (36 + C - 1) / C;
-    static constexpr int ROWS = V4 ? C / 4 : C;
-    static constexpr int S = T + COL0 + (V4 ? 1 : 2);  // row stride in columns
-    static constexpr int SIZE = ROWS * S * CS;         // int32
-    // int32 index of sample r (0 <= r < C) of column col
-    __host__ __device__ static constexpr int at(int col, int r)
-    {
-        return V4 ? ((r / 4) * S + col) * 4 + (r % 4) : r * S + col;
-    }
-    // offset of sample (run start of thread t) + c, relative to &img[t * CS]
-    __host__ __device__ static constexpr int off(int c)
-    {
-        return at((c - (((c % C) + C) % C)) / C + COL0, ((c % C) + C) % C);
-    }
-};
-
-struct FastLds {
-    int32_t *smp;                        // SmpImg<C,T>: samples, HIST zeros in front
-    unsigned long long *sums;            // [511] heap order
-    int32_t *kpar;                       // [511]
-    double *coefd;                       // [32] coefficients of the candidate as fp64
-    unsigned long long *wtot;            // [16] per-wave totals
-    uint32_t *lvl_bits, *lvl_meth;       // [9]
-    int32_t *coef;                       // [32]
-    int32_t *misc;                       // [16]
-    uint32_t *trial;                     // [32]
-    uint32_t *bits;                      // [ENC_WWORDS]
-};
-
-// Emit window of the fast path, in words: a section of typical density fits one
-// window (n/2 words = 16 bits per sample, rounded up to a power of two); denser
-// sections take more passes.  Small blocks thus leave LDS for more workgroups.
-// wide: 32 bits per sample up to 128 Kbit, for the instance that runs four workgroups per CU
-// anyway (MODE 2, VGPRs) on samples wider than 16 bits -- a 24-bit section of ~19 bits per sample
-// then takes one pass instead of two.  (MODE 3 had it too while it ran four waves per SIMD; at
-// five the 8 KB it costs are a workgroup per CU: configs[3] K3 420 -> 390 us without it.)
-__host__ __device__ inline int fast_window_words(int n, bool wide = false)
-{
-    int w = 256;
-    if (wide) { while (w < 2 * ENC_WWORDS && w < n) w <<= 1; return w; }
-    while (w < ENC_WWORDS && 2 * w < n) w <<= 1;
-    return w;
-}
-__host__ __device__ inline bool fast_wide_window(int mode, int bps) { return mode == 2 && bps > 16; }
-
-__host__ __device__ inline size_t fast_lds_layout(int n, size_t img_doubles, size_t off[11], bool wide = false)
-{
-    size_t o = 0;
-    off[0] = o; o += 8 * 512;                                   // sums
-    off[1] = o; o += 8 * 48;                                    // coefd (zero-padded past 32)
-    off[2] = o; o += 8 * 16;                                    // wtot
-    off[3] = o; o += 4 * img_doubles;                           // smp image (ints)
-    off[4] = o; o += 4 * 512;                                   // kpar
-    off[5] = o; o += 4 * 12;                                    // lvl_bits
-    off[6] = o; o += 4 * 12;                                    // lvl_meth
-    off[7] = o; o += 4 * 32;                                    // coef
-    off[8] = o; o += 4 * 16;                                    // misc
-    off[9] = o; o += 4 * 32;                                    // trial
-    o = (o + 15) & ~(size_t)15;
-    off[10] = o; o += 4 * fast_window_words(n, wide);           // bits
-    return o;
-}
-
-constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }          // floor(log2 v)
-constexpr int clog2_up(int v) { return clog2(v) + ((v & (v - 1)) ? 1 : 0); }    // ceil(log2 v): runs of 3, 9, 18
-
-template <int C, int T>
-struct FastCtx {
-    FastLds l;
-    int n, i0, tid, lane, wv;
-    int obits, precision, pmin_req, pmax_req;
-};
-
-// FIR residual of this thread's C samples x[] for an LPC candidate
-// (optimize.c:70-122).  l.coefd holds the coefficients as doubles, zero past
-// `order`, so the tap loop runs in whole blocks of 8.
-template <int C, int T>
-__device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift)
-{
-    using Img = SmpImg<C, T>;
-    const FastLds &l = e.l;
-    const double inv = __builtin_ldexp(1.0, -shift);
-    // outputs per register block: a divisor of C
-    constexpr int OB = (C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : (C % 5 == 0) ? 5 : (C % 7 == 0) ? 7 : 1;
-    // taps per block: a multiple of C (going back C*k samples is going back k
-    // columns of the image, so every block sees the same immediate offsets)
-    constexpr int TB = (16 % C == 0) ? 16 : C * ((8 + C - 1) / C);
-    const int32_t *mine = l.smp + e.tid * Img::CS;   // column of this thread's run
-#pragma unroll
-    for (int ob = 0; ob < C; ob += OB) {
-        // keep the register blocks apart: interleaving them only costs VGPRs
-        __builtin_amdgcn_sched_barrier(0);
-        double acc[OB];
-#pragma unroll
-        for (int o = 0; o < OB; o++) acc[o] = 0.0;
-#pragma unroll 1
-        for (int tb = 0; tb < order; tb += TB) {
-            const int32_t *base = mine - (tb / C) * Img::CS;
-#pragma unroll
-            for (int sb = 0; sb < TB; sb += 8) {
-                constexpr int dummy = 0; (void)dummy;
-                if (order > tb + sb) {
-                    // taps tb+sb+1 .. tb+sb+NT_ : samples c = ob+o-(sb+jj+1)
-                    const int NT_ = (TB - sb < 8) ? TB - sb : 8;
-                    double W[OB + 7];
-                    if constexpr (Img::V4) {
-                        // the window starts on a group of four: 16-byte loads
-                        static_assert(!Img::V4 || (TB == 16 && OB % 4 == 0), "aligned windows");
-#pragma unroll
-                        for (int m4 = 0; m4 < OB + 7; m4 += 4) {
-                            const int4 v = *reinterpret_cast<const int4 *>(base + Img::off(ob - sb - 8 + m4));
-                            W[m4] = (double)v.x;
-                            if (m4 + 1 < OB + 7) W[m4 + 1] = (double)v.y;
-                            if (m4 + 2 < OB + 7) W[m4 + 2] = (double)v.z;
-                            if (m4 + 3 < OB + 7) W[m4 + 3] = (double)v.w;
-                        }
-                    } else {
-#pragma unroll
-                        for (int m = 0; m < OB + 7; m++)
-                            if (m < OB + NT_ - 1) W[m] = (double)base[Img::off(ob - sb - NT_ + m)];
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < 8; jj++) {
-                        if (jj < NT_) {
-                            const double cd = l.coefd[tb + sb + jj];
-#pragma unroll
-                            for (int o = 0; o < OB; o++)
-                                acc[o] = __builtin_fma(cd, W[o + NT_ - 1 - jj], acc[o]);
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int o = 0; o < OB; o++) {
-            // pred >> shift == floor(pred * 2^-shift).  The kernel runs with the
-            // fp64 rounding mode "toward -inf" (set_round_down): acc * 2^-shift is
-            // exact, |.| < 2^51, so the one rounding of fma(acc, 2^-shift, 1.5 * 2^52)
-            // is that floor, and the low mantissa word is the floor's low 32 bits in
-            // two's complement.  (int32)(x - (pred >> shift)) only needs those.
-            const double z = __builtin_fma(acc[o], inv, 6755399441055744.0);
-            const uint32_t qlo = (uint32_t)__double2loint(z);
-            uint32_t x;
-            if constexpr (Img::V4) {
-                const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob + (o & ~3)));   // one load per four
-                x = (uint32_t)((o & 3) == 0 ? v.x : (o & 3) == 1 ? v.y : (o & 3) == 2 ? v.z : v.w);
-            } else {
-                x = (uint32_t)mine[Img::off(ob + o)];
-            }
-            r[ob + o] = (int32_t)(x - qlo);
-        }
-    }
-    // warm-up samples pass through (optimize.c:84-86): only the first threads
-    if (e.i0 < order) {
-#pragma unroll
-        for (int o = 0; o < C; o++)
-            if (e.i0 + o < order) r[o] = mine[Img::off(o)];
-    }
-}
-
-// The same FIR for orders <= 8 with the coefficients as wave-uniform doubles read
-// from K2's compact row by scalar loads (MODE 0): no coefficient traffic through
-// LDS, no vector registers for them.
-template <int C, int T>
-__device__ __forceinline__ void fir_lpc_o8(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
-                                           const double *__restrict__ cd)
-{
-    using Img = SmpImg<C, T>;
-    const double inv = __builtin_ldexp(1.0, -shift);
-    constexpr int OB = (C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : (C % 5 == 0) ? 5 : (C % 7 == 0) ? 7 : 1;
-    const int32_t *mine = e.l.smp + e.tid * Img::CS;
-    double cf[8];
-#pragma unroll
-    for (int jj = 0; jj < 8; jj++) cf[jj] = cd[jj];
-#pragma unroll
-    for (int ob = 0; ob < C; ob += OB) {
-        __builtin_amdgcn_sched_barrier(0);
-        double acc[OB];
-#pragma unroll
-        for (int o = 0; o < OB; o++) acc[o] = 0.0;
-        double W[OB + 7];
-        if constexpr (Img::V4) {
-#pragma unroll
-            for (int m4 = 0; m4 < OB + 7; m4 += 4) {
-                const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob - 8 + m4));
-                W[m4] = (double)v.x;
-                if (m4 + 1 < OB + 7) W[m4 + 1] = (double)v.y;
-                if (m4 + 2 < OB + 7) W[m4 + 2] = (double)v.z;
-                if (m4 + 3 < OB + 7) W[m4 + 3] = (double)v.w;
-            }
-        } else {
-#pragma unroll
-            for (int m = 0; m < OB + 7; m++) W[m] = (double)mine[Img::off(ob - 8 + m)];
-        }
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++)
-#pragma unroll
-            for (int o = 0; o < OB; o++)
-                acc[o] = __builtin_fma(cf[jj], W[o + 7 - jj], acc[o]);
-#pragma unroll
-        for (int o = 0; o < OB; o++) {
-            const double z = __builtin_fma(acc[o], inv, 6755399441055744.0);   // floor under round-down, see fir_lpc
-            const uint32_t qlo = (uint32_t)__double2loint(z);
-            uint32_t x;
-            if constexpr (Img::V4) {
-                const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob + (o & ~3)));
-                x = (uint32_t)((o & 3) == 0 ? v.x : (o & 3) == 1 ? v.y : (o & 3) == 2 ? v.z : v.w);
-            } else {
-                x = (uint32_t)mine[Img::off(ob + o)];
-            }
-            r[ob + o] = (int32_t)(x - qlo);
-        }
-    }
-    if (e.i0 < order) {
-#pragma unroll
-        for (int o = 0; o < C; o++)
-            if (e.i0 + o < order) r[o] = mine[Img::off(o)];
-    }
-}
-
-// Orders 9 .. 16 on a row known up front (MODE 3), the coefficients again as wave-uniform
-// doubles from K2's compact row (scalar loads; TAPS = 12 or 16 of them, zero past the order): no
-// coefficient reads from the LDS (one per tap and block of eight outputs in fir_lpc), and ONE
-// window of TAPS + 7 samples per block of eight outputs instead of one per eight taps.
-template <int C, int T, int TAPS>
-__device__ __forceinline__ void fir_lpc_o16(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
-                                            const double *__restrict__ cd)
-{
-    using Img = SmpImg<C, T>;
-    static_assert(Img::V4 && C % 8 == 0 && (TAPS == 12 || TAPS == 16), "fir_lpc_o16: runs of 8 or 16");
-    const double inv = __builtin_ldexp(1.0, -shift);
-    const int32_t *mine = e.l.smp + e.tid * Img::CS;
-    double cf[TAPS];
-#pragma unroll
-    for (int jj = 0; jj < TAPS; jj++) cf[jj] = cd[jj];
-#pragma unroll
-    for (int ob = 0; ob < C; ob += 8) {
-        __builtin_amdgcn_sched_barrier(0);
-        double acc[8];
-#pragma unroll
-        for (int o = 0; o < 8; o++) acc[o] = 0.0;
-        double W[TAPS + 8];                                // samples ob-TAPS .. ob+7 (the last one unused)
-#pragma unroll
-        for (int m4 = 0; m4 < TAPS + 8; m4 += 4) {
-            const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob - TAPS + m4));
-            W[m4] = (double)v.x; W[m4 + 1] = (double)v.y; W[m4 + 2] = (double)v.z; W[m4 + 3] = (double)v.w;
-        }
-#pragma unroll
-        for (int jj = 0; jj < TAPS; jj++)
-#pragma unroll
-            for (int o = 0; o < 8; o++)
-                acc[o] = __builtin_fma(cf[jj], W[o + TAPS - 1 - jj], acc[o]);      // tap jj+1: sample ob+o-(jj+1)
-#pragma unroll
-        for (int o = 0; o < 8; o++) {
-            const double z = __builtin_fma(acc[o], inv, 6755399441055744.0);   // floor under round-down, see fir_lpc
-            const uint32_t qlo = (uint32_t)__double2loint(z);
-            const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob + (o & ~3)));
-            const uint32_t x = (uint32_t)((o & 3) == 0 ? v.x : (o & 3) == 1 ? v.y : (o & 3) == 2 ? v.z : v.w);
-            r[ob + o] = (int32_t)(x - qlo);
-        }
-    }
-    if (e.i0 < order) {
-#pragma unroll
-        for (int o = 0; o < C; o++)
-            if (e.i0 + o < order) r[o] = mine[Img::off(o)];
-    }
-}
-
-template <int C, int T, int NP>
-__device__ __forceinline__ void fir_lpc_dotn(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
-                                             const int32_t *__restrict__ cp);
-template <int C, int T>
-__device__ __forceinline__ void fir_lpc_dot8(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
-                                             const int32_t *__restrict__ cp)
-{
-    fir_lpc_dotn<C, T, 4>(e, r, order, shift, cp);
-}
-
-// Orders <= 8 on a channel whose samples fit 16 bits (K0's narrow rows), when the
-// prediction provably stays inside int32 (sum|coef| * 2^magbits < 2^31, checked by
-// the caller): v_dot2_i32_i16 does two taps per instruction on int16 pairs and
-// costs about what one fp64 FMA does, with no int -> fp64 conversions in front.
-// Sample pairs R(k) = (lo: x[k], hi: x[k+1]) are packed from the int32 window;
-// cp[j] = (lo: coef of tap 2j+2, hi: coef of tap 2j+1) comes from K2 (scalars).
-// NP = int16 pairs per output: 4 for orders <= 8, 8 for orders <= 16 (order searches).
-template <int C, int T, int NP>
-__device__ __forceinline__ void fir_lpc_dotn(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift,
-                                             const int32_t *__restrict__ cp)
-{
-    using Img = SmpImg<C, T>;
-    static_assert(Img::V4 && C % 8 == 0 && (NP == 4 || NP == 8), "fir_lpc_dotn: runs of 8 or 16");
-    typedef short s2 __attribute__((ext_vector_type(2)));
-    constexpr int H = 2 * NP;                              // samples of history an output reaches back
-    const int32_t *mine = e.l.smp + e.tid * Img::CS;
-    s2 q[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) q[j] = __builtin_bit_cast(s2, cp[j]);
-#pragma unroll
-    for (int ob = 0; ob < C; ob += 8) {
-        __builtin_amdgcn_sched_barrier(0);
-        int32_t W[H + 8];                                  // samples ob-H .. ob+7
-#pragma unroll
-        for (int m4 = 0; m4 < H + 8; m4 += 4) {
-            const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob - H + m4));
-            W[m4] = v.x; W[m4 + 1] = v.y; W[m4 + 2] = v.z; W[m4 + 3] = v.w;
-        }
-        s2 R[H + 6];                                       // R[m] = (x[ob-H+m], x[ob-H+1+m])
-#pragma unroll
-        for (int m = 0; m < H + 6; m++)
-            R[m] = __builtin_bit_cast(s2, (int32_t)__builtin_amdgcn_perm((uint32_t)W[m + 1], (uint32_t)W[m], 0x05040100u));
-#pragma unroll
-        for (int o = 0; o < 8; o++) {
-            // taps (2j+1, 2j+2) use x[o-2j-2], x[o-2j-1] = R at window index o + H - 2 - 2j
-            int32_t acc = 0;
-#pragma unroll
-            for (int j = 0; j < NP; j++) acc = __builtin_amdgcn_sdot2(R[o + H - 2 - 2 * j], q[j], acc, false);
-            r[ob + o] = (int32_t)((uint32_t)W[H + o] - (uint32_t)(acc >> shift));
-        }
-    }
-    if (e.i0 < order) {
-#pragma unroll
-        for (int o = 0; o < C; o++)
-            if (e.i0 + o < order) r[o] = mine[Img::off(o)];
-    }
-}
-
 // optimize.c:34-68 encode_residual_fixed on the thread's run.  The reference
 // computes in long long and stores to int32: the low 32 bits, which wrapping
 // 32-bit arithmetic yields directly.
@@ -1746,7 +1392,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
         const int32_t *srcp = smp_all + (size_t)s * n;
         // K0 may have stored this row as int16 (info.reserved, honoured only when the
         // launcher says the flag is K0's): half the loads, one sign extension per sample
-        const int nflag = (C % 8 == 0 && narrow_ok) ? prep[s].reserved : 0;     // 0, or 1 + bit length of max |x|
+        const int nflag = (C % 8 == 0 && narrow_ok) ? (prep[s].reserved & 0xFF) : 0;     // 0, or 1 + bit length of max |x|
         const bool narrow = nflag != 0;
         magbits_n = nflag - 1;
         if (C % 8 == 0 && narrow) {
@@ -2277,610 +1923,6 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
   }
 }
 
-// ---------------------------------------------------------------------------
-// K3-S  k_order_search<C, T, G>: the order searches of encode_residual()
-// (optimize.c:201-261: 2/4/8-LEVEL, SEARCH, LOG) as a kernel of their own.
-// ---------------------------------------------------------------------------
-// bits[order] depends on nothing but the order, so the reference's sequential search is a
-// walk over a table.  This kernel fills the table -- FIR (optimize.c:70-122), fold, partition
-// sums, Rice parameter / partition-order search (rice.c:105-187) for every candidate order
-// the method can visit -- G candidates per round: every wave runs the FIR and the fold of every
-// candidate over its part of the block, the T thread sums go to LDS as 32-bit leaves, and then
-// ONE WAVE PER CANDIDATE does the whole Rice search from them (wave_candidate_bits); nothing of
-// the emit's state (residuals, parameters, windows) is carried.  (Round 2 also had an instance
-// whose FIRs ran as fp64 matrix products, v_mfma_f64_16x16x4_f64 over 16 candidates x 16
-// samples, exact because every product and sum is an integer below 2^53: once the search
-// behind the FIR went wave-per-candidate in this instance too, the two measured the same --
-// SEARCH 1-32 on 24-bit samples 1.33 against 1.41 ms, 1-24: 1.30 against 0.98, 1-12: 0.54
-// against 0.43 -- and the matrix instance was dropped)
-// It then replays the method's decision on the table and leaves the winner the way K2 leaves
-// the single row of the MAX / EST methods: opt_order[s] and the compact row fin[s].  The lean
-// K3 instance (MODE 0 / 3) encodes that row -- the reference's own final call
-// (optimize.c:266-275) -- so est_bits, parameters and bits come from the same code as before.
-template <int G>
-struct SrchLds {
-    unsigned long long *sums;   // [G][512] heap order per candidate slot; in leaf mode G per-wave heaps of 128
-                                // and behind them the G x T thread sums as 32-bit leaves
-    unsigned long long *wtot;   // [G][16]  per-wave totals
-    double *coefd;              // [G][32]  candidate rows as doubles, zero past the order
-    int32_t *smp;               // SmpImg<C, T>
-    uint32_t *lvl_bits;         // [2][G][12] (double-buffered by round parity)
-    uint32_t *lvl_meth;         // [2][G]
-    int32_t *pairs;             // [G][8]   taps as int16 pairs (packed FIR)
-    int32_t *rowi;              // [G][4]   order index, shift, sum |coef|, spare
-    uint32_t *trial;            // [32]     bits[order index], 0xFFFFFFFF = not evaluated
-    int32_t *list;              // [32]     candidate order indices of this subframe
-    int32_t *misc;              // [32]: count, winner, two overflow flags, one "differs" word per wave (<= 16), ...
-};
-
-template <int G>
-__host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[12], int threads)
-{
-    size_t o = 0;
-    // sums: G x 4 KB for the general way; leaf mode overlays G heaps of 1 KB and G x T leaves
-    const size_t general = 8 * 512 * (size_t)G, leafy = 8 * 128 * (size_t)G + 4 * (size_t)G * (size_t)threads;
-    off[0] = o; o += general > leafy ? general : leafy;
-    off[1] = o; o += 8 * 16 * G;
-    off[2] = o; o += 8 * 32 * G;
-    off[3] = o; o += 4 * img_ints;
-    o = (o + 15) & ~(size_t)15;
-    off[4] = o; o += 4 * 2 * G * 12;
-    off[5] = o; o += 4 * 2 * G;
-    off[6] = o; o += 4 * 8 * G;
-    off[7] = o; o += 4 * 4 * G;
-    off[8] = o; o += 4 * 32;
-    off[9] = o; o += 4 * 32;
-    off[10] = o; o += 4 * 32;
-    off[11] = 0;
-    return (o + 15) & ~(size_t)15;
-}
-
-
-// rice.c:105-187 for ONE candidate by ONE wave, from the finest-level sums a round of
-// k_order_search left in LDS (leaf[t] = the sum of thread t's run): no barrier, no atomics.  A lane
-// takes T/64 consecutive leaves and owns the nodes above them down to level 6 (always seven
-// that can be asked for: four at level 8, two at 7, one at 6); levels 5..0 are 63 nodes built
-// through a small per-wave heap in LDS and evaluated one per lane.  Level totals: a wave
-// reduction for the three lane-local levels, a wave scan over the heap lanes for the rest.
-// Returns the subframe estimate of calc_rice_params_lpc (rice.c:180-187).
-template <int T>
-__device__ __forceinline__ uint32_t wave_candidate_bits(const uint32_t *__restrict__ leaf,
-                                                        unsigned long long *__restrict__ heap, int n, int ord,
-                                                        int pmin, int pmax, int obits, int precision, int lane)
-{
-    constexpr int LPL = T / 64;                 // leaves per lane: 4 (n = 4096), 8, 16
-    constexpr int L8 = LPL / 4;                 // leaves per level-8 node
-    static_assert(LPL >= 4 && LPL <= 16, "wave_candidate_bits: 256 .. 1024 tiles");
-    uint32_t lf[LPL];
-#pragma unroll
-    for (int q = 0; q < LPL; q += 4) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(leaf + lane * LPL + q);
-        lf[q] = v.x; lf[q + 1] = v.y; lf[q + 2] = v.z; lf[q + 3] = v.w;
-    }
-    unsigned long long s8[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        s8[i] = 0;
-#pragma unroll
-        for (int q = 0; q < L8; q++) s8[i] += lf[i * L8 + q];
-    }
-    const unsigned long long s7[2] = {s8[0] + s8[1], s8[2] + s8[3]};
-    const unsigned long long s6 = s7[0] + s7[1];
-
-    auto node = [&](unsigned long long sum, int p, int jn, uint32_t *b) -> int {
-        const int cnt = (n >> p) - (jn == 0 ? ord : 0);
-        return (sum >> 32) ? rice_k_fast(sum, cnt, b) : rice_k_fast_u32((uint32_t)sum, cnt, b);
-    };
-    uint32_t lb[9];
-#pragma unroll
-    for (int p = 0; p < 9; p++) lb[p] = 0;
-    uint32_t rice2 = 0;                         // bit p: some parameter of level p is above 14
-    // ---- lane-local levels 8, 7, 6 ----
-    {
-        uint32_t b8 = 0, b7 = 0, b6 = 0;
-        bool k8 = false, k7 = false, k6 = false;
-        if (pmax >= 8 && pmin <= 8) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) { uint32_t b; k8 |= node(s8[i], 8, 4 * lane + i, &b) > 14; b8 += b; }
-        }
-        if (pmax >= 7 && pmin <= 7) {
-#pragma unroll
-            for (int i = 0; i < 2; i++) { uint32_t b; k7 |= node(s7[i], 7, 2 * lane + i, &b) > 14; b7 += b; }
-        }
-        if (pmax >= 6 && pmin <= 6) { uint32_t b; k6 = node(s6, 6, lane, &b) > 14; b6 = b; }
-        uint32_t t8 = b8, t7 = b7, t6 = b6;
-#define WSUM(X_) do { X_ += dpp_u32<0x111>(X_); X_ += dpp_u32<0x112>(X_); X_ += dpp_u32<0x114>(X_);       \
-                      X_ += dpp_u32<0x118>(X_); X_ += dpp_u32<0x142, 0xA>(X_); X_ += dpp_u32<0x143, 0xC>(X_); } while (0)
-        WSUM(t8); WSUM(t7); WSUM(t6);
-#undef WSUM
-        lb[8] = (uint32_t)__builtin_amdgcn_readlane((int)t8, 63);
-        lb[7] = (uint32_t)__builtin_amdgcn_readlane((int)t7, 63);
-        lb[6] = (uint32_t)__builtin_amdgcn_readlane((int)t6, 63);
-        if (__any(k8)) rice2 |= 1u << 8;
-        if (__any(k7)) rice2 |= 1u << 7;
-        if (__any(k6)) rice2 |= 1u << 6;
-    }
-    // ---- levels 5 .. 0: a 127-entry heap of this wave (entry 2^p - 1 + j = node j of level p) ----
-    if (pmin <= 5) {
-        heap[63 + lane] = s6;
-#pragma unroll
-        for (int p = 5; p >= 0; p--) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane < (1 << p)) {
-                const int c = (2 << p) - 1 + 2 * lane;
-                heap[(1 << p) - 1 + lane] = heap[c] + heap[c + 1];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int p = ilog2_dev((uint32_t)(lane + 1));           // lanes 0..62: node `lane`, level p
-        uint32_t b = 0;
-        bool big = false;
-        if (lane < 63 && p >= pmin && p <= pmax) big = node(heap[lane], p, lane + 1 - (1 << p), &b) > 14;
-        const uint32_t sc = wave_incl_scan_u32_dpp(b);
-        const unsigned long long bigm = __ballot(big);
-#pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)sc, (2 << q) - 2);
-            const uint32_t lo = q ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (1 << q) - 2) : 0u;
-            lb[q] = hi - lo;
-            const unsigned long long lvl = ((1ull << ((2 << q) - 1)) - 1) & ~((1ull << ((1 << q) - 1)) - 1);
-            if (bigm & lvl) rice2 |= 1u << q;
-        }
-        __builtin_amdgcn_wave_barrier();                        // the heap is reused by the next candidate
-    }
-    // rice.c:127-138, :157-171, :180-187
-    uint32_t best = 0, method = 0;
-#pragma unroll
-    for (int p = 0; p < 9; p++) {
-        const uint32_t b = lb[p] + 4u * (1u << p);
-        if (p >= pmin && p <= pmax && (p == pmin || b <= best)) { best = b; method = (rice2 >> p) & 1u; }
-    }
-    uint32_t bits = (uint32_t)(ord * obits + 2) + (uint32_t)(4 + 5 + ord * precision);
-    bits += best;
-    bits += method + 4u;
-    return bits;
-}
-
-
-template <int C, int T, int G>
-__global__ __launch_bounds__(T, (T <= 256) ? 4 : (T <= 512) ? 2 : 1)
-void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
-                    const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
-                    int32_t *__restrict__ opt_all, int32_t *__restrict__ fin_all,
-                    const fhip_subframe_info *__restrict__ prep, int narrow_ok,
-                    const int32_t *__restrict__ dev_sub)
-{
-    static_assert(C % 8 == 0 && T >= 64 && (T & (T - 1)) == 0, "k_order_search: runs of 8 or 16");
-    if (dev_sub && (int)blockIdx.x >= dev_count(dev_sub, 0)) return;
-    using Img = SmpImg<C, T>;
-    constexpr int LT = clog2(T);
-    constexpr int NW = T / WAVE;
-#ifndef LOG_MERGE
-#define LOG_MERGE 1
-#endif
-    static_assert(T >= 256 && NW >= G, "leaf mode: wave m of the first G takes candidate m");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    size_t off[12];
-    srch_lds_layout<G>((size_t)Img::SIZE, off, T);
-    SrchLds<G> l;
-    l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
-    l.wtot = reinterpret_cast<unsigned long long *>(lds_raw + off[1]);
-    l.coefd = reinterpret_cast<double *>(lds_raw + off[2]);
-    l.smp = reinterpret_cast<int32_t *>(lds_raw + off[3]);
-    l.lvl_bits = reinterpret_cast<uint32_t *>(lds_raw + off[4]);
-    l.lvl_meth = reinterpret_cast<uint32_t *>(lds_raw + off[5]);
-    l.pairs = reinterpret_cast<int32_t *>(lds_raw + off[6]);
-    l.rowi = reinterpret_cast<int32_t *>(lds_raw + off[7]);
-    l.trial = reinterpret_cast<uint32_t *>(lds_raw + off[8]);
-    l.list = reinterpret_cast<int32_t *>(lds_raw + off[9]);
-    l.misc = reinterpret_cast<int32_t *>(lds_raw + off[10]);
-
-    // fp64 rounding toward -inf: fir_lpc's floor (see k_encode_pow2)
-    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2" ::: "memory");
-
-    const int s = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    FastCtx<C, T> e;
-    e.l.smp = l.smp; e.l.sums = nullptr; e.l.kpar = nullptr; e.l.coefd = l.coefd; e.l.wtot = nullptr;
-    e.l.lvl_bits = nullptr; e.l.lvl_meth = nullptr; e.l.coef = nullptr; e.l.misc = nullptr;
-    e.l.trial = nullptr; e.l.bits = nullptr;
-    e.n = n; e.tid = tid; e.lane = lane; e.wv = wv; e.i0 = tid * C;
-    e.obits = prep[s].obits;
-    e.precision = P.lpc_precision;
-    e.pmin_req = P.min_partition_order;
-    e.pmax_req = P.max_partition_order;
-
-    // ---- stage the samples (the same image k_encode_pow2 builds) ----------------------
-    int magbits = -1;
-    int differs;
-    {
-        const int32_t *srcp = smp_all + (size_t)s * n;
-        const int nflag = narrow_ok ? prep[s].reserved : 0;
-        magbits = nflag - 1;
-        int32_t xn[C];
-        int32_t first;
-        if (nflag != 0) {
-            const int4 *src4 = reinterpret_cast<const int4 *>(reinterpret_cast<const int16_t *>(srcp) + e.i0);
-#pragma unroll
-            for (int q = 0; q < C / 8; q++) {
-                const int4 t4 = src4[q];
-                xn[8 * q] = (int32_t)(int16_t)t4.x;     xn[8 * q + 1] = t4.x >> 16;
-                xn[8 * q + 2] = (int32_t)(int16_t)t4.y; xn[8 * q + 3] = t4.y >> 16;
-                xn[8 * q + 4] = (int32_t)(int16_t)t4.z; xn[8 * q + 5] = t4.z >> 16;
-                xn[8 * q + 6] = (int32_t)(int16_t)t4.w; xn[8 * q + 7] = t4.w >> 16;
-            }
-            first = (int32_t)*reinterpret_cast<const int16_t *>(srcp);
-        } else {
-            const int4 *src4 = reinterpret_cast<const int4 *>(srcp + e.i0);
-#pragma unroll
-            for (int q = 0; q < C / 4; q++) {
-                const int4 t4 = src4[q];
-                xn[4 * q] = t4.x; xn[4 * q + 1] = t4.y; xn[4 * q + 2] = t4.z; xn[4 * q + 3] = t4.w;
-            }
-            first = srcp[0];
-        }
-        int32_t mx = first, mn = first;
-#pragma unroll
-        for (int o = 0; o < C; o++) { mx = max(mx, xn[o]); mn = min(mn, xn[o]); }
-        differs = (mx != mn);
-#pragma unroll
-        for (int g4 = 0; g4 < C; g4 += 4)
-            *reinterpret_cast<int4 *>(l.smp + tid * 4 + Img::off(g4)) =
-                make_int4(xn[g4], xn[g4 + 1], xn[g4 + 2], xn[g4 + 3]);
-    }
-    if (tid < Img::COL0 * C) l.smp[Img::at(tid / C, tid % C)] = 0;
-    if (tid < 32) l.trial[tid] = 0xFFFFFFFFu;
-    if (tid < 2) l.misc[24 + tid] = 0;                 // rounds: "a thread sum left 32 bits", per round parity
-
-    const int omethod = P.order_method;
-    const int min_order = P.min_prediction_order, max_order = P.max_prediction_order;
-    const int32_t *crow_base = coefs_all + (size_t)s * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
-    const int32_t *srow = shift_all + (size_t)s * FHIP_MAX_ORDER;
-
-    // the orders the method can visit (indices = order - 1), each once
-    if (tid == 0) {
-        int nc = 0;
-        if (omethod >= 2 && omethod <= 4) {
-            const int levels = 1 << (omethod - 1);
-            uint32_t seen = 0;
-            for (int i = levels - 1; i >= 0; i--) {
-                int o = min_order + (((max_order - min_order + 1) * (i + 1)) / levels) - 2;
-                if (o < 0) o = 0;
-                if (!((seen >> o) & 1u)) { seen |= 1u << o; l.list[nc++] = o; }
-            }
-        } else if (omethod == 5) {
-            for (int i = 0; i < max_order; i++) l.list[nc++] = i;
-        }
-        // (LOG, order method 6: the candidates of a step depend on the winner so far; its
-        // rounds are the steps of optimize.c:244-261, see below)
-        l.misc[0] = nc;
-    }
-    const int wave_differs = (__ballot(differs) != 0ull) ? 1 : 0;
-    if (lane == 0) l.misc[4 + wv] = wave_differs;
-    __syncthreads();
-    int any_differs = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) any_differs |= l.misc[4 + w];
-    const bool constant = (__builtin_amdgcn_readfirstlane(any_differs) == 0);
-    const int nc = __builtin_amdgcn_readfirstlane(l.misc[0]);
-
-    // partition-order window over all candidates (rice.c:148-155): the highest order has the
-    // tightest clamp, order 1 the loosest
-    const int pmin_lo = clamp_porder(e.pmin_req, n, max_order);
-    const int pmax_hi = clamp_porder(e.pmax_req, n, 1);
-
-    // LOG walk (optimize.c:240-261), carried by every thread alike: the winner so far, the
-    // orders evaluated, the step
-    const bool is_log = (omethod == 6);
-    int lg_best = min_order - 1 + (max_order - min_order) / 3;
-    uint32_t lg_seen = 0;
-    int lg_step = 16;
-    static_assert(G >= 3, "a LOG step has up to three new candidates");
-
-    for (int g0 = 0, round = 0;; g0 += G, round++) {
-        int ng;
-        uint32_t lg_pack = 0;             // the round's LOG candidates, five bits each, in visiting order
-        int lg_merged = 0;                // ... and the steps of optimize.c:247 they belong to
-        if (constant) break;
-        if (!is_log) {
-            ng = min(G, nc - g0);
-            if (ng <= 0) break;
-        } else {
-            // The next steps' orders not yet evaluated (last - step, last, last + step).  What a step
-            // visits depends on the winner so far -- but often not at all: from order index 3 of
-            // 1..12 the walk visits 3, then 11, then 7 whoever wins.  So a round takes the first
-            // step that has candidates and then every following step whose candidate set is the
-            // same for EVERY order that could be the winner by then (the winner on entry or any
-            // candidate of the round), while they fit G.  The replay below then visits exactly the
-            // reference's candidates in the reference's order.  All scalar (uniform) arithmetic.
-            ng = 0;
-            uint32_t poss = 1u << lg_best, seen = lg_seen;
-            int st = lg_step;
-            while (st > 0) {
-                uint32_t set0 = 0;
-                bool first = true, same = true;
-                for (uint32_t pm = poss; pm; pm &= pm - 1) {
-                    const int b = __builtin_ctz(pm);
-                    uint32_t sb = 0;
-                    for (int i = b - st; i <= b + st; i += st)
-                        if (i >= min_order - 1 && i < max_order && !((seen >> i) & 1u)) sb |= 1u << i;
-                    if (first) { set0 = sb; first = false; }
-                    else if (sb != set0) same = false;
-                }
-                const int cnt = __builtin_popcount(set0);
-                if (!same || ng + cnt > G) break;          // (never on a round's first step: one winner, <= 3 orders)
-                if (ng > 0 && !LOG_MERGE) break;
-                for (uint32_t m = set0; m; m &= m - 1) lg_pack |= (uint32_t)__builtin_ctz(m) << (5 * ng++);
-                seen |= set0;
-                poss |= set0;
-                lg_merged++;
-                st >>= 1;
-            }
-            if (ng == 0) break;                            // every step consumed, nothing left to visit
-        }
-        const int par = round & 1;
-        // ---- the round's rows: doubles, int16 pairs, sum |coef|, shift ----
-        if (tid < G * 32) {
-            const int g = tid >> 5, j = tid & 31;
-            const int cand = (g >= ng) ? 0 : is_log ? (int)((lg_pack >> (5 * g)) & 31u) : l.list[g0 + g];
-            const int ord = cand + 1;
-            const int32_t cv = (g < ng && j < ord) ? crow_base[cand * FHIP_MAX_ORDER + j] : 0;
-            l.coefd[g * 32 + j] = (double)cv;
-            const int32_t nb = __shfl_xor(cv, 1, WAVE);
-            if (j < 16 && (j & 1) == 0) l.pairs[g * 8 + (j >> 1)] = (nb & 0xFFFF) | (cv << 16);
-            int32_t sa = cv < 0 ? -cv : cv;
-            sa += __shfl_xor(sa, 1, WAVE); sa += __shfl_xor(sa, 2, WAVE);
-            sa += __shfl_xor(sa, 4, WAVE); sa += __shfl_xor(sa, 8, WAVE);
-            sa += __shfl_xor(sa, 16, WAVE);
-            if (j == 0) {
-                l.rowi[g * 4 + 0] = cand;
-                l.rowi[g * 4 + 1] = (g < ng) ? srow[cand] : 0;
-                l.rowi[g * 4 + 2] = sa;
-                // rice.c:148-155 for this order, once (an integer division each)
-                l.rowi[g * 4 + 3] = clamp_porder(e.pmin_req, n, ord) | (clamp_porder(e.pmax_req, n, ord) << 8);
-            }
-        }
-        if (tid < G * 12) l.lvl_bits[par * G * 12 + tid] = 0;
-        if (tid < G) l.lvl_meth[par * G + tid] = 0;
-        if (tid == 0) l.misc[24 + (par ^ 1)] = 0;
-        __syncthreads();
-
-        // The search behind the thread sums, two ways.  Leaf mode (T <= 512): the thread sums
-        // -- the finest partition sums there are, T of them -- go to LDS as 32-bit leaves and
-        // ONE WAVE PER CANDIDATE does rice.c:105-187 from them (wave_candidate_bits: no barrier,
-        // no atomics, a third of the instructions of the pyramid + node pass below, which every
-        // wave runs for every candidate).  A thread sum that leaves 32 bits (32-bit noise)
-        // flags the round, which is then run again the general way: 64-bit pyramid in every
-        // wave, one thread per (candidate, level, partition) node.
-        bool leaf_mode = true;
-        uint32_t *rleaf = reinterpret_cast<uint32_t *>(l.sums + G * 128);      // behind the G heaps
-#pragma unroll 1
-        for (int pass = 0; pass < 2; pass++) {
-        // ---- per candidate: FIR, fold, thread sum, in-wave pyramid ----
-#pragma unroll 1
-        for (int g = 0; g < ng; g++) {
-            const int cand = __builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 0]);
-            const int cshift = __builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 1]);
-            const uint32_t cabs = (uint32_t)__builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 2]);
-            const int ord = cand + 1;
-            unsigned long long v = 0;
-            {
-            int32_t r[C];
-            FastCtx<C, T> eg = e;
-            eg.l.coefd = l.coefd + g * 32;
-#if defined(FHIP_SRCH_PROBE) && FHIP_SRCH_PROBE == 1      // timing probe: no FIR
-#pragma unroll
-            for (int o = 0; o < C; o++) r[o] = l.smp[tid * 4 + Img::off(o)] + cshift;
-#else
-            if (ord <= 16 && magbits >= 0 && ((unsigned long long)cabs << magbits) < (1ull << 31)) {
-                if (ord <= 8) fir_lpc_dotn<C, T, 4>(eg, r, ord, cshift, l.pairs + g * 8);
-                else fir_lpc_dotn<C, T, 8>(eg, r, ord, cshift, l.pairs + g * 8);
-            } else {
-                fir_lpc<C, T>(eg, r, ord, cshift);
-            }
-#endif
-            // rice.c:120-123 fold; partition 0 of every level starts at `ord` (rice.c:85-94)
-            if (e.i0 < ord) {
-#pragma unroll
-                for (int o = 0; o < C; o++) v += (e.i0 + o < ord) ? 0u : zigzag32(r[o]);
-            } else {
-#pragma unroll
-                for (int o = 0; o < C; o++) v += zigzag32(r[o]);
-            }
-            }
-            if (leaf_mode) {
-                rleaf[g * T + tid] = (uint32_t)v;
-                if (__any((v >> 32) != 0ull) && lane == 0) atomicOr(reinterpret_cast<uint32_t *>(&l.misc[24 + par]), 1u);
-                continue;
-            }
-            const int pmm = __builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 3]);
-            const int pmin = pmm & 0xFF, pmax = pmm >> 8;
-            unsigned long long *sums = l.sums + g * 512;
-#define SPYR_STORE(S_, V_)                                                                  \
-    do {                                                                                    \
-        const int lev_ = LT - (S_);                                                         \
-        if (lev_ <= pmax && lev_ >= pmin && lev_ <= 8 && (lane & ((1 << (S_)) - 1)) == 0)   \
-            sums[(1 << lev_) - 1 + (tid >> (S_))] = (V_);                                   \
-    } while (0)
-            if (!__any((v >> 26) != 0ull)) {
-                // every thread sum below 2^26: the wave's total fits 32 bits, one DPP add per step
-                uint32_t w = (uint32_t)v;
-                SPYR_STORE(0, (unsigned long long)w); w += dpp_u32<0x101>(w);
-                SPYR_STORE(1, (unsigned long long)w); w += dpp_u32<0x102>(w);
-                SPYR_STORE(2, (unsigned long long)w); w += dpp_u32<0x104>(w);
-                SPYR_STORE(3, (unsigned long long)w); w += dpp_u32<0x108>(w);
-                SPYR_STORE(4, (unsigned long long)w); w += (uint32_t)__shfl_down((int)w, 16, WAVE);
-                SPYR_STORE(5, (unsigned long long)w); w += (uint32_t)__shfl_down((int)w, 32, WAVE);
-                SPYR_STORE(6, (unsigned long long)w);
-                v = w;
-            } else {
-                SPYR_STORE(0, v); v += row_shl_u64<1>(v);
-                SPYR_STORE(1, v); v += row_shl_u64<2>(v);
-                SPYR_STORE(2, v); v += row_shl_u64<4>(v);
-                SPYR_STORE(3, v); v += row_shl_u64<8>(v);
-                SPYR_STORE(4, v); v += __shfl_down(v, 16, WAVE);
-                SPYR_STORE(5, v); v += __shfl_down(v, 32, WAVE);
-                SPYR_STORE(6, v);
-            }
-#undef SPYR_STORE
-            if (lane == 0) l.wtot[g * 16 + wv] = v;
-        }
-        __syncthreads();
-        if (leaf_mode) {
-            if (l.misc[24 + par] != 0) { leaf_mode = false; continue; }      // workgroup-uniform
-            if (wv < ng) {
-                const int ord = l.rowi[wv * 4 + 0] + 1;
-                const int pmm = l.rowi[wv * 4 + 3];
-                const uint32_t b = wave_candidate_bits<T>(rleaf + wv * T, l.sums + wv * 128, n, ord, pmm & 0xFF,
-                                                          pmm >> 8, e.obits, e.precision, lane);
-                if (lane == 0) l.trial[ord - 1] = b;
-            }
-            break;
-        }
-
-        // ---- one thread per (candidate, level, partition) node ----
-        {
-            const int first = (1 << pmin_lo) - 1, last = (2 << pmax_hi) - 2;
-#pragma unroll 1
-            for (int g = 0; g < ng; g++) {
-                const int ord = __builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 0]) + 1;
-                const int pmm = __builtin_amdgcn_readfirstlane(l.rowi[g * 4 + 3]);
-                const int pmin = pmm & 0xFF, pmax = pmm >> 8;
-                for (int q0 = first; q0 <= last; q0 += T) {
-                    const int q = q0 + tid;
-                    const int p = ilog2_dev((uint32_t)(q + 1));
-                    const bool live = q <= last && p >= pmin && p <= pmax;
-                    uint32_t b = 0;
-                    int k = 0;
-                    if (live) {
-                        const int jn = q + 1 - (1 << p);
-                        const int cnt = (n >> p) - (jn == 0 ? ord : 0);
-                        unsigned long long sum;
-                        if (p <= LT - 7) {
-                            const int span = NW >> p;
-                            sum = 0;
-                            for (int w = 0; w < span; w++) sum += l.wtot[g * 16 + jn * span + w];
-                        } else {
-                            sum = l.sums[g * 512 + q];
-                        }
-                        k = (sum >> 32) ? rice_k_fast(sum, cnt, &b) : rice_k_fast_u32((uint32_t)sum, cnt, &b);
-                    }
-                    // a wave whose 64 nodes lie on one level (every wave past the first node
-                    // row) adds them up in registers: one LDS atomic per wave instead of 64
-                    const int p_first = __builtin_amdgcn_readfirstlane(p);
-                    const int p_last = ilog2_dev((uint32_t)(q0 + (tid | 63) + 1));
-                    if (p_first == p_last) {
-                        uint32_t t = b;
-                        t += dpp_u32<0x111>(t); t += dpp_u32<0x112>(t);
-                        t += dpp_u32<0x114>(t); t += dpp_u32<0x118>(t);
-                        t += dpp_u32<0x142, 0xA>(t); t += dpp_u32<0x143, 0xC>(t);
-                        const bool rice2 = __any(live && k > 14);
-                        if (lane == 63 && p_first >= pmin && p_first <= pmax) {
-                            atomicAdd(&l.lvl_bits[(par * G + g) * 12 + p_first], t);
-                            if (rice2) atomicOr(&l.lvl_meth[par * G + g], 1u << p_first);
-                        }
-                    } else if (live) {
-                        atomicAdd(&l.lvl_bits[(par * G + g) * 12 + p], b);
-                        if (k > 14) atomicOr(&l.lvl_meth[par * G + g], 1u << p);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- rice.c:127-138 and :157-171 per candidate ----
-        if (tid < ng) {
-            const int ord = l.rowi[tid * 4 + 0] + 1;
-            const int pmin = l.rowi[tid * 4 + 3] & 0xFF, pmax = l.rowi[tid * 4 + 3] >> 8;
-            const uint32_t lmask = l.lvl_meth[par * G + tid];
-            uint32_t best = 0, method = 0;
-            for (int p = pmin; p <= pmax; p++) {
-                const uint32_t b = l.lvl_bits[(par * G + tid) * 12 + p] + 4u * (1u << p);
-                if (p == pmin || b <= best) { best = b; method = (lmask >> p) & 1u; }
-            }
-            uint32_t bits = (uint32_t)(ord * e.obits + 2) + (uint32_t)(4 + 5 + ord * e.precision);
-            bits += best;
-            bits += method + 4u;
-            l.trial[ord - 1] = bits;
-        }
-        break;
-        }   // pass
-        // The round's rows (l.rowi), leaves, heaps and level words are read until the last wave is
-        // through -- in the general way too: its per-candidate block above reads l.rowi after the
-        // node pass's barrier, and the next round's row staging would overwrite it (one barrier per
-        // round; the general way is the rare fall-back).
-        __syncthreads();
-        if (is_log) {
-            // optimize.c:249-259: the step's orders in ascending order against the winner so far
-            for (int sidx = 0; sidx < lg_merged; sidx++) {
-                const int last = lg_best;
-                for (int i = last - lg_step; i <= last + lg_step; i += lg_step) {
-                    if (i < min_order - 1 || i >= max_order || ((lg_seen >> i) & 1u)) continue;
-                    const uint32_t cur = ((lg_seen >> lg_best) & 1u) ? l.trial[lg_best] : 0xFFFFFFFFu;
-                    lg_seen |= 1u << i;
-                    if (l.trial[i] < cur) lg_best = i;
-                }
-                lg_step >>= 1;
-            }
-            lg_best = __builtin_amdgcn_readfirstlane(lg_best);      // keeps the walk in scalar registers
-            lg_seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)lg_seen);
-        }
-    }
-    __syncthreads();
-
-    // ---- the method's walk over the table (optimize.c:201-261) ----
-    if (tid == 0) {
-        int best = 0;
-        if (constant) {
-            best = 0;
-        } else if (omethod >= 2 && omethod <= 4) {
-            const int levels = 1 << (omethod - 1);
-            uint32_t best_bits = 0;
-            best = max_order - 1;
-            for (int i = levels - 1; i >= 0; i--) {
-                int o = min_order + (((max_order - min_order + 1) * (i + 1)) / levels) - 2;
-                if (o < 0) o = 0;
-                const uint32_t b = l.trial[o];
-                if (i == levels - 1) best_bits = b;
-                else if (b < best_bits) { best_bits = b; best = o; }
-            }
-        } else if (omethod == 5) {
-            uint32_t best_bits = l.trial[0];
-            for (int i = 1; i < max_order; i++) {
-                const uint32_t b = l.trial[i];
-                if (b < best_bits) { best_bits = b; best = i; }
-            }
-        } else {
-            best = lg_best;
-        }
-        l.misc[1] = best;
-    }
-    __syncthreads();
-    if (tid < 32) {
-        // the winner as K2's compact row (kernels.h: FIN_STRIDE / FIN_DBL / FIN_PAIRS)
-        const int best = l.misc[1];
-        const int order = best + 1;
-        int32_t *f = fin_all + (size_t)s * FIN_STRIDE;
-        const int32_t cv = (tid < order) ? crow_base[best * FHIP_MAX_ORDER + tid] : 0;
-        f[tid] = cv;
-        int32_t sa = cv < 0 ? -cv : cv;
-        sa += __shfl_xor(sa, 1, WAVE); sa += __shfl_xor(sa, 2, WAVE);
-        sa += __shfl_xor(sa, 4, WAVE); sa += __shfl_xor(sa, 8, WAVE);
-        sa += __shfl_xor(sa, 16, WAVE);
-        const int32_t nb = __shfl_xor(cv, 1, WAVE);
-        if (tid < 16) reinterpret_cast<double *>(f + FIN_DBL)[tid] = (double)cv;
-        if (tid < 8 && (tid & 1) == 0) f[FIN_PAIRS + (tid >> 1)] = (nb & 0xFFFF) | (int32_t)((uint32_t)cv << 16);
-        if (tid == 0) {
-            f[32] = srow[best];
-            f[33] = order;
-            f[34] = sa;
-            opt_all[s] = order;
-        }
-    }
-}
-
 }  // namespace
 
 size_t encode_lds_bytes(int n)
@@ -2934,14 +1976,14 @@ bool fast_geometry(const fhip_params &p, int n, int *C, int *T)
 // True when every kernel of the pipeline that touches the sample rows understands
 // 16-bit rows for such a batch: the register K0 for stereo, the wave-typed K1 (or
 // no K1 at all) and a K3 fast-path geometry with runs of 8 or 16 samples.
-bool narrow_rows_ok(const fhip_params &p, int nsub, int n, bool lpc_path)
+bool narrow_rows_ok(const fhip_params &p, int nsub, int n, bool lpc_path, bool wave_typed_k1)
 {
     // measurements only (the generic K3 forced onto a fast-path geometry reads int32 rows)
     static const bool off = getenv("FHIP_NO_NARROW") != nullptr || getenv("FHIP_K3_GENERIC") != nullptr;
     if (off || p.channels != 2 || (n & 3) != 0 || n > 8192) return false;
     int fc = 0, ft = 0;
     if (!fast_geometry(p, n, &fc, &ft) || (fc % 8) != 0) return false;
-    if (lpc_path && !autocorr_is_wave_typed(nsub, n, p.max_prediction_order)) return false;
+    if (lpc_path && !wave_typed_k1 && !autocorr_is_wave_typed(nsub, n, p.max_prediction_order)) return false;
     return true;
 }
 
@@ -3041,53 +2083,6 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
     else if (chunk <= 32) LAUNCH_ENC(32);
     else LAUNCH_ENC(64);
 #undef LAUNCH_ENC
-    return hipGetLastError();
-}
-
-// The order-search kernel serves the LPC order searches (order methods 2..6) of block sizes
-// whose fast-path geometry has runs of 8 or 16 samples in at least 256 threads.
-bool order_search_supported(const fhip_params &p, int n)
-{
-    static const bool off = getenv("FHIP_NO_ORDER_SEARCH") != nullptr;      // measurements only
-    if (off) return false;
-    if (p.prediction_type != 2 || n <= p.max_prediction_order || n < 5) return false;
-    // (LOG, order method 6, walks step by step: a round per step of optimize.c:244-261, up to
-    // three candidates each.  A table of all orders measured slower: 342 + 74 us at level 8.)
-    static const bool no_log = getenv("FHIP_ORDER_SEARCH_NO_LOG") != nullptr;     // measurements only
-    if (p.order_method < 2 || p.order_method > (no_log ? 5 : 6)) return false;
-    int fc = 0, ft = 0;
-    if (!fast_geometry(p, n, &fc, &ft)) return false;
-    return (fc == 16 && (ft == 256 || ft == 512 || ft == 1024)) || (fc == 8 && ft == 256);
-}
-
-hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32_t *smp, int nsub,
-                               int n, const int32_t *coefs, const int32_t *shift,
-                               int32_t *opt_order, int32_t *fin, const fhip_subframe_info *prep,
-                               bool narrow_ok, const int32_t *dev_sub)
-{
-    if (nsub == 0) return hipSuccess;
-    int fc = 0, ft = 0;
-    if (!order_search_supported(p, n) || !fast_geometry(p, n, &fc, &ft)) return hipErrorInvalidValue;
-    constexpr int G = 4;
-    size_t off[12];
-#define LAUNCH_SRCH(CC, TT)                                                                  \
-    do {                                                                                     \
-        const size_t lds = srch_lds_layout<G>((size_t)SmpImg<CC, TT>::SIZE, off, TT);        \
-        hipError_t er = hipFuncSetAttribute(                                                 \
-            reinterpret_cast<const void *>(&k_order_search<CC, TT, G>),                      \
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-        if (er != hipSuccess) return er;                                                     \
-        hipLaunchKernelGGL((k_order_search<CC, TT, G>), dim3(nsub), dim3(TT), lds, st, p, n, \
-                           smp, coefs, shift, opt_order, fin, prep, narrow_ok ? 1 : 0, dev_sub); \
-    } while (0)
-    switch (fc * 10000 + ft) {
-    case 160256: LAUNCH_SRCH(16, 256); break;
-    case 160512: LAUNCH_SRCH(16, 512); break;
-    case 161024: LAUNCH_SRCH(16, 1024); break;
-    case 80256: LAUNCH_SRCH(8, 256); break;
-    default: return hipErrorInvalidValue;
-    }
-#undef LAUNCH_SRCH
     return hipGetLastError();
 }
 

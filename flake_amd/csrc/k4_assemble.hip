@@ -79,9 +79,24 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
                 int32_t *__restrict__ frame_bytes, uint32_t number_base, uint32_t number_step,
                 const uint32_t *__restrict__ numbers,
                 int sr_code0, int sr_code1, int bps_code, int verbatim_size,
-                const long long *__restrict__ frame_src, const int32_t *__restrict__ dev_frames)
+                const long long *__restrict__ frame_src, const int32_t *__restrict__ dev_frames, MultiBin mb)
 {
     if (dev_frames && (int)blockIdx.x >= dev_count(dev_frames, 0)) return;      // (a ragged batch's grid is its bin's capacity)
+    int f = blockIdx.x;
+    if (mb.nbins) {
+        // every bin of a ragged batch in one launch (kernels.h: MultiBin; one workgroup per frame
+        // slot: wg0 = unit0): info / frame_bytes / numbers / frame_src are the handle's whole
+        // slot-indexed arrays, the sections and the frames lie bin by bin
+        const int k = find_bin(mb, f);
+        const int local = f - mb.unit0[k];
+        if (local >= __builtin_amdgcn_readfirstlane(mb.cnt[mb.cnt_ix[k]])) return;
+        n = mb.n[k];
+        verbatim_size = mb.vsize[k];
+        slot_bytes = mb.slot[k];
+        frame_stride = mb.stride[k];
+        rice += mb.bits_off[k] - (long long)mb.unit0[k] * P.channels * slot_bytes;     // indexed by the global slot below
+        frames += mb.fr_off[k] - (long long)mb.unit0[k] * frame_stride;
+    }
     __shared__ uint8_t s_hdr[32];
     __shared__ uint8_t s_prefix[FHIP_MAX_CH][ASM_PREFIX_BYTES];
     __shared__ AsmSeg s_seg[ASM_MAX_SEG];
@@ -92,7 +107,6 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
     __shared__ int s_info[FHIP_MAX_CH][8];       // type, type_code, order, shift, obits, wasted, rice_nbits, ch_mode
 
     const int tid = threadIdx.x;
-    const int f = blockIdx.x;
     const int nch = P.channels;
     const fhip_subframe_info *fi = info + (size_t)f * nch;
     const int32_t *pcm_frame = pcm + (frame_src ? (size_t)frame_src[f] : (size_t)f * n * nch);
@@ -410,7 +424,31 @@ hipError_t launch_assemble(hipStream_t st, const fhip_params &p, const int32_t *
                                         : 16 + ((n * p.channels * bps + 7) >> 3);
     hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(NT), 0, st, p, n, pcm, info, rice,
                        (long long)slot_bytes, frames, (long long)frame_stride, frame_bytes,
-                       number_base, number_step, numbers, sr0, sr1, bpsc, vsize, frame_src, dev_frames);
+                       number_base, number_step, numbers, sr0, sr1, bpsc, vsize, frame_src, dev_frames, MultiBin{});
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_bins(hipStream_t st, const fhip_params &p, const MultiBin &mb, const int32_t *pcm,
+                                const fhip_subframe_info *info, const uint8_t *rice, uint8_t *frames,
+                                int32_t *frame_bytes, const uint32_t *numbers, const long long *frame_src)
+{
+    if (mb.nbins < 1 || !numbers || !frame_src) return hipErrorInvalidValue;
+    const int slots = mb.unit0[mb.nbins - 1] + mb.cap[mb.nbins - 1];
+    if (slots == 0) return hipSuccess;
+    static const int sr_table[16] = {0, 0, 0, 0, 8000, 16000, 22050, 24000, 32000, 44100, 48000,
+                                     96000, 0, 0, 0, 0};
+    static const int bd_table[8] = {0, 8, 12, 0, 16, 20, 24, 0};
+    int sr0 = 0, sr1 = 0, bpsc = 0;
+    for (int i = 4; i < 12; i++) if (p.sample_rate == sr_table[i]) { sr0 = i; break; }
+    if (!sr0) {
+        const int sr = p.sample_rate;
+        if (sr % 1000 == 0 && sr <= 255000) { sr0 = 12; sr1 = sr / 1000; }
+        else if (sr % 10 == 0 && sr <= 655350) { sr0 = 14; sr1 = sr / 10; }
+        else if (sr < 65535) { sr0 = 13; sr1 = sr; }
+    }
+    for (int i = 1; i < 8; i++) if (p.bits_per_sample == bd_table[i]) { bpsc = i; break; }
+    hipLaunchKernelGGL(k_assemble, dim3(slots), dim3(NT), 0, st, p, 0, pcm, info, rice, 0ll, frames, 0ll,
+                       frame_bytes, 0u, 0u, numbers, sr0, sr1, bpsc, 0, frame_src, (const int32_t *)nullptr, mb);
     return hipGetLastError();
 }
 
@@ -564,14 +602,18 @@ void k_frame_offsets_perm(const int32_t *__restrict__ fbytes, const int32_t *__r
                           long long cap, long long *__restrict__ totals)
 {
     __shared__ long long s_part[SCAN_NT];
+    __shared__ int s_max;
     const int tid = threadIdx.x;
     const int nframes = dev_count(dev_frames, 0);
     const int per = (nframes + SCAN_NT - 1) / SCAN_NT;
     const int f0 = min(tid * per, nframes), f1 = min(f0 + per, nframes);
     long long sum = 0;
-    for (int f = f0; f < f1; f++) sum += max(fbytes[order[f]], 0);
+    int mx = 0;
+    if (tid == 0) s_max = 0;
+    for (int f = f0; f < f1; f++) { const int b = max(fbytes[order[f]], 0); sum += b; mx = max(mx, b); }
     s_part[tid] = sum;
     __syncthreads();
+    if (mx > 0) atomicMax(&s_max, mx);
     for (int off = 1; off < SCAN_NT; off <<= 1) {
         const long long v = (tid >= off) ? s_part[tid - off] : 0;
         __syncthreads();
@@ -582,10 +624,10 @@ void k_frame_offsets_perm(const int32_t *__restrict__ fbytes, const int32_t *__r
     for (int f = f0; f < f1; f++) { offsets[f] = run; run += max(fbytes[order[f]], 0); }
     if (tid == SCAN_NT - 1) {
         offsets[nframes] = s_part[tid];
-        // totals: frames, bytes, largest frame (k_pack_frames_perm), 1 = the stream does not fit `cap`
+        // totals: frames, bytes, largest frame, 1 = the stream does not fit `cap`
         totals[0] = nframes;
         totals[1] = s_part[tid];
-        totals[2] = 0;
+        totals[2] = s_max;                     // encode.c:967 (ordered by the scan's barriers)
         totals[3] = (s_part[tid] > cap) ? 1 : 0;
     }
 }
@@ -601,10 +643,7 @@ void k_pack_frames_perm(const uint8_t *__restrict__ frames, const long long *__r
     if (f >= dev_count(dev_frames, 0)) return;
     const int slot = order[f];
     const int len = max(fbytes[slot], 0);
-    if (tid == 0) {
-        if (stream_bytes) stream_bytes[f] = fbytes[slot];           // the frame sizes in stream order
-        atomicMax(reinterpret_cast<unsigned long long *>(&totals[2]), (unsigned long long)len);   // encode.c:967
-    }
+    if (tid == 0 && stream_bytes) stream_bytes[f] = fbytes[slot];   // the frame sizes in stream order
     if (offsets[f] + len > cap) return;                             // the caller's buffer ends here (totals[3])
     const uint8_t *src = frames + src_off[slot];                   // 4-byte aligned
     uint8_t *dst = packed + offsets[f];

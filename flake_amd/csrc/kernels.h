@@ -37,7 +37,8 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
 
 // True when K0, K1 and K3 all handle 16-bit sample rows for such a batch; the
 // caller then passes allow_narrow / narrow_ok to the three launches of the batch.
-bool narrow_rows_ok(const fhip_params &p, int nsub, int n, bool lpc_path);
+// (wave_typed_k1: the caller runs the wave-typed K1 whatever the count -- launch_autocorr_bins)
+bool narrow_rows_ok(const fhip_params &p, int nsub, int n, bool lpc_path, bool wave_typed_k1 = false);
 
 // True when K1 will also do K0's apply stage for such a batch (stereo, whole
 // tiles, the wave-typed kernel): launch_prepare(decide_only) + launch_autocorr(pcm).
@@ -123,6 +124,37 @@ struct VbsBins {
     long long slot[8];        // residual-section slot bytes of the piece length
     long long bits_off[8];    // byte offset of the bin's sections in rice_bits[]
 };
+// One launch over ALL bins for the kernels whose code does not depend on the piece length (K1's
+// wave-typed kernel, K2, K4): the chain walk of K1, the Levinson recursion of K2 and the serial
+// header / CRC phases of K4 are latency, not throughput, and eight launches of a few hundred
+// frames each paid it eight times.  Workgroup -> (bin, unit inside the bin) through wg0[]; the
+// unit-indexed arrays (info, autoc, coefs ...) are the handle's whole workspaces, indexed by
+// unit0[bin] + local unit; sample rows start at smp_off[bin].
+struct MultiBin {
+    int nbins;                // 0: a plain launch
+    const int32_t *cnt;       // device: live units (subframes for K1 / K2, frames for K4) of entry k at
+    int cnt_ix[8];            //   cnt[cnt_ix[k]]: entries may list the bins in any order (K1: longest first)
+    int wg0[9];               // first workgroup of bin k; wg0[nbins] = the grid
+    int n[8];
+    int unit0[8];             // K1 / K2: first subframe of the bin; K4: first frame slot
+    int cap[8];               // units the bin can hold
+    int narrow[8];            // K1: the bin's rows may be 16-bit (K0's records say which)
+    long long smp_off[8];
+    double c[8];              // K1: the window constant of lpc.c:34 for the bin's n
+    long long stride[8], fr_off[8], slot[8], bits_off[8];     // K4
+    int vsize[8];                                              // K4: verbatim size (encode.c:521-527)
+};
+hipError_t launch_autocorr_bins(hipStream_t st, const MultiBin &mb, const int32_t *smp, int max_order,
+                                double *autoc, const fhip_subframe_info *info,
+                                const autocorr_lpc_out *lpc_out);
+bool autocorr_bins_supported(int max_order, const int *n, int nbins);
+hipError_t launch_lpc_bins(hipStream_t st, const MultiBin &mb, const double *autoc, int max_order,
+                           int precision, int omethod, int32_t *coefs, int32_t *shift,
+                           int32_t *opt_order, int32_t *fin);
+hipError_t launch_assemble_bins(hipStream_t st, const fhip_params &p, const MultiBin &mb, const int32_t *pcm,
+                                const fhip_subframe_info *info, const uint8_t *rice, uint8_t *frames,
+                                int32_t *frame_bytes, const uint32_t *numbers, const long long *frame_src);
+
 // CNT_*: layout of the device-side counts k_vbs_plan leaves (int32[24])
 constexpr int VBS_CNT_FRAMES = 0, VBS_CNT_SUB = 8, VBS_CNT_ALL = 16, VBS_CNT_WORDS = 24;
 hipError_t launch_vbs_plan(hipStream_t st, const int32_t *nfr, const int32_t *sizes, int nblocks,

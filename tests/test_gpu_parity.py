@@ -514,7 +514,7 @@ def test_log_walk_every_order_range(oracle):
             check(oracle, p, pcm, n, f"LOG {lo}..{hi} n={n} bps={bps}")
 
 
-@pytest.mark.parametrize("n", [4096, 8192, 16384, 2048])
+@pytest.mark.parametrize("n", [4096, 8192, 16384, 2048, 512, 1024, 1536, 2560, 3072, 3584, 5120, 6144, 7168])
 @pytest.mark.parametrize("om,mo", [(flake_amd.OM_SEARCH, 32), (flake_amd.OM_SEARCH, 9), (flake_amd.OM_8LEVEL, 32),
                                    (flake_amd.OM_4LEVEL, 12), (flake_amd.OM_2LEVEL, 8), (flake_amd.OM_LOG, 32)])
 def test_order_search_kernel(oracle, n, om, mo):

@@ -1944,7 +1944,12 @@ bool fast_geometry(const fhip_params &p, int n, int *C, int *T)
         if (n >= 4096) { c = 16; t = n / 16; }
         else if (n >= 2048) { c = 8; t = 256; }
         else if (n >= 1024) { c = 4; t = 256; }
-        else if (n == 512) { c = 8; t = 64; }
+        else if (n == 512) {
+            c = 8; t = 64;
+            // partitions finer than a run of 8 (partition orders 7, 8: the eighths of a 4096 block
+            // under the VBS presets): a thread per level-8 partition instead of the generic kernel
+            if ((n >> p.max_partition_order) < 8 && (n >> p.max_partition_order) >= 2) { c = 2; t = 256; }
+        }
         else if (n == 256) { c = 4; t = 64; }
         else return false;
     } else if (odd == 9) {                // 576, 1152, 2304, 4608, 9216
@@ -2038,6 +2043,7 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
         case 40256: LAUNCH_FAST(4, 256); break;
         case 80064: LAUNCH_FAST(8, 64); break;
         case 40064: LAUNCH_FAST(4, 64); break;
+        case 20256: LAUNCH_FAST(2, 256); break;
         case 90064: LAUNCH_FAST(9, 64); break;
         case 100256: LAUNCH_FAST(10, 256); break;
         case 100512: LAUNCH_FAST(10, 512); break;

@@ -11,9 +11,14 @@ K2 Levinson/quantise -> K3 residual + Rice search + Rice bit emit) over one
 batch of synthetic PCM that is already resident in HBM: BASELINE.json
 configs[1] -- stereo 16-bit 44.1 kHz, block size 4096, LPC order 8 (level-5
 parameters with the MAX order method), 4096 frames per GPU.  Frames are
-independent, so with N ranks each rank encodes its own 4096-frame shard of a
-4096*N-frame job (weak scaling); the only collective is the final all-reduce of
-{frames, residual bits} (RCCL), once per job, inside the timed region.
+independent, so with N ranks each rank encodes its own shard; the only collective
+is the final all-reduce of {frames, residual bits} (RCCL), once per job, inside
+the timed region.
+
+  --scaling weak    (default, what the driver runs) 4096 frames per rank: a 4096*N-frame job
+  --scaling strong  ONE job of --frames frames cut into contiguous shards (flake_amd.shard.
+                    shard_range): the per-GPU batch shrinks as N grows -- BASELINE configs[3]'s
+                    "one batch sharded over 1/2/4/8 GPUs"
 
 Prints ONE JSON line on rank 0 (see the keys in main()).
 """
@@ -31,6 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+SIMDS = 1024                     # 256 CUs x 4
+CLOCK_HZ = 2.4e9                 # max clock: issue bounds below are the least time the work can take
+ISSUE_CYCLES = 4                 # one wave64 vector instruction per 4 cycles and SIMD (MI355X_MICROARCH.md)
 
 
 def parse_args():
@@ -44,7 +52,9 @@ def parse_args():
     ap.add_argument("--settle-ms", type=float, default=40.0,
                     help="untimed steps before the warm-up until this much wall time has passed: "
                          "the clocks ramp for ~20 ms under this load whatever --warmup says")
-    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=4096,
+                    help="frames per GPU per step (weak scaling) or of the whole job (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--workload", choices=["configs[1]", "configs[3]"], default="configs[1]",
                     help="configs[1] is the one BASELINE.json's metric is quoted on (the default "
                          "and the only one the driver runs); configs[3] (8-channel 24-bit LPC-12, "
@@ -52,7 +62,7 @@ def parse_args():
                          "timed region and sharding for a scaling run of that shape")
     ap.add_argument("--ahead", action="store_true",
                     help="hint the next batch's feeder stage ahead (fhip_prepare_ahead) so that it "
-                         "runs beside the kernels in flight; measured SLOWER on MI355X (DESIGN.md 5: "
+                         "runs beside the kernels in flight; measured SLOWER on MI355X (DESIGN.md: "
                          "the kernels contend, 0.163-0.194 vs 0.151 ms/step), hence opt-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
@@ -60,14 +70,102 @@ def parse_args():
     ap.add_argument("--profile-steps", type=int, default=200,
                     help="extra steps with per-kernel hipEvent timing for the roofline object")
     ap.add_argument("--no-other-configs", action="store_true",
-                    help="skip the short per-kernel timings of BASELINE configs[2], configs[3], "
-                         "level 8 and level 2 that rank 0 adds as \"other_configs\" at N = 1")
+                    help="skip the per-kernel timings of the other BASELINE configs, the small-batch "
+                         "steps and the host path that rank 0 adds at N = 1")
     ap.add_argument("--other-steps", type=int, default=20)
     ap.add_argument("--with-residual", action="store_true",
                     help="also write the int32 residual (stage A of SURVEY 8d)")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------
+def workload(name):
+    import flake_amd
+    if name == "configs[3]":
+        p = flake_amd.level_params(5, channels=8, bits_per_sample=24, sample_rate=192000,
+                                   order_method=flake_amd.OM_MAX, max_prediction_order=12)
+        return p, "Msamples/s encoded, 8-channel 24-bit 192k blocksize 4096 LPC-12", \
+            ("configs[3]: 8-channel 24-bit 192 kHz, blocksize 4096, LPC-12 (level-5 params, "
+             "order method MAX, max order 12, partition orders 0-5), synthetic resonator PCM "
+             "resident in HBM")
+    p = flake_amd.level_params(5, channels=2, bits_per_sample=16, sample_rate=44100,
+                               order_method=flake_amd.OM_MAX)
+    return p, "Msamples/s encoded, 16-bit stereo 44.1k blocksize 4096 LPC-8", \
+        ("configs[1]: stereo 16-bit 44.1 kHz, blocksize 4096, LPC max order 8 "
+         "(level-5 params, order method MAX, partition orders 0-5, stereo "
+         "estimate), synthetic resonator PCM resident in HBM")
+
+
+def load_pmc():
+    """profiles/pmc_traffic.json: HBM bytes and SQ instruction counts per launch of the headline
+    kernels (rocprofv3 --pmc passes, tools/prof_round.sh); counters cannot be read from inside
+    this process, so the figures belong to the code state named there (`traffic_current`)."""
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        tj = json.load(open(tp))
+        from flake_amd.srcid import kernel_sources_sha1
+        tj["_current"] = (tj.get("_src_sha1") == kernel_sources_sha1())
+        return tj
+    except Exception:
+        return None
+
+
+def per_kernel_bounds(p, n, nframes, kernel_ms, rice_bytes, pmc, with_residual=False):
+    """What binds each kernel of the step, and how close to that bound it runs.
+
+    hbm         least bytes the kernel must move / 8 TB/s
+    fp64_issue  its un-fused fp64 operations (a multiply and an add per product: the reference's
+                rounding sequence) as wave instructions x 4 cycles over 1024 SIMDs at 2.4 GHz
+    valu_issue  its vector instructions per wave (SQ_INSTS_VALU / SQ_WAVES, PMC) x waves per SIMD x
+                4 cycles at 2.4 GHz
+    frac = bound time / measured time."""
+    import flake_amd
+    ch = p.channels
+    nsub = nframes * ch
+    samples = nsub * n
+    lags = p.max_prediction_order + 1
+    out = {}
+    for k, ms in kernel_ms.items():
+        t = ms * 1e-3
+        if k == "k_prepare":
+            row_bytes = 2 if (ch == 2 and p.bits_per_sample <= 16) else 4
+            b = samples * 4 + samples * row_bytes + nsub * 16
+            out[k] = {"ms": round(ms, 4), "bound": "hbm", "bytes": b,
+                      "frac": round(b / t / 1e9 / HBM_PEAK_GBPS, 4)}
+        elif k == "k_autocorr":
+            ops = samples * (2 * lags + 1)              # window multiply + a multiply and an add per lag
+            tb = ops / 64 * ISSUE_CYCLES / SIMDS / CLOCK_HZ
+            out[k] = {"ms": round(ms, 4), "bound": "fp64_issue", "fp64_ops": ops, "frac": round(tb / t, 4)}
+        elif k == "k_lpc":
+            o = p.max_prediction_order
+            ops = nsub * (2 * o * o + 8 * o)
+            tb = ops / 64 * ISSUE_CYCLES / SIMDS / CLOCK_HZ
+            out[k] = {"ms": round(ms, 4), "bound": "fp64_issue", "fp64_ops": ops, "frac": round(tb / t, 4),
+                      "note": "one lane per subframe: latency, not issue, sets its time"}
+        else:
+            ent = (pmc or {}).get(k, {}) if pmc else {}
+            vpw, waves = ent.get("valu_per_wave"), ent.get("waves_per_launch")
+            if vpw and waves and ent.get("frames") == nframes and ent.get("workload") == "configs[1]" \
+                    and ch == 2 and n == 4096 and p.bits_per_sample == 16:
+                tb = vpw * (waves / SIMDS) * ISSUE_CYCLES / CLOCK_HZ
+                out[k] = {"ms": round(ms, 4), "bound": "valu_issue", "valu_per_wave": vpw,
+                          "waves_per_launch": waves, "frac": round(tb / t, 4),
+                          "source": f"profiles/pmc_traffic.json, tag {pmc.get('_tag')}",
+                          "current": pmc.get("_current")}
+            else:
+                b = samples * 4 + rice_bytes + nsub * flake_amd.INFO_DTYPE.itemsize \
+                    + (samples * 4 if with_residual else 0)
+                out[k] = {"ms": round(ms, 4), "bound": "hbm", "bytes": b,
+                          "frac": round(b / t / 1e9 / HBM_PEAK_GBPS, 4),
+                          "note": "no instruction counts on record for this shape: algorithmic bytes"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU legs
+# ---------------------------------------------------------------------------------------------
 def _cpu_worker(job):
     """One host process of the all-cores leg: the oracle on its own copy of the sample."""
     frames, n, reps, pvals = job
@@ -88,9 +186,9 @@ def _cpu_worker(job):
 
 
 def host_cores():
-    """Host cores this job may really use: the scheduler affinity, cut to the cgroup's CPU
-    quota where one is set (a GPU box hands each GPU a share of the host: 16 cores for one
-    GPU of this pool), and to BENCH_CPU_CORES if given."""
+    """(cores used, cores available): the scheduler affinity cut to the cgroup's CPU quota where
+    one is set (a GPU box hands each GPU a share of the host: 16 cores for one GPU of this pool);
+    the all-cores leg uses at most BENCH_CPU_CORES (default 16) of them."""
     n = len(os.sched_getaffinity(0))
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -99,7 +197,45 @@ def host_cores():
     except Exception:
         pass
     cap = int(os.environ.get("BENCH_CPU_CORES", "16"))
-    return max(1, min(n, cap))
+    return max(1, min(n, cap)), n
+
+
+def small_cpu_baseline(params, n, frames, pcm=None, budget_s=2.0):
+    """The CPU restatement (kind "port", one thread) on a small sample of a workload: the figure
+    every `other_configs` row carries.  Whole frames through the oracle's flake_encode_frame()
+    (encode_block: the VBS driver included) when the row's outputs are frames."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib
+    import flake_amd
+    orc = oraclelib.Oracle()
+    ch = params.channels
+    if pcm is None:
+        pcm = flake_amd.synth_pcm(frames, n, ch, params.bits_per_sample)
+    frames = pcm.shape[0]
+    t0 = time.perf_counter()
+    done = 0
+    if params.variable_block_size:
+        fc = 0
+        for b in range(frames):
+            rc, _, fc = orc.encode_block(params, fc, pcm[b], n, 8 * n * ch * 4 + 4096)
+            if rc <= 0:
+                raise RuntimeError("oracle encode_block failed")
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+    else:
+        slot = flake_amd.rice_slot_bytes(params, n)
+        step = max(1, frames // 8)
+        for f0 in range(0, frames, step):
+            orc.encode_subframes_batch(params, pcm[f0:f0 + step], n, want_residual=False, slot_bytes=slot)
+            done += min(step, frames - f0)
+            if time.perf_counter() - t0 > budget_s:
+                break
+    dt = time.perf_counter() - t0
+    samples = done * n * ch
+    return {"value": round(samples / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"{done} frames of this workload ({samples / 1e6:.2f} Msamples, {dt:.2f} s), "
+                      "oracle/flake_oracle.c"}
 
 
 def cpu_baseline(params, n, budget_s, gpu_bits_per_frame=None):
@@ -145,7 +281,7 @@ def cpu_baseline(params, n, budget_s, gpu_bits_per_frame=None):
     # ---- every host core, one process each (spawned: this process holds the GPU)
     try:
         import multiprocessing as mp
-        ncores = host_cores()
+        ncores, navail = host_cores()
         wf = 256
         wreps = max(1, int(reps * frames / wf * 0.5))            # ~ half the one-thread budget each
         pvals = [getattr(params, k) for k, _ in params._fields_]
@@ -155,7 +291,7 @@ def cpu_baseline(params, n, budget_s, gpu_bits_per_frame=None):
             wall = time.perf_counter() - t0
         tot = ncores * wreps * wf * n * params.channels
         out["all_cores"] = {"value": round(tot / max(times) / 1e6, 1), "unit": "Msamples/s",
-                            "cores": ncores, "kind": "port",
+                            "cores": ncores, "cores_available": navail, "kind": "port",
                             "sample": f"{ncores} processes x {wreps} x {wf} frames, slowest worker "
                                       f"{max(times):.1f} s (pool wall {wall:.1f} s incl. start-up)"}
     except Exception as e:                                        # a reported extra, never fatal
@@ -195,6 +331,9 @@ def cpu_baseline(params, n, budget_s, gpu_bits_per_frame=None):
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# GPU side extras (rank 0, N = 1)
+# ---------------------------------------------------------------------------------------------
 def copy_bandwidth(dev, achieved_gbps, nbytes=1 << 30, reps=10):
     """Device-to-device copy of `nbytes` on the current stream: bytes read + bytes written per
     second, the rate a kernel that only moves data reaches on this box."""
@@ -215,83 +354,183 @@ def copy_bandwidth(dev, achieved_gbps, nbytes=1 << 30, reps=10):
     return {"copy_GBps_measured": round(gbps, 1), "frac_of_copy": round(achieved_gbps / gbps, 4)}
 
 
-def other_configs(dev_index, steps):
-    """Per-kernel timings (hipEvents on the launch stream) of the BASELINE configs the
-    headline is NOT quoted on, at their full sizes, plus two presets with an order
-    search: reported next to the headline, never as `value`."""
+def settled_ms(step, sync, steps, settle_ms=40.0):
+    """ms per step at settled clocks: untimed steps for `settle_ms`, then `steps` timed ones."""
+    for _ in range(3):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < settle_ms:
+        for _ in range(5):
+            step()
+        sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def kernel_profile(enc, step, steps, per_step=False):
+    """hipEvent time per kernel (pairs on the launch stream, fhip_set_profiling): the average
+    launch, or -- per_step: a step launches a kernel several times (a ragged batch's bins) --
+    the sum over one step."""
+    enc.set_profiling(True)
+    enc.kernel_times(reset=True)
+    for _ in range(steps):
+        step()
+    enc.sync()
+    per = {k: tms / (steps if per_step else c) for k, (tms, c) in enc.kernel_times(reset=True).items() if c}
+    enc.set_profiling(False)
+    return per
+
+
+def subframe_case(dev_index, tag, p, nframes, steps, with_residual=False, cpu=True, cpu_frames=48):
+    """One uniform-batch workload through fhip_encode_subframes_dev: ms per step at settled
+    clocks, hipEvent time per kernel, what binds each, and a small CPU figure beside it."""
     import torch
     import flake_amd
+    dev = torch.device("cuda", dev_index)
+    n = p.block_size
+    nsub = nframes * p.channels
+    slot = flake_amd.rice_slot_bytes(p, n)
+    pcm = torch.from_numpy(flake_amd.synth_pcm(nframes, n, p.channels, p.bits_per_sample)).to(dev)
+    info = torch.zeros(nsub * flake_amd.INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    bits = torch.zeros(nsub * slot, dtype=torch.uint8, device=dev)
+    resid = torch.zeros((nframes, p.channels, n), dtype=torch.int32, device=dev) if with_residual else None
+    enc = flake_amd.Encoder(p, max_frames=nframes, device=dev_index)
+    enc.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 
+    def step():
+        enc.encode_subframes_dev(pcm, nframes, n, info, residual=resid, rice_bits=bits, slot_bytes=slot)
+    ms = settled_ms(step, lambda: torch.cuda.synchronize(dev), steps)
+    per = kernel_profile(enc, step, max(3, steps // 2))
+    info_np = np.frombuffer(info.cpu().numpy().tobytes(), dtype=flake_amd.INFO_DTYPE)
+    samples = nframes * n * p.channels
+    rice_bytes = int(((info_np["rice_nbits"].clip(min=0) + 31) // 32 * 4).sum())
+    alg = samples * 4 + rice_bytes + nsub * flake_amd.INFO_DTYPE.itemsize + (samples * 4 if with_residual else 0)
+    dom = max(per, key=per.get)
+    row = {
+        "workload": tag, "frames": nframes, "samples_per_step": samples,
+        "ms_per_step": round(ms, 4), "Msamples_per_s": round(samples / ms / 1e3, 1),
+        "kernel_ms": {k: round(v, 4) for k, v in per.items()},
+        "dominant_kernel": dom,
+        "algorithmic_bytes": alg,
+        "hbm_frac_dominant": round(alg / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "hbm_frac_step": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "per_kernel": per_kernel_bounds(p, n, nframes, per, rice_bytes, None, with_residual),
+        "bits_per_sample_out": round(float(info_np["rice_nbits"].clip(min=0).sum()) / samples, 3),
+    }
+    enc.close()
+    del pcm, info, bits, resid
+    torch.cuda.empty_cache()
+    if cpu:
+        try:
+            row["cpu_baseline"] = small_cpu_baseline(p, n, cpu_frames)
+        except Exception as e:
+            row["cpu_baseline"] = {"error": repr(e)}
+    return row
+
+
+def vbs_case(dev_index, level, nblocks, steps, cpu=True):
+    """BASELINE configs[4] shape: variable block size (vbs.c) + exhaustive order / partition
+    search, blocks and stream device-resident through fhip_encode_blocks_vbs_dev (no host
+    synchronisation inside): ms per batch at settled clocks and the serial per-kernel sums."""
+    import torch
+    import flake_amd
+    dev = torch.device("cuda", dev_index)
+    p = flake_amd.level_params(level)
+    n = p.block_size
+    pcm_h = flake_amd.synth_pcm(nblocks, n, 2, 16)
+    pcm_h[::3, n // 2:, :] //= 16            # a transient in every third block: something to split
+    pcm = torch.from_numpy(pcm_h).to(dev)
+    cap = pcm_h.size * 5
+    packed = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    totals = torch.zeros(4, dtype=torch.int64, device=dev)
+    enc = flake_amd.Encoder(p, max_frames=8 * nblocks, device=dev_index)
+    enc.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
+    def step():
+        enc.encode_blocks_vbs_dev(pcm, nblocks, n, packed, cap, totals)
+    ms = settled_ms(step, lambda: torch.cuda.synchronize(dev), steps)
+    per = kernel_profile(enc, step, 3, per_step=True)      # (profiling serialises the bins: sums, not the step)
+    t = totals.cpu().numpy()
+    samples = nblocks * n * 2
+    alg = samples * 4 + int(t[1])
+    dom = max(per, key=per.get)
+    tag = ("-l 12 -m 5 -r 8 -v 1, n 4096" if level == 10 else "-l 32 -m 5 -r 8 -v 1, n 8192")
+    row = {
+        "workload": f"configs[4]: level {level} (variable block size, SEARCH order method, partition orders "
+                    f"0-8: {tag}), stereo 16-bit, {nblocks} blocks device-resident -> packed stream in HBM",
+        "blocks": nblocks, "frames_out": int(t[0]), "bytes_out": int(t[1]), "samples_per_step": samples,
+        "ms_per_step": round(ms, 4), "Msamples_per_s": round(samples / ms / 1e3, 1),
+        "kernel_ms_serial_sums": {k: round(v, 4) for k, v in per.items()},
+        "dominant_kernel": dom,
+        "algorithmic_bytes": alg,
+        "hbm_frac_step": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        "note": "eight bins of equal piece length; K1 / K2 / K4 one launch over all bins, K0 / order search / "
+                "K3 per bin on three internal streams; no host synchronisation inside",
+    }
+    enc.close()
+    del pcm, packed
+    torch.cuda.empty_cache()
+    if cpu:
+        try:
+            row["cpu_baseline"] = small_cpu_baseline(p, n, 24, pcm=pcm_h[:24])
+        except Exception as e:
+            row["cpu_baseline"] = {"error": repr(e)}
+    return row
+
+
+def other_configs(dev_index, steps, cpu=True):
+    """The BASELINE configs the headline is NOT quoted on, at their full sizes, two more presets,
+    and stage A of the headline (int32 residual out): reported next to the headline, never as
+    `value`; every row carries a small CPU figure (port, one core)."""
+    import flake_amd
     P = flake_amd.level_params
+    rows = []
     cases = [
         ("configs[2]: stereo 24-bit 96 kHz, n 4096, LPC order SEARCH 1-32, partition orders 0-8",
          P(5, bits_per_sample=24, sample_rate=96000, order_method=flake_amd.OM_SEARCH,
-           max_prediction_order=32, max_partition_order=8), 4096),
+           max_prediction_order=32, max_partition_order=8), 4096, False, 6),
         ("configs[3]: 8-channel 24-bit 192 kHz, n 4096, LPC-12 (MAX), 32768 subframes",
          P(5, channels=8, bits_per_sample=24, sample_rate=192000, order_method=flake_amd.OM_MAX,
-           max_prediction_order=12), 4096),
+           max_prediction_order=12), 4096, False, 16),
         ("configs[0] (the reference's CPU case) on the GPU: mono 16-bit, n 4096, fixed orders 0-4, "
-         "partition orders 0-3", P(2, channels=1, block_size=4096), 8192),
-        ("level 8: stereo 16-bit, n 4096, LPC <= 12 LOG search, partition orders 0-6", P(8), 4096),
+         "partition orders 0-3", P(2, channels=1, block_size=4096), 8192, False, 64),
+        ("level 8: stereo 16-bit, n 4096, LPC <= 12 LOG search, partition orders 0-6", P(8), 4096, False, 24),
         ("level 2: stereo 16-bit, n 1152, fixed orders 0-4, partition orders 0-3", P(2),
-         4096 * 4096 // 1152),
+         4096 * 4096 // 1152, False, 128),
+        ("configs[1], stage A (SURVEY 8d): the headline workload with the int32 residual written too",
+         P(5, order_method=flake_amd.OM_MAX), 4096, True, 48),
     ]
-    dev = torch.device("cuda", dev_index)
-    out = []
-    for tag, p, nframes in cases:
-        n = p.block_size
-        nsub = nframes * p.channels
-        slot = flake_amd.rice_slot_bytes(p, n)
-        pcm = torch.from_numpy(flake_amd.synth_pcm(nframes, n, p.channels, p.bits_per_sample)).to(dev)
-        info = torch.zeros(nsub * flake_amd.INFO_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-        bits = torch.zeros(nsub * slot, dtype=torch.uint8, device=dev)
-        enc = flake_amd.Encoder(p, max_frames=nframes, device=dev_index)
-        enc.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-
-        def step():
-            enc.encode_subframes_dev(pcm, nframes, n, info, rice_bits=bits, slot_bytes=slot)
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize(dev)
-        t_settle = time.perf_counter()           # as for the headline: the clocks ramp for ~20-40 ms
-        while (time.perf_counter() - t_settle) * 1e3 < 40.0:
-            for _ in range(5):
-                step()
-            torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize(dev)
-        ms = (time.perf_counter() - t0) / steps * 1e3
-        enc.set_profiling(True)
-        enc.kernel_times(reset=True)
-        for _ in range(max(3, steps // 2)):
-            step()
-        enc.sync()
-        per = {k: tms / c for k, (tms, c) in enc.kernel_times(reset=True).items() if c}
-        enc.set_profiling(False)
-        info_np = np.frombuffer(info.cpu().numpy().tobytes(), dtype=flake_amd.INFO_DTYPE)
-        samples = nframes * n * p.channels
-        alg = samples * 4 + int(((info_np["rice_nbits"].clip(min=0) + 31) // 32 * 4).sum()) \
-            + nsub * flake_amd.INFO_DTYPE.itemsize
-        dom = max(per, key=per.get)
-        out.append({
-            "workload": tag, "frames": nframes, "samples_per_step": samples,
-            "ms_per_step": round(ms, 4), "Msamples_per_s": round(samples / ms / 1e3, 1),
-            "kernel_ms": {k: round(v, 4) for k, v in per.items()},
-            "dominant_kernel": dom,
-            "algorithmic_bytes": alg,
-            "hbm_frac_dominant": round(alg / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            "hbm_frac_step": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            "bits_per_sample_out": round(float(info_np["rice_nbits"].clip(min=0).sum()) / samples, 3),
-        })
-        enc.close()
-        del pcm, info, bits
-        torch.cuda.empty_cache()
-    return out
+    for tag, p, nframes, with_res, cpu_frames in cases:
+        rows.append(subframe_case(dev_index, tag, p, nframes, steps, with_res, cpu, cpu_frames))
+    for level in (10, 12):
+        rows.append(vbs_case(dev_index, level, 1024, max(5, steps // 2), cpu))
+    return rows
 
 
-def host_path(nframes=4096, n=4096):
+def small_batch(dev_index, steps, full_ms):
+    """What a shard of an 8-way (4-, 2-way) split of ONE batch costs: the step at 512 / 1024 / 2048
+    frames of configs[1] and at 512 / 1024 frames of configs[3], per kernel, with the strong-scaling
+    efficiency it implies (step(4096) / (k x step(4096 / k)); launch gaps and K1's chain walk do
+    not shrink with the batch)."""
+    rows = []
+    for name, frames in (("configs[1]", 512), ("configs[1]", 1024), ("configs[1]", 2048),
+                         ("configs[3]", 512), ("configs[3]", 1024)):
+        p, _, _ = workload(name)
+        r = subframe_case(dev_index, f"{name} at {frames} frames", p, frames, steps, cpu=False)
+        ways = 4096 // frames
+        base = full_ms.get(name)
+        rows.append({"workload": name, "frames": frames, "ms_per_step": r["ms_per_step"],
+                     "kernel_ms": r["kernel_ms"], "split_ways": ways,
+                     "implied_strong_scaling_efficiency":
+                         (round(base / (ways * r["ms_per_step"]), 3) if base else None)})
+    return rows
+
+
+def host_path(nframes=4096, n=4096, vbs=True):
     """The PCIe-inclusive rate through the host C layer (flake_amd_encode_frames: pageable host
     PCM -> complete FLAC frames in host memory), with and without the stream MD5.  Reported
     beside the headline, never as `value`."""
@@ -307,6 +546,8 @@ def host_path(nframes=4096, n=4096):
     try:
         os.environ["FLAKE_AMD_BATCH"] = str(nframes)
         for key, md5 in (("ms_md5_off", "0"), ("ms_md5_on", "1")):
+            if md5 == "1" and not vbs:
+                continue                                 # (the per-rank leg: the stream's bytes only)
             os.environ["FLAKE_AMD_MD5"] = md5
             enc = flake_amd.HostEncoder(level=5, channels=2, bits_per_sample=16, sample_rate=44100,
                                         block_size=n, order_method=flake_amd.OM_MAX)
@@ -323,11 +564,12 @@ def host_path(nframes=4096, n=4096):
             enc.close()
             res[key] = round(best * 1e3, 3)
         res["Msamples_per_s_md5_off"] = round(res["samples"] / res["ms_md5_off"] / 1e3, 1)
-        # BASELINE configs[4] territory: variable block size (vbs.c) + order / partition search,
-        # through the same host entry: split, gather of the pieces, one pass of the path per piece
-        # length and the packing of the frames all stay on the device
+        if not vbs:
+            return res
+        # BASELINE configs[4] territory through the same host entry: upload, the device-resident
+        # batch (fhip_encode_blocks_vbs_dev), download of the stream's bytes
         os.environ["FLAKE_AMD_MD5"] = "0"
-        vbs = {}
+        vb = {}
         for level in (10, 12):
             nblk = 1024
             os.environ["FLAKE_AMD_BATCH"] = str(nblk)
@@ -350,9 +592,9 @@ def host_path(nframes=4096, n=4096):
                 if call:
                     best = dt if best is None else min(best, dt)
             enc.close()
-            vbs[f"level{level}"] = {"blocks": nblk, "block_size": bs, "ms": round(best * 1e3, 3),
-                                    "Msamples_per_s": round(nblk * bs * 2 / best / 1e6, 1)}
-        res["vbs_presets_md5_off"] = vbs
+            vb[f"level{level}"] = {"blocks": nblk, "block_size": bs, "ms": round(best * 1e3, 3),
+                                   "Msamples_per_s": round(nblk * bs * 2 / best / 1e6, 1)}
+        res["vbs_presets_md5_off"] = vb
         res["note"] = ("pageable host memory in and out; copies over PCIe, kernels and frame packing "
                        "overlap across two handles; MD5 (sequential over the stream) on a helper thread")
     finally:
@@ -393,6 +635,7 @@ def main():
         raise SystemExit(launch_ranks(args.gpus))
     import torch
     import flake_amd
+    from flake_amd.shard import shard_range
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -409,6 +652,7 @@ def main():
     # BENCH_FORCE_DIST=1: go through the collective path (RCCL init, all-reduce, barrier,
     # all-gather on this rank's stream) even with one rank -- what a one-GPU box can rehearse
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST", "") == "1"
+    backend = None
     if use_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
@@ -442,36 +686,30 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
-    # ---- workload: BASELINE.json configs[1] --------------------------------
-    if args.workload == "configs[3]":
-        p = flake_amd.level_params(5, channels=8, bits_per_sample=24, sample_rate=192000,
-                                   order_method=flake_amd.OM_MAX, max_prediction_order=12)
-        metric = "Msamples/s encoded, 8-channel 24-bit 192k blocksize 4096 LPC-12"
-        workload = ("configs[3]: 8-channel 24-bit 192 kHz, blocksize 4096, LPC-12 (level-5 params, "
-                    "order method MAX, max order 12, partition orders 0-5), synthetic resonator PCM "
-                    "resident in HBM")
-    else:
-        p = flake_amd.level_params(5, channels=2, bits_per_sample=16, sample_rate=44100,
-                                   order_method=flake_amd.OM_MAX)
-        metric = "Msamples/s encoded, 16-bit stereo 44.1k blocksize 4096 LPC-8"
-        workload = ("configs[1]: stereo 16-bit 44.1 kHz, blocksize 4096, LPC max order 8 "
-                    "(level-5 params, order method MAX, partition orders 0-5, stereo "
-                    "estimate), synthetic resonator PCM resident in HBM")
+    # ---- workload: BASELINE.json configs[1] (or configs[3]) ------------------
+    p, metric, wl_text = workload(args.workload)
     n = p.block_size
-    nframes = args.frames
+    if args.scaling == "strong":
+        first, last = shard_range(args.frames, rank, world)     # one job, contiguous shards
+        nframes = last - first
+        if nframes < 1:
+            raise SystemExit("--scaling strong needs at least one frame per rank")
+        first_frame = first
+    else:
+        nframes = args.frames                                     # the same batch size on every rank
+        first_frame = rank * args.frames
     nsub = nframes * p.channels
     slot = flake_amd.rice_slot_bytes(p, n)
 
-    # default: the one resident batch of BASELINE configs[1].  With --ahead two batches of this
-    # rank's shard alternate (different frames of the same signal model): while batch i is in
-    # flight the handle is told batch i+1 is ready (fhip_prepare_ahead)
+    # default: the one resident batch.  With --ahead two batches of this rank's shard alternate
+    # (different frames of the same signal model): while batch i is in flight the handle is told
+    # batch i+1 is ready (fhip_prepare_ahead)
     nbatches = 2 if args.ahead else 1
     pcms = [torch.from_numpy(flake_amd.synth_pcm(nframes, n, p.channels, p.bits_per_sample,
-                                                 first_frame=(nbatches * rank + k) * nframes)).to(dev)
+                                                 first_frame=nbatches * first_frame + k * nframes)).to(dev)
             for k in range(nbatches)]
     if nbatches == 1:
-        pcms.append(pcms[0])       # BASELINE configs[1]: one resident batch of 4096 frames per GPU
-    pcm = pcms[0]
+        pcms.append(pcms[0])
     info_bytes = flake_amd.INFO_DTYPE.itemsize
     info = torch.zeros(nsub * info_bytes, dtype=torch.uint8, device=dev)
     bits = torch.zeros(nsub * slot, dtype=torch.uint8, device=dev)
@@ -487,8 +725,6 @@ def main():
     enc.set_stream(stream.cuda_stream)
     # gloo reduces host tensors; RCCL device tensors
     cdev = dev if (not use_dist or backend == "nccl") else torch.device("cpu")
-    # the job's counters: a host tensor unless RCCL is going to reduce them
-    stats = torch.zeros(3, dtype=torch.int64, device=cdev if use_dist else torch.device("cpu"))
 
     ahead = args.ahead
     count = [0]
@@ -503,25 +739,29 @@ def main():
 
     batch_bits = [0, 0]           # residual bits of the two batches (filled before the timed region)
     batch_rice_bytes = [0, 0]
+    nb_view = info.view(torch.int32).view(nsub, info_bytes // 4)[:, 10]
 
     def info_bits():
-        nb = info.view(torch.int32).view(nsub, info_bytes // 4)[:, 10].clamp(min=0)
+        nb = nb_view.clamp(min=0)
         return int(nb.sum().item()), int(((nb + 31) // 32 * 4).sum().item())
 
     def job_stats(steps):
-        """The job's only exchange: {frames, residual bits} summed over ranks.
-        The batches' bit totals were read back from their info records before the timed region
-        (the same resident input every step: the totals do not change); the records of the step
-        timed last are read back once more behind the closing fence and must say the same."""
-        last = (count[0] - 1) % 2
-        # (one host tensor, one copy: element-wise writes into a device tensor would each be a
-        # kernel launch inside the timed region)
-        mine = torch.tensor([nframes * steps,
-                             batch_bits[last] * ((steps + 1) // 2) + batch_bits[last ^ 1] * (steps // 2),
-                             1], dtype=torch.int64)                       # [2]: ranks_seen
-        stats.copy_(mine)
+        """The job's only exchange: {frames, residual bits} summed over ranks.  The
+        residual bits are reduced ON THE DEVICE from the records the last step wrote (one torch
+        reduction, inside the timed region) and count `steps` times: every step encodes the same
+        resident batch (two alternating ones with --ahead, whose totals were read beforehand)."""
+        last_bits = nb_view.clamp(min=0).sum()                        # device scalar, no host sync
+        if ahead:
+            other = batch_bits[count[0] % 2]
+            job_bits = last_bits * ((steps + 1) // 2) + other * (steps // 2)
+        else:
+            job_bits = last_bits * steps
+        mine = torch.stack([torch.tensor(nframes * steps, dtype=torch.int64, device=dev), job_bits.to(torch.int64),
+                            torch.tensor(1, dtype=torch.int64, device=dev)])
+        st = mine.to(cdev)
         if use_dist:
-            dist.all_reduce(stats)
+            dist.all_reduce(st)
+        return st
 
     def fence():
         if use_dist:
@@ -545,12 +785,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    job_stats(args.steps)
+    stats = job_stats(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if args.steps:
-        # outside the timed region (a read-back of 11 MB of records and two host syncs: 0.2 ms,
-        # 7 % of a 20-step run): what the last timed step wrote is the batch's total
+        # behind the closing fence: what the last timed step wrote is the batch's total
         last_bits = info_bits()[0]
         if last_bits != batch_bits[(count[0] - 1) % 2]:
             raise SystemExit(f"bench: the last timed step wrote {last_bits} residual bits, "
@@ -560,86 +799,81 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         per_rank = [torch.zeros(2, dtype=torch.int64, device=cdev) for _ in range(world)]
-        dist.all_gather(per_rank, torch.tensor([rank, nframes * args.steps], dtype=torch.int64,
-                                               device=cdev))
-        rank_frames = {int(r[0]): int(r[1]) for r in per_rank}
+        dist.all_gather(per_rank, torch.tensor([rank, nframes], dtype=torch.int64, device=cdev))
+        rank_batch = {int(r[0]): int(r[1]) for r in per_rank}
     else:
-        rank_frames = {0: nframes * args.steps}
-
-    samples_per_step = nframes * n * p.channels * world
+        rank_batch = {0: nframes}
+    frames_per_step = sum(rank_batch.values())
+    samples_per_step = frames_per_step * n * p.channels
     value = samples_per_step * args.steps / dt / 1e6
+
+    # ---- N > 1: the PCIe-inclusive host path of every rank's shard, side by side ----
+    host_ranks = None
+    if use_dist and world > 1 and not args.no_other_configs and args.workload == "configs[1]":
+        try:
+            dist.barrier()
+            hp = host_path(nframes=max(64, nframes), n=n, vbs=False)
+            mine = torch.tensor([hp["ms_md5_off"], hp["samples"]], dtype=torch.float64, device=cdev)
+        except Exception:
+            mine = torch.tensor([0.0, 0.0], dtype=torch.float64, device=cdev)
+        allhp = [torch.zeros(2, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(allhp, mine)
+        if rank == 0:
+            ms = [float(x[0]) for x in allhp]
+            host_ranks = {"per_rank_ms_md5_off": [round(m, 3) for m in ms],
+                          "sum_Msamples_per_s": round(sum(float(x[1]) / float(x[0]) / 1e3 for x in allhp if float(x[0]) > 0), 1),
+                          "note": "each rank: pageable host PCM -> FLAC frames in host memory for its shard "
+                                  "(flake_amd_encode_frames), all ranks at once; never `value`"}
 
     # ---- roofline of the dominant kernel (rank 0, hipEvents on the launch stream)
     roofline = None
     cpu = None
     others = None
     host = None
+    small = None
     if rank == 0:
         rice_bytes = sum(batch_rice_bytes) // 2            # the two alternating batches, averaged
         alg_bytes = (nframes * n * p.channels * 4          # int32 PCM in
                      + rice_bytes                          # packed residual sections out
                      + nsub * info_bytes                   # side info out
                      + (nframes * n * p.channels * 4 if args.with_residual else 0))
-        enc.set_profiling(True)
-        enc.kernel_times(reset=True)
-        for i in range(args.profile_steps):
-            step()                       # as in the timed region, the feeder of batch i+1 beside batch i
-        enc.sync()
+        per = kernel_profile(enc, step, args.profile_steps) if args.profile_steps else {}
         torch.cuda.synchronize(dev)
-        kt = enc.kernel_times(reset=True)
-        enc.set_profiling(False)
         enc.encode_subframes_dev(pcms[0], nframes, n, info, residual=resid, rice_bits=bits,
                                  slot_bytes=slot)           # batch 0's records for the CPU cross-check
         enc.sync()
         info_np = np.frombuffer(info.cpu().numpy().tobytes(), dtype=flake_amd.INFO_DTYPE)
-        per = {k: (ms / max(c, 1)) for k, (ms, c) in kt.items() if c}
+        pmc = load_pmc() if args.workload == "configs[1]" else None
         if per:                          # empty with --profile-steps 0 (the PMC passes)
             dom = max(per, key=per.get)
             achieved = alg_bytes / (per[dom] * 1e-3) / 1e9
-            # HBM bytes per launch of that kernel: rocprofv3 --pmc passes (FETCH_SIZE and
-            # WRITE_SIZE, separate runs of this bench; tools/prof_round.sh) summarised into
-            # profiles/pmc_traffic.json -- counters cannot be read from inside this process, so the
-            # figure belongs to the code state named in traffic_source, not to this run
-            traffic = None
-            traffic_source = None
-            traffic_current = None
-            tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tp) and args.workload == "configs[1]":     # counters taken on configs[1]
-                try:
-                    tj = json.load(open(tp))
-                    traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
-                    traffic_source = f"profiles/pmc_traffic.json, tag {tj.get('_tag')}"
-                    from flake_amd.srcid import kernel_sources_sha1
-                    # true when the counters were taken with exactly these kernel sources
-                    traffic_current = (tj.get("_src_sha1") == kernel_sources_sha1())
-                except Exception:
-                    traffic = None
+            traffic = (pmc or {}).get(dom, {}).get("hbm_bytes_per_launch") if nframes == 4096 else None
             roofline = {
                 "bound": "hbm", "kernel": dom,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "traffic_source": traffic_source,
-                "traffic_current": traffic_current,
+                "traffic_source": f"profiles/pmc_traffic.json, tag {pmc.get('_tag')}" if pmc else None,
+                "traffic_current": pmc.get("_current") if pmc else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": {k: round(v, 4) for k, v in per.items()},
-                # with the next batch's k_prepare hinted ahead it runs on a stream of its own
-                # beside k_autocorr: the step is shorter than the sum of these durations
+                # what binds each kernel and how close it runs to THAT bound: the step is three
+                # launches of which only the first is an HBM problem
+                "per_kernel": per_kernel_bounds(p, n, nframes, per, rice_bytes, pmc, args.with_residual),
                 "prepare_ahead": ahead,
                 "step_ms": round(dt / args.steps * 1e3, 4),
                 "pipeline_achieved": round(alg_bytes / (dt / args.steps) / 1e9, 1),
                 "pipeline_frac": round(alg_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
             }
-        if roofline is not None:
             try:                             # the fraction of a *measured* copy too
                 roofline.update(copy_bandwidth(dev, achieved))
             except Exception as e:
                 roofline["copy_GBps_measured"] = None
                 roofline["copy_error"] = repr(e)
             try:                             # all HBM bytes the step's kernels moved (PMC) / step
-                if args.workload != "configs[1]":
+                if pmc is None or nframes != 4096:
                     raise KeyError(args.workload)
-                tj = json.load(open(tp))
-                moved = sum(v["hbm_bytes_per_launch"] for k, v in tj.items() if not k.startswith("_"))
+                moved = sum(v["hbm_bytes_per_launch"] for k, v in pmc.items()
+                            if not k.startswith("_") and isinstance(v, dict) and "hbm_bytes_per_launch" in v)
                 roofline["pipeline_traffic"] = moved
                 roofline["pipeline_traffic_GBps"] = round(moved / (dt / args.steps) / 1e9, 1)
             except Exception:
@@ -653,9 +887,17 @@ def main():
                 cpu = {"error": repr(e)}
         if world == 1 and not args.no_other_configs and args.workload == "configs[1]":
             try:
-                others = other_configs(dev_index, args.other_steps)
+                others = other_configs(dev_index, args.other_steps, cpu=not args.no_cpu_baseline)
             except Exception as e:                      # reported extras must not cost the headline line
                 others = [{"error": repr(e)}]
+            try:
+                full = {"configs[1]": dt / args.steps * 1e3 if nframes == 4096 else None}
+                for r in others or []:
+                    if isinstance(r, dict) and str(r.get("workload", "")).startswith("configs[3]"):
+                        full["configs[3]"] = r["ms_per_step"]
+                small = small_batch(dev_index, args.other_steps, full)
+            except Exception as e:
+                small = [{"error": repr(e)}]
             try:
                 host = host_path()
             except Exception as e:                      # a reported extra, never fatal
@@ -675,29 +917,35 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "int64/f64",
             "data": "synthetic",
             "config": {
-                "workload": workload,
-                "frames_per_gpu": nframes,
+                "workload": wl_text,
+                "frames_per_gpu": nframes if args.scaling == "weak" else [rank_batch.get(r, 0) for r in range(world)],
+                "job_frames_per_step": frames_per_step,
                 "samples_per_step": samples_per_step,
                 "batches": ("two batches of this shard alternate; the next one's feeder stage is "
                             "hinted ahead (fhip_prepare_ahead)") if ahead else "one resident batch",
                 "outputs": "subframe info + packed Rice residual sections"
                            + (" + int32 residual" if args.with_residual else ""),
-                "parallelism": f"frame-sharded x{world}",
+                "parallelism": f"frame-sharded x{world}"
+                               + (" (one job cut into contiguous shards)" if args.scaling == "strong" else ""),
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
             "other_configs": others,
+            "small_batch_ms": small,
             "host_path": host,
+            "host_path_ranks": host_ranks,
         }
         out["job_frames"] = int(stats[0].item())
         out["job_residual_bits"] = int(stats[1].item())
+        out["job_residual_bits_note"] = ("the last timed step's records reduced on the device inside the timed "
+                                         "region, times the steps (every step encodes the same resident batch)")
         out["ranks_seen"] = int(stats[2].item())
-        out["rank_frames"] = [rank_frames.get(r, 0) for r in range(world)]
+        out["rank_frames"] = [rank_batch.get(r, 0) * args.steps for r in range(world)]
         out["dist_backend"] = backend if use_dist else None
         print(json.dumps(out), flush=True)
 

@@ -27,6 +27,8 @@ def test_host_cores_respects_the_cap(monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
     monkeypatch.setenv("BENCH_CPU_CORES", "3")
-    assert 1 <= bench.host_cores() <= 3
+    used, avail = bench.host_cores()
+    assert 1 <= used <= 3 and used <= avail <= len(os.sched_getaffinity(0))
     monkeypatch.setenv("BENCH_CPU_CORES", "100000")
-    assert 1 <= bench.host_cores() <= len(os.sched_getaffinity(0))
+    used, avail = bench.host_cores()
+    assert 1 <= used == avail <= len(os.sched_getaffinity(0))

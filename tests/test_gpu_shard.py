@@ -111,6 +111,24 @@ def test_bench_launches_its_own_ranks():
     assert out["value"] > 0 and out["scaling"] == "weak"
 
 
+def test_bench_strong_scaling_two_ranks():
+    """`--scaling strong`: ONE job of --frames frames cut into contiguous shards
+    (flake_amd.shard.shard_range), here 301 frames over two ranks: 151 + 150."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", "strong",
+                        "--steps", "5", "--warmup", "2", "--settle-ms", "1", "--frames", "301",
+                        "--profile-steps", "0", "--no-cpu-baseline", "--no-other-configs"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["ranks_seen"] == 2
+    assert out["config"]["frames_per_gpu"] == [151, 150] == [b - a for a, b in (shard_range(301, 0, 2), shard_range(301, 1, 2))]
+    assert out["rank_frames"] == [151 * 5, 150 * 5] and out["job_frames"] == 301 * 5
+    assert out["config"]["samples_per_step"] == 301 * 4096 * 2
+    assert out["job_residual_bits"] > 0 and out["value"] > 0
+
+
 def test_bench_rccl_path_with_one_rank():
     """The collective path of bench.py over RCCL (init with device_id, all-reduce, barrier,
     all-gather on this rank's stream) -- what a one-GPU box can rehearse of the N-GPU run --

@@ -465,8 +465,14 @@ static_assert(WT_ROWS0 + 3 * WT_ROWS1 == WT_SUB, "producer row split");
 // start on even doubles; ds_read_b128 serves 16 lanes per LDS cycle and is
 // conflict-free when their 16-byte slots differ mod 16: stride/2 odd (83).  The
 // shifted `b0` stream stays on single 8-byte reads (its alignment depends on the
-// lag); with this stride they are 2-way conflicted, which the walk -- bound by
-// instruction issue, not by the LDS -- does not feel.
+// lag).  An 8-byte read serves 32 lanes per LDS cycle; with an even stride (2 x 83
+// doubles = 332 dwords = 12 mod 64) subframes sl and sl + 16 fall on the same bank
+// pair: every b0 read is 2-way conflicted -- ALL of the kernel's bank-conflict cycles
+// (SQ pass over the probe builds, profiles/r03_k1_lds_counters.txt: producers alone 0,
+// consumers 1546 per wave, none without the b0 reads).  A stride that clears them is
+// odd and breaks the `a` stream's 16-byte alignment; dropping EVERY b0 read (probe
+// NOB, wrong results) shortens the launch by 5 us of 55, so the conflicts are worth
+// 2-3 us at most and the layout stays.
 constexpr int WT_ROW = PS_HH + PS_HALF + 2;          // doubles per parity array (82)
 constexpr int WT_STRIDE = 2 * WT_ROW + 2;            // per subframe (166)
 static_assert(WT_ROW % 2 == 0 && WT_STRIDE % 4 == 2, "16-byte aligned arrays, odd slot stride");
@@ -520,7 +526,7 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
                    int nsub, int n, int maxlag, wt_groups grp, double c,
                    const int32_t *__restrict__ pcm, int32_t *__restrict__ smp_out,
                    const fhip_subframe_info *__restrict__ info, wt_lpc_args lpc, int narrow_ok,
-                   const int32_t *__restrict__ dev_sub, MultiBin mb)
+                   const int32_t *__restrict__ dev_sub, MultiBin mb, wt_groups grp1, int lsplit)
 {
     extern __shared__ __attribute__((aligned(16))) double wt_lds[];
     double *acbuf = wt_lds + WT_NBUF * WT_BUF;          // [32][FHIP_MAX_LAGS], LPCMO > 0 only
@@ -547,6 +553,14 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
         lpc.fin += u0 * FIN_STRIDE;
     } else {
         nsub = dev_count(dev_sub, nsub);
+    }
+    // lsplit = 2 (small batches: fewer workgroups than CUs): two workgroups share a tile of 32
+    // subframes, one walks the even lags (grp), the other the odd ones (grp1) -- a wave then carries
+    // one or two chains instead of three, and the walk, which is what a small batch waits for, is
+    // that much shorter.  Both stage the same rows.  K2 cannot be the tail then.
+    if (lsplit == 2) {
+        if (blk & 1) grp = grp1;
+        blk >>= 1;
     }
     const int sub0 = blk * WT_SUB;
     if (sub0 >= nsub) return;                           // (a ragged batch's grid is its bin's capacity)
@@ -727,6 +741,8 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
     }
 
     // -------------------------------- consumer --------------------------------
+    // (s_setprio for the walk -- consumers ahead of the staging wave on their SIMD -- changed nothing:
+    // 55.6 vs 56.1 us, round 3)
     const int pi = lane >> 5, sl = lane & 31;
     const int l0 = grp.l0[wv], nch = grp.nch[wv];       // wave-uniform
     const bool live = (sub0 + sl < nsub) && nch > 0;
@@ -883,7 +899,7 @@ namespace {
 //   wt : rounds x (n/2 x max(23, 4.8 NCH) + 8000)      32 subframes per workgroup, whole tiles only, K2 included
 //   ps : rounds x (n/2 x 39 + 1000)                      Gp subframes per wave
 //   cur: passes of 2048 waves x (n x 33..41 + 1000)      G subframes per wave
-struct ac_choice { int kernel; int G, nl2, Gp, lps, ge, ne, no; };   // kernel: 0 cur, 1 ps, 2 wt
+struct ac_choice { int kernel; int G, nl2, Gp, lps, ge, ne, no, split; };   // kernel: 0 cur, 1 ps, 2 wt; split: wt's lag split
 ac_choice pick_autocorr(int nsub, int n, int max_order)
 {
     ac_choice ch{};
@@ -907,12 +923,22 @@ ac_choice pick_autocorr(int nsub, int n, int max_order)
                          (n * (waves_cur > simds ? 41.0 : 33.0) + 1000.0);
     const double t_ps = (ch.Gp >= 1) ? (double)(((nsub + ch.Gp - 1) / ch.Gp + simds - 1) / simds) * (0.5 * n * 39.0 + 1000.0) : 1e30;
     double t_wt = 1e30;
+    ch.split = 1;
     if ((n % AC_TILE) == 0) {
         const int e0 = (ch.ne + 1) / 2;
         // re-measured after this round's changes: 23 ns per step up to three chains per
         // group, 8 us per launch for barriers, head and the K2 tail (n = 2560 .. 7168)
         const double per_step = (4.8 * e0 > 23.0) ? 4.8 * e0 : 23.0;
-        t_wt = (double)(((nsub + WT_SUB - 1) / WT_SUB + 255) / 256) * (0.5 * n * per_step + 8000.0);
+        const int tiles = (nsub + WT_SUB - 1) / WT_SUB;
+        t_wt = (double)((tiles + 255) / 256) * (0.5 * n * per_step + 8000.0);
+        // a small batch leaves CUs idle: split the lags over two workgroups per tile (round 3)
+        static const bool no_split = getenv("FHIP_NO_LAG_SPLIT") != nullptr;      // measurements only
+        if (!no_split && 2 * tiles <= 256 && max_order >= 2) {
+            ch.split = 2;
+            const int m = (ch.ne + 3) / 4;                 // chains of the largest group after the split
+            const double ps2 = (4.8 * m > 14.0) ? 4.8 * m : 14.0;
+            t_wt = 0.5 * n * ps2 + 8000.0;
+        }
     }
     // only the wave-typed kernel runs K2 as its tail; the others pay its launch (~9 us)
     const double k2 = (max_order <= 12) ? 9000.0 : 0.0;
@@ -937,7 +963,9 @@ bool autocorr_is_wave_typed(int nsub, int n, int max_order)
 bool autocorr_does_lpc(int nsub, int n, int max_order)
 {
     static const bool off = getenv("FHIP_NO_LPC_TAIL") != nullptr;      // measurements only
-    return !off && max_order <= 12 && pick_autocorr(nsub, n, max_order).kernel == 2;
+    if (off || max_order > 12) return false;
+    const ac_choice ch = pick_autocorr(nsub, n, max_order);
+    return ch.kernel == 2 && ch.split == 1;              // (a lag-split launch leaves K2 to its own kernel)
 }
 
 bool autocorr_fuses_prepare(const fhip_params &p, int nsub, int n)
@@ -993,7 +1021,7 @@ hipError_t launch_autocorr_bins(hipStream_t st, const MultiBin &mb, const int32_
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_autocorr_wt<N_, false, L_>), dim3(blocks), dim3(8 * WAVE), lds, st, smp, \
                            autoc, 0, 0, max_order, gr, 0.0, (const int32_t *)nullptr, (int32_t *)nullptr, info, la, 0, \
-                           (const int32_t *)nullptr, mb);                                    \
+                           (const int32_t *)nullptr, mb, wt_groups{}, 1);                    \
     } while (0)
     if (lpcmo == 8) {
         switch (nch) {
@@ -1045,13 +1073,32 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
     if (narrow_ok && (!info || pcm_fused)) return hipErrorInvalidValue;
     const int e0 = (ne + 1) / 2, e1 = ne - e0, o0 = (no + 1) / 2, o1 = no - o0;
     if (use_wt) {
-        wt_groups gr;
-        gr.l0[0] = 0;          gr.nch[0] = e0;
-        gr.l0[1] = 2 * e0;     gr.nch[1] = e1;
-        gr.l0[2] = 1;          gr.nch[2] = o0;
-        gr.l0[3] = 1 + 2 * o0; gr.nch[3] = o1;
-        const int nch = e0;                                    // e0 >= e1, o0, o1
-        const int blocks = (nsub + WT_SUB - 1) / WT_SUB;
+        wt_groups gr, gr1{};
+        const int split = (pcm_fused || lpc_out) ? 1 : ch.split;
+        int nch;
+        if (split == 2) {
+            // even lags over the four consumer waves of one workgroup, odd lags over those of its
+            // partner: groups of consecutive same-parity lags, sizes differing by at most one,
+            // the largest first
+            auto spread = [](wt_groups &g, int first, int count) {
+                int l = first;
+                for (int w = 0; w < 4; w++) {
+                    const int k = count / 4 + (w < count % 4 ? 1 : 0);
+                    g.l0[w] = l; g.nch[w] = k;
+                    l += 2 * k;
+                }
+            };
+            spread(gr, 0, ne);
+            spread(gr1, 1, no);
+            nch = (ne + 3) / 4;                                // ne >= no
+        } else {
+            gr.l0[0] = 0;          gr.nch[0] = e0;
+            gr.l0[1] = 2 * e0;     gr.nch[1] = e1;
+            gr.l0[2] = 1;          gr.nch[2] = o0;
+            gr.l0[3] = 1 + 2 * o0; gr.nch[3] = o1;
+            nch = e0;                                          // e0 >= e1, o0, o1
+        }
+        const int blocks = split * ((nsub + WT_SUB - 1) / WT_SUB);
         const size_t lds = sizeof(double) * (size_t)WT_NBUF * WT_BUF;
         wt_lpc_args la{};
         int lpcmo = 0;
@@ -1069,7 +1116,7 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all); \
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_autocorr_wt<N_, F_, L_>), dim3(blocks), dim3(8 * WAVE), lds_all, st, smp, \
-                           autoc, nsub, n, max_order, gr, c, pcm_fused, smp_out, info, la, narrow_ok ? 1 : 0, dev_sub, MultiBin{}); \
+                           autoc, nsub, n, max_order, gr, c, pcm_fused, smp_out, info, la, narrow_ok ? 1 : 0, dev_sub, MultiBin{}, gr1, split); \
     } while (0)
 #define LAUNCH_WT(N_)                                                                        \
     case N_:                                                                                 \

@@ -163,9 +163,18 @@ __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C],
                         for (int m = 0; m < OB + 7; m++)
                             if (m < OB + NT_ - 1) W[m] = (double)base[Img::off(ob - sb - NT_ + m)];
                     }
+                    // taps past the order multiply zeros (the rows are zero-padded).  Stopping the
+                    // last piece at the order (a scalar test per tap; 21 % fewer FMAs and coefficient
+                    // reads over orders 1 .. 32) measured SLOWER: configs[2]'s search 1.271 -> 1.299 ms
+                    // (round 3; the branches break up the block's schedule)
+#ifdef FHIP_FIR_TRIM64
+                    const int left = order - (tb + sb);
+#else
+                    constexpr int left = 8;
+#endif
 #pragma unroll
                     for (int jj = 0; jj < 8; jj++) {
-                        if (jj < NT_) {
+                        if (jj < NT_ && jj < left) {
                             const double cd = l.coefd[tb + sb + jj];
 #pragma unroll
                             for (int o = 0; o < OB; o++)
@@ -353,14 +362,23 @@ __device__ __forceinline__ void fir_lpc_dotn(const FastCtx<C, T> &e, int32_t (&r
 #pragma unroll
         for (int m = 0; m < H + OBW - 2; m++)
             R[m] = __builtin_bit_cast(s2, (int32_t)__builtin_amdgcn_perm((uint32_t)W[m + 1], (uint32_t)W[m], 0x05040100u));
+        // taps (2j+1, 2j+2) use x[o-2j-2], x[o-2j-1] = R at window index o + H - 2 - 2j; pairs past
+        // the order hold zeros and are skipped (a scalar test per pair)
+        int32_t acc[OBW];
 #pragma unroll
-        for (int o = 0; o < OBW; o++) {
-            // taps (2j+1, 2j+2) use x[o-2j-2], x[o-2j-1] = R at window index o + H - 2 - 2j
-            int32_t acc = 0;
+        for (int o = 0; o < OBW; o++) acc[o] = 0;
 #pragma unroll
-            for (int j = 0; j < NP; j++) acc = __builtin_amdgcn_sdot2(R[o + H - 2 - 2 * j], q[j], acc, false);
-            r[ob + o] = (int32_t)((uint32_t)W[H + o] - (uint32_t)(acc >> shift));
+        for (int j = 0; j < NP; j++) {
+#ifndef FHIP_FIR_NO_TRIM
+            if (2 * j < order)
+#endif
+            {
+#pragma unroll
+                for (int o = 0; o < OBW; o++) acc[o] = __builtin_amdgcn_sdot2(R[o + H - 2 - 2 * j], q[j], acc[o], false);
+            }
         }
+#pragma unroll
+        for (int o = 0; o < OBW; o++) r[ob + o] = (int32_t)((uint32_t)W[H + o] - (uint32_t)(acc[o] >> shift));
     }
     if (e.i0 < order) {
 #pragma unroll

@@ -179,7 +179,11 @@ __device__ __forceinline__ uint32_t wave_candidate_bits(const uint32_t *__restri
 // a 4096 or 8192 block) is 256 leaves of 2k or 4k samples: T = 256 with runs of 4k, T = 128 with
 // runs of 4k for the odd eighths of a 4096 block.
 template <int C, int T, int G>
-__global__ __launch_bounds__(T, (T <= 256) ? 4 : (T <= 512) ? 2 : 1)
+// (runs of 20 .. 28 samples at three waves per SIMD, 168 VGPRs: at four they spill up to 200 bytes per lane)
+#ifndef FHIP_SRCH_WLONG
+#define FHIP_SRCH_WLONG 3
+#endif
+__global__ __launch_bounds__(T, (T <= 256) ? (C >= 20 ? FHIP_SRCH_WLONG : 4) : (T <= 512) ? 2 : 1)
 void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                     const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                     int32_t *__restrict__ opt_all, int32_t *__restrict__ fin_all,

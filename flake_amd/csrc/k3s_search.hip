@@ -42,8 +42,15 @@ struct SrchLds {
     int32_t *misc;              // [32]: count, winner, two overflow flags, one "differs" word per wave (<= 16), ...
 };
 
+// MM (the SEARCH method's FIRs on the int8 matrix pipe, k_order_search<.., true>): three planes of
+// sample limbs (bytes, MM_HIST zeros in front), the coefficient limbs of all 32 candidate rows, four
+// per-wave heaps for the Rice search and two small tables; the leaves of the 16 candidates of a
+// pass lie over the general way's sums (16 KB).
+constexpr int MM_HIST = 32;
+__host__ __device__ constexpr int mm_plane_bytes(int n) { return n + MM_HIST + 16; }
+
 template <int G>
-__host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[12], int leaves)
+__host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[16], int leaves, int mm_n = 0)
 {
     size_t o = 0;
     // sums: G x 4 KB for the general way; leaf mode overlays G heaps of 1 KB and G x NL leaves
@@ -61,6 +68,14 @@ __host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[12
     off[9] = o; o += 4 * 32;
     off[10] = o; o += 4 * 32;
     off[11] = 0;
+    o = (o + 15) & ~(size_t)15;
+    off[12] = off[13] = off[14] = off[15] = 0;
+    if (mm_n) {
+        off[12] = o; o += 3 * (size_t)mm_plane_bytes(mm_n);      // sample limb planes
+        off[13] = o; o += 2 * 32 * 32;                          // coefficient limbs [limb][candidate][32]
+        off[14] = o; o += 4 * 128 * 8;                          // a heap per wave
+        off[15] = o; o += 4 * 64;                               // shift[32], pmin | pmax << 8 [32]
+    }
     return (o + 15) & ~(size_t)15;
 }
 
@@ -173,17 +188,133 @@ __device__ __forceinline__ uint32_t wave_candidate_bits(const uint32_t *__restri
 }
 
 
+// ---------------------------------------------------------------------------
+// The FIRs of an order SEARCH on the int8 matrix pipe (round 3; tools/mfma_i8_probe.hip priced it)
+// ---------------------------------------------------------------------------
+// pred[c][i] = sum_t coef[c][t] x[i - t] (optimize.c:95-106) for 16 candidate rows at once is a matrix
+// product, and an EXACT one on v_mfma_i32_16x16x64_i8 once both sides are cut into balanced int8
+// limbs: x = x0 + 2^8 x1 + 2^16 x2 (|x| < 2^23), c = c0 + 2^8 c1 (|c| < 2^14).  The limb products of
+// equal weight 2^(8w) share one instruction along K = 64 (chunks 0,1: c0 . x_w, taps 1..32; chunks
+// 2,3: c1 . x_{w-1}): four instructions per tile of 16 samples x 16 candidates, int32 sums below 2^21.
+// pred = lo + 2^16 hi with lo = P0 + 2^8 P1, hi = P2 + 2^8 P3 (exact in int32), and for shift <= 16
+// pred >> shift = (hi << (16 - shift)) + (lo >> shift) in the low 32 bits -- all the reference's
+// (int32)(x - (pred >> shift)) needs (optimize.c:108).
+//
+// A tile's 16 rows are the samples of equal index o in the 16 leaves (runs of 16) of a block of 256:
+// sample 16 (16 B + m) + o for row m.  Every lane of a tile then needs its 16 operand bytes at the
+// same misalignment o behind a 16-byte aligned address that does not depend on o: two aligned reads
+// per plane and BLOCK, a funnel shift by a compile-time amount per tile; and after the block's 16
+// tiles a lane holds the folded sums of its own four leaves (rows 4 g + r) for its candidate (column
+// n): no cross-lane reduction.  Lane maps (probed): A[m = l & 15][k = 16 (l >> 4) + j],
+// B[k = 16 (l >> 4) + j][n = l & 15], D[m = 4 (l >> 4) + r][n = l & 15].
+template <int C, int T>
+__device__ __forceinline__ void mm_search(const unsigned char *__restrict__ planes, const signed char *__restrict__ cl,
+                                          const int32_t *__restrict__ tab, const int32_t *__restrict__ img,
+                                          uint32_t *__restrict__ leaf, unsigned long long *__restrict__ heaps,
+                                          uint32_t *__restrict__ trial, int n, int max_order, int obits, int precision,
+                                          int tid)
+{
+    using Img = SmpImg<C, T>;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef const v4i __attribute__((address_space(3))) *lds_v4;
+    typedef const int __attribute__((address_space(3))) *lds_i;
+    constexpr int PB = mm_plane_bytes(C * T);
+    constexpr int NW = T / WAVE;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int g = lane >> 4, nn = lane & 15, h = g & 1;
+    const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)planes;
+    const unsigned xbase = (unsigned)(size_t)(const __attribute__((address_space(3))) int32_t *)img;
+
+#pragma unroll 1
+    for (int ct = 0; ct * 16 < max_order; ct++) {
+        // ---- the pass's 16 rows as B operands: weight w pairs (c0, x_w) with (c1, x_{w-1}) ----
+        v4i Bop[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int limb = g >> 1;
+            const bool on = (limb == 0) ? (w <= 2) : (w >= 1);
+            v4i v = *reinterpret_cast<const v4i *>(cl + (limb * 32 + ct * 16 + nn) * 32 + 16 * h);
+            if (!on) v = v4i{0, 0, 0, 0};
+            Bop[w] = v;
+        }
+        const int cand = ct * 16 + nn;                       // this lane's candidate: order cand + 1
+        const int sh = tab[cand], sh16 = 16 - sh, ord = cand + 1;
+#pragma unroll 1
+        for (int bq = 0; bq < 4; bq++) {
+            const int blk = wv * 4 + bq;                     // block of 16 leaves: threads 16 blk .. 16 blk + 15
+            const bool first = (blk == 0);                   // only the subframe's first block holds warm-up samples
+            uint32_t acc[4] = {0, 0, 0, 0};
+            const unsigned rowoff = (unsigned)(MM_HIST + 256 * blk + 16 * nn - 16 * (h + 1));     // 16-byte aligned
+#pragma unroll
+            for (int o4 = 0; o4 < 16; o4 += 4) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int o = o4; o < o4 + 4; o++) {
+                    v4i Aop[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const int pl = (g >> 1) == 0 ? w : w - 1;        // chunks 0,1: x_w; chunks 2,3: x_{w-1}
+                        const int plc = pl < 0 ? 0 : (pl > 2 ? 2 : pl);
+                        const unsigned ad = lbase + (unsigned)plc * PB + rowoff;
+                        const v4i R0 = *(lds_v4)(size_t)ad;
+                        v4i R1 = R0;
+                        if (o) R1 = *(lds_v4)(size_t)(ad + 16);
+                        const int W[8] = {R0.x, R0.y, R0.z, R0.w, R1.x, R1.y, R1.z, R1.w};
+                        const int aa = o >> 2, bb = o & 3;
+                        if (bb == 0) Aop[w] = v4i{W[aa], W[aa + 1], W[aa + 2], W[aa + 3]};
+                        else Aop[w] = v4i{(int)__builtin_amdgcn_alignbyte(W[aa + 1], W[aa], bb),
+                                          (int)__builtin_amdgcn_alignbyte(W[aa + 2], W[aa + 1], bb),
+                                          (int)__builtin_amdgcn_alignbyte(W[aa + 3], W[aa + 2], bb),
+                                          (int)__builtin_amdgcn_alignbyte(W[aa + 4], W[aa + 3], bb)};
+                    }
+                    // the samples of this lane's four rows: element o of the runs of threads 16 blk + 4 g + r
+                    int32_t xs[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        xs[r] = *(lds_i)(size_t)(xbase + 4u * (unsigned)((16 * blk + 4 * g + r) * 4 + Img::off(o & ~3) + (o & 3)));
+                    v4i P[4];
+#pragma unroll
+                    for (int w = 0; w < 4; w++)
+                        P[w] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aop[w], Bop[w], v4i{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int32_t lo = P[0][r] + (P[1][r] << 8), hi = P[2][r] + (P[3][r] << 8);
+                        const uint32_t q = ((uint32_t)hi << sh16) + (uint32_t)(lo >> sh);
+                        const int32_t res = (int32_t)((uint32_t)xs[r] - q);
+                        const uint32_t u = zigzag32(res);
+                        // rice.c:85-94: partition 0 of every level starts at the order
+                        if (first) acc[r] += (16 * (4 * g + r) + o < ord) ? 0u : u;
+                        else acc[r] += u;
+                    }
+                }
+            }
+            // leaves 16 blk + 4 g + r of this lane's candidate
+            *reinterpret_cast<uint4 *>(leaf + nn * T + 16 * blk + 4 * g) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+        }
+        __syncthreads();
+        // ---- rice.c:105-187 per candidate, a wave each (four per wave) ----
+        for (int m = wv; m < 16 && ct * 16 + m < max_order; m += NW) {
+            const int o1 = ct * 16 + m + 1;
+            const int pmm = tab[32 + ct * 16 + m];
+            const uint32_t b = wave_candidate_bits<T>(leaf + m * T, heaps + wv * 128, n, o1, pmm & 0xFF, pmm >> 8,
+                                                      obits, precision, lane);
+            if (lane == 0) trial[o1 - 1] = b;
+        }
+        __syncthreads();
+    }
+}
+
 // Geometries: runs of C samples (whole groups of four) in T threads, n = C * T.  The finest
 // partition sums there are -- the LEAVES -- are the 256 partitions of level 8 (T <= 256: one or
 // two per thread) or the T thread sums; every piece of a variable-block-size stream (k eighths of
 // a 4096 or 8192 block) is 256 leaves of 2k or 4k samples: T = 256 with runs of 4k, T = 128 with
 // runs of 4k for the odd eighths of a 4096 block.
-template <int C, int T, int G>
+template <int C, int T, int G, bool MM = false>
 // (runs of 20 .. 28 samples at three waves per SIMD, 168 VGPRs: at four they spill up to 200 bytes per lane)
 #ifndef FHIP_SRCH_WLONG
 #define FHIP_SRCH_WLONG 3
 #endif
-__global__ __launch_bounds__(T, (T <= 256) ? (C >= 20 ? FHIP_SRCH_WLONG : 4) : (T <= 512) ? 2 : 1)
+__global__ __launch_bounds__(T, (T <= 256) ? ((C >= 20 || MM) ? FHIP_SRCH_WLONG : 4) : (T <= 512) ? 2 : 1)
 void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                     const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                     int32_t *__restrict__ opt_all, int32_t *__restrict__ fin_all,
@@ -201,9 +332,10 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 #ifndef LOG_MERGE
 #define LOG_MERGE 1
 #endif
+    static_assert(!MM || (C == 16 && T == 256), "the matrix path: 256 leaves of 16 samples");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    size_t off[12];
-    srch_lds_layout<G>((size_t)Img::SIZE, off, NL);
+    size_t off[16];
+    srch_lds_layout<G>((size_t)Img::SIZE, off, NL, MM ? C * T : 0);
     SrchLds<G> l;
     l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
     l.wtot = reinterpret_cast<unsigned long long *>(lds_raw + off[1]);
@@ -235,6 +367,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     // ---- stage the samples (the same image k_encode_pow2 builds) ----------------------
     int magbits = -1;
     int differs;
+    bool mm_fits = false;
     {
         const int32_t *srcp = smp_all + (size_t)s * n;
         const int rflag = prep[s].reserved;                 // K0's: low byte 16-bit row, bits 8.. 1 + magbits
@@ -276,6 +409,30 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 #pragma unroll
         for (int o = 0; o < C; o++) { mx = max(mx, xn[o]); mn = min(mn, xn[o]); }
         differs = (mx != mn);
+        if constexpr (MM) {
+            // three balanced int8 limbs per sample, x = x0 + 2^8 x1 + 2^16 x2, as byte planes in sample
+            // order; the top limb holds samples from -2^23 up to 2^23 - 32897 (beyond: the vector way)
+            mm_fits = (mx <= 8355711) && (mn >= -8388608);
+            uint32_t b0[C / 4], b1[C / 4], b2[C / 4];
+#pragma unroll
+            for (int q = 0; q < C / 4; q++) { b0[q] = 0; b1[q] = 0; b2[q] = 0; }
+#pragma unroll
+            for (int o = 0; o < C; o++) {
+                const int32_t v = xn[o];
+                const int32_t x0 = (int32_t)(int8_t)v;
+                const int32_t r1 = (v - x0) >> 8;
+                const int32_t x1 = (int32_t)(int8_t)r1;
+                const int32_t x2 = (r1 - x1) >> 8;
+                b0[o >> 2] |= ((uint32_t)x0 & 0xFFu) << (8 * (o & 3));
+                b1[o >> 2] |= ((uint32_t)x1 & 0xFFu) << (8 * (o & 3));
+                b2[o >> 2] |= ((uint32_t)x2 & 0xFFu) << (8 * (o & 3));
+            }
+            unsigned char *pl = lds_raw + off[12] + MM_HIST + C * tid;
+            constexpr int PB = mm_plane_bytes(C * T);
+            *reinterpret_cast<uint4 *>(pl) = make_uint4(b0[0], b0[1], b0[2], b0[3]);
+            *reinterpret_cast<uint4 *>(pl + PB) = make_uint4(b1[0], b1[1], b1[2], b1[3]);
+            *reinterpret_cast<uint4 *>(pl + 2 * PB) = make_uint4(b2[0], b2[1], b2[2], b2[3]);
+        }
 #pragma unroll
         for (int g4 = 0; g4 < C; g4 += 4)
             *reinterpret_cast<int4 *>(l.smp + tid * 4 + Img::off(g4)) =
@@ -308,6 +465,30 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         // rounds are the steps of optimize.c:244-261, see below)
         l.misc[0] = nc;
     }
+    signed char *mm_cl = reinterpret_cast<signed char *>(lds_raw + off[13]);
+    int32_t *mm_tab = reinterpret_cast<int32_t *>(lds_raw + off[15]);
+    if constexpr (MM) {
+        // the limbs c = c0 + 2^8 c1 of every candidate row (zero past its order), 16 taps to a K
+        // chunk, bytes in the order of the samples they meet: chunk h holds taps 16 h + 16 .. 16 h + 1
+        for (int q = tid; q < 32 * 32; q += T) {
+            const int c = q >> 5, t = q & 31;                // tap t + 1 of the row of order c + 1
+            const int32_t v = (t <= c && c < max_order) ? crow_base[c * FHIP_MAX_ORDER + t] : 0;
+            const int32_t c0 = (int32_t)(int8_t)v, c1 = (v - c0) >> 8;
+            const int h = t >> 4, j = 15 - (t & 15);
+            mm_cl[(0 * 32 + c) * 32 + 16 * h + j] = (signed char)c0;
+            mm_cl[(1 * 32 + c) * 32 + 16 * h + j] = (signed char)c1;
+        }
+        if (tid < 32) {
+            mm_tab[tid] = (tid < max_order) ? srow[tid] : 0;
+            mm_tab[32 + tid] = clamp_porder(e.pmin_req, n, tid + 1) | (clamp_porder(e.pmax_req, n, tid + 1) << 8);
+        }
+        if (tid < 6) {                                       // MM_HIST zeros in front of every plane
+            unsigned char *z = lds_raw + off[12] + (tid >> 1) * mm_plane_bytes(C * T) + 16 * (tid & 1);
+            *reinterpret_cast<uint4 *>(z) = make_uint4(0, 0, 0, 0);
+        }
+        const int wave_fits = __all(mm_fits) ? 1 : 0;
+        if (lane == 0) l.misc[26 + wv] = wave_fits;
+    }
     const int wave_differs = (__ballot(differs) != 0ull) ? 1 : 0;
     if (lane == 0) l.misc[4 + wv] = wave_differs;
     __syncthreads();
@@ -316,6 +497,20 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     for (int w = 0; w < NW; w++) any_differs |= l.misc[4 + w];
     const bool constant = (__builtin_amdgcn_readfirstlane(any_differs) == 0);
     const int nc = __builtin_amdgcn_readfirstlane(l.misc[0]);
+    bool mm_done = false;
+    if constexpr (MM) {
+        int fits = 1;
+#pragma unroll
+        for (int w = 0; w < NW; w++) fits &= l.misc[26 + w];
+        // SEARCH (optimize.c:224-238) on samples the limbs hold: bits[order] of every order from the
+        // matrix pipe, 16 candidates to a pass
+        if (__builtin_amdgcn_readfirstlane(fits) && !constant && omethod == 5) {
+            mm_search<C, T>(lds_raw + off[12], mm_cl, mm_tab, l.smp, reinterpret_cast<uint32_t *>(l.sums),
+                            reinterpret_cast<unsigned long long *>(lds_raw + off[14]), l.trial, n, max_order,
+                            e.obits, e.precision, tid);
+            mm_done = true;
+        }
+    }
 
     // partition-order window over all candidates (rice.c:148-155): the highest order has the
     // tightest clamp, order 1 the loosest
@@ -334,7 +529,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         int ng;
         uint32_t lg_pack = 0;             // the round's LOG candidates, five bits each, in visiting order
         int lg_merged = 0;                // ... and the steps of optimize.c:247 they belong to
-        if (constant) break;
+        if (constant || mm_done) break;
         if (!is_log) {
             ng = min(G, nc - g0);
             if (ng <= 0) break;
@@ -685,7 +880,22 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
     int fc = 0, ft = 0;
     if (!order_search_supported(p, n) || !search_geometry(n, &fc, &ft)) return hipErrorInvalidValue;
     constexpr int G = 4;
-    size_t off[12];
+    size_t off[16];
+    // SEARCH on 4096-sample blocks: the FIRs on the int8 matrix pipe (samples beyond 24 bits, constant
+    // subframes and the other methods take the vector way inside the same kernel)
+    static const bool no_mm = getenv("FHIP_NO_MM") != nullptr;              // measurements only
+    // (16-bit samples at orders <= 16 keep the packed dot products: SEARCH 1-12 at 16 bits 0.28 ms that
+    // way, 0.43 on the matrix pipe, whose passes always cost 16 candidates x 32 taps)
+    if (!no_mm && fc == 16 && ft == 256 && p.order_method == 5 && p.bits_per_sample <= 24 &&
+        (p.bits_per_sample > 16 || p.max_prediction_order > 16)) {
+        const size_t lds = srch_lds_layout<G>((size_t)SmpImg<16, 256>::SIZE, off, 256, 4096);
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_order_search<16, 256, G, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (er != hipSuccess) return er;
+        hipLaunchKernelGGL((k_order_search<16, 256, G, true>), dim3(nsub), dim3(256), lds, st, p, n, smp, coefs,
+                           shift, opt_order, fin, prep, narrow_ok ? 1 : 0, dev_sub);
+        return hipGetLastError();
+    }
 #define LAUNCH_SRCH(CC, TT)                                                                  \
     do {                                                                                     \
         const size_t lds = srch_lds_layout<G>((size_t)SmpImg<CC, TT>::SIZE, off, TT < 256 ? 256 : TT); \

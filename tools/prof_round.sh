@@ -5,7 +5,9 @@ T=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python -m pytest tests -x -q -m gpu > gpurun_out/${T}_gputests.log 2>&1; tail -3 gpurun_out/${T}_gputests.log
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err; echo bench rc $?
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_stats -- python3 bench.py --no-cpu-baseline > gpurun_out/${T}_stats.log 2>&1; echo stats rc $?
+# the headline alone (its per-kernel averages must agree with roofline.kernel_ms), then everything else
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_stats -- python3 bench.py --no-cpu-baseline --no-other-configs > gpurun_out/${T}_stats.log 2>&1; echo stats rc $?
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_stats_other -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 5 --profile-steps 0 > gpurun_out/${T}_stats_other.log 2>&1; echo stats other rc $?
 P="--steps 3 --warmup 1 --settle-ms 0 --profile-steps 0 --no-cpu-baseline --no-other-configs"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/${T}_fetch -- python3 bench.py $P > gpurun_out/${T}_fetch.log 2>&1; echo fetch rc $?
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/${T}_write -- python3 bench.py $P > gpurun_out/${T}_write.log 2>&1; echo write rc $?

@@ -10,7 +10,9 @@ def avg(path, counter):
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] == counter: agg[r['Kernel_Name']].append(float(r['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in agg.items()}
-shutil.copy(one(f'{tag}_stats', '*kernel_stats.csv'), f'{R}/profiles/{tag}_kernel_stats.csv')
+shutil.copy(one(f'{tag}_stats', '*kernel_stats.csv'), f'{R}/profiles/{tag}_kernel_stats.csv')          # the headline alone
+try: shutil.copy(one(f'{tag}_stats_other', '*kernel_stats.csv'), f'{R}/profiles/{tag}_other_kernel_stats.csv')   # other_configs, small batches, host path
+except Exception: pass
 for suffix in ('bench.json', 'bench_g2.json', 'bench_g2_strong.json'):
     src = os.path.join(R, 'gpurun_out', f'{tag}_{suffix}')
     if os.path.exists(src) and os.path.getsize(src): shutil.copy(src, f'{R}/profiles/{tag}_{suffix}')

@@ -154,3 +154,53 @@ def test_vbs_dev_corpus_properties(oracle, decoder, level, nblocks):
     exp, esizes = oracle_stream(oracle, p, flat[:npre * n], n)
     assert (got["block_bytes"][:npre] == esizes).all()
     assert got["packed"][:exp.size].tobytes() == exp.tobytes()
+
+
+_VBS_SEEDS = int(__import__("os").environ.get("FLAKE_FUZZ_VBS_SEEDS", "24"))
+_VBS_FIRST = int(__import__("os").environ.get("FLAKE_FUZZ_FIRST", "0"))
+
+
+@pytest.mark.parametrize("seed", range(_VBS_FIRST, _VBS_FIRST + _VBS_SEEDS))
+def test_vbs_dev_random_streams(oracle, decoder, seed):
+    """Seeded sweep through the device-resident VBS entry: block sizes (multiples of 8 from 128),
+    channel counts, sample widths, prediction types, every order method, ragged order / partition
+    ranges, signal kinds with quiet stretches -- the packed stream against the oracle's
+    flake_encode_frame() loop, byte for byte, and decoded back."""
+    from cases import fuzz_params, fuzz_signal
+    r = np.random.RandomState(9000 + seed)
+    n = int(r.choice([128, 256, 512, 1000, 1024, 1152, 2048, 2304, 4096, 4096, 4608, 8192]))
+    ch = int(r.choice([1, 2, 2, 2, 3, 8]))
+    bps = int(r.choice([8, 16, 16, 16, 20, 24, 24]))
+    p = fuzz_params(r, n, ch, bps)
+    p.variable_block_size = 1
+    p.allow_vbs = 1
+    if p.prediction_type != flake_amd.PRED_FIXED and n // 8 <= p.max_prediction_order:
+        # a piece no longer than the maximum order takes the reference's FIXED branch with this minimum
+        # order; above 4 that is undefined behaviour there (optimize.c:168-173; DESIGN.md 4)
+        p.min_prediction_order = min(p.min_prediction_order, 4)
+    nblocks = 3 if n * ch > 16000 else int(r.randint(3, 9))
+    pcm = fuzz_signal(r, int(r.randint(0, 5)), nblocks, n, ch, bps).reshape(nblocks, n, ch).copy()
+    for b in range(nblocks):                          # quiet stretches of whole eighths: the splitter cuts
+        if r.rand() < 0.7:
+            a, c = sorted(int(v) for v in r.randint(0, 9, 2))
+            pcm[b, a * n // 8: c * n // 8] //= int(r.choice([8, 64, 1024]))
+    first = int(r.choice([0, 5 * n, 2 ** 21 - 8 * n]))
+    what = f"vbs seed {seed}: n={n} ch={ch} bps={bps} pred={p.prediction_type} om={p.order_method} " \
+           f"order {p.min_prediction_order}..{p.max_prediction_order} porder {p.min_partition_order}..{p.max_partition_order}"
+    got = run_dev(p, pcm, n, first=first)
+    flat = pcm.reshape(-1, ch)
+    out, esizes, fc = [], [], first
+    for b in range(nblocks):
+        rc, data, fc = oracle.encode_block(p, fc, pcm[b], n, 8 * n * ch * 4 + 4096)
+        assert rc > 0, what
+        out.append(data)
+        esizes.append(rc)
+    exp = np.concatenate(out)
+    nfr, nbytes, mx, cut = (int(v) for v in got["totals"])
+    assert cut == 0 and nbytes == exp.size, (what, nbytes, exp.size)
+    bad = np.nonzero(got["packed"][:nbytes] != exp)[0]
+    assert bad.size == 0, (what, "first differing byte", int(bad[0]) if bad.size else -1)
+    assert (got["block_bytes"] == np.array(esizes)).all(), what
+    if first == 0:
+        dec, _ = decoder.decode(got["packed"][:nbytes], ch, bps, flat.shape[0])
+        assert (dec == flat).all(), what

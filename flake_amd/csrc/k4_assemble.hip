@@ -30,16 +30,34 @@ constexpr int ASM_PREFIX_BYTES = 224;     // 8+33 header bits, 32 warm-ups of <=
 struct AsmSeg { int kind; int ch; long long nbits; long long dst; };   // kind: 0 LDS bytes, 1 rice slot, 2 verbatim samples
 
 struct MiniSink {                          // MSB-first writer into LDS bytes (serial, one thread)
+    // Fields gather in a 64-bit register and leave a byte at a time by plain byte stores (round 2 set
+    // every bit by a read-modify-write of its LDS byte: ~400 dependent LDS round trips per subframe
+    // prefix, the latency a frame's workgroup waited for).  No recursion: the compiler keeps it inline.
     uint8_t *buf; int nbits;
-    __device__ void put(int nb, uint32_t v)
+    unsigned long long acc = 0; int nacc = 0;
+    __device__ __forceinline__ void emit(int nb, uint32_t v)      // 1 <= nb <= 32
     {
-        for (int b = nb - 1; b >= 0; b--) {
-            const int pos = nbits++;
-            const uint32_t bit = (b < 32) ? ((v >> b) & 1u) : 0u;   // fields wider than 32 bits are zero-extended
-            if ((pos & 7) == 0) buf[pos >> 3] = 0;
-            buf[pos >> 3] |= (uint8_t)(bit << (7 - (pos & 7)));
+        const uint32_t m = (nb == 32) ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+        acc = (acc << nb) | (unsigned long long)(v & m);
+        nacc += nb;
+#pragma unroll
+        for (int z = 0; z < 5; z++) {
+            if (nacc >= 8) {
+                nacc -= 8;
+                buf[nbits >> 3] = (uint8_t)(acc >> nacc);
+                nbits += 8;
+            }
         }
+        // the pending bits, left-aligned, as the (partial) last byte: readers see a complete byte image
+        buf[nbits >> 3] = (uint8_t)((acc << (8 - nacc)) & 0xFFu);
     }
+    __device__ __forceinline__ void put(int nb, uint32_t v)
+    {
+        if (nb <= 0) return;
+        if (nb > 32) { emit(nb - 32, 0u); nb = 32; }               // fields wider than 32 bits are zero-extended
+        emit(nb, v);
+    }
+    __device__ __forceinline__ int bits() const { return nbits + nacc; }
 };
 
 __device__ __forceinline__ uint16_t crc16_mulmod(uint16_t a, uint16_t b)
@@ -53,6 +71,35 @@ __device__ __forceinline__ uint16_t crc16_mulmod(uint16_t a, uint16_t b)
         if ((b >> i) & 1u) r ^= a;
     }
     return (uint16_t)r;
+}
+
+// x^(8 * 2^i) mod P, i = 0 .. 23 (compile-time: repeated squaring of x^8)
+constexpr uint16_t crc16_mulmod_c(uint16_t a, uint16_t b)
+{
+    uint32_t r = 0;
+    for (int i = 15; i >= 0; i--) {
+        r <<= 1;
+        if (r & 0x10000u) r ^= 0x18005u;
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return (uint16_t)r;
+}
+struct Crc16Pow { uint16_t v[24]; };
+constexpr Crc16Pow crc16_pow_table()
+{
+    Crc16Pow t{};
+    uint16_t p = 0x100;
+    for (int i = 0; i < 24; i++) { t.v[i] = p; p = crc16_mulmod_c(p, p); }
+    return t;
+}
+__device__ __forceinline__ uint16_t crc16_pow8(int i)
+{
+    constexpr Crc16Pow t = crc16_pow_table();
+    // (a wave-uniform index into 24 constants: a select chain, no memory)
+    uint16_t r = t.v[0];
+#pragma unroll
+    for (int q = 1; q < 24; q++) r = (i == q) ? t.v[q] : r;
+    return r;
 }
 
 __device__ __forceinline__ int32_t asm_sample(const int32_t *pcm_frame, int nch, int ch, int t,
@@ -103,7 +150,6 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
     __shared__ int s_nseg, s_verbatim, s_hdr_bits;
     __shared__ long long s_total_bits;
     __shared__ uint16_t s_crc_tab[256];
-    __shared__ uint16_t s_part[NT];
     __shared__ int s_info[FHIP_MAX_CH][8];       // type, type_code, order, shift, obits, wasted, rice_nbits, ch_mode
 
     const int tid = threadIdx.x;
@@ -156,14 +202,14 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
         if (bs1 >= 0) hs.put(bs1 < 256 ? 8 : 16, (uint32_t)bs1);
         if (sr_code1 > 0) hs.put(sr_code1 < 256 ? 8 : 16, (uint32_t)sr_code1);
         uint8_t c8 = 0;
-        for (int q = 0; q < (hs.nbits >> 3); q++) {
+        for (int q = 0; q < (hs.bits() >> 3); q++) {
             c8 ^= s_hdr[q];
             for (int b = 0; b < 8; b++) c8 = (uint8_t)((c8 & 0x80) ? ((c8 << 1) ^ 0x07) : (c8 << 1));
         }
         hs.put(8, c8);
-        s_hdr_bits = hs.nbits;
+        s_hdr_bits = hs.bits();
 
-        long long bits = hs.nbits;
+        long long bits = hs.bits();
         int verb = 0;
         for (int c = 0; c < nch; c++) {
             const int type = s_info[c][0], order = s_info[c][2], obits = s_info[c][4];
@@ -207,7 +253,7 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
             }
         }
         s_info[tid][0] = type;
-        s_info[tid][3] = ps.nbits;              // reuse: prefix length
+        s_info[tid][3] = ps.bits();             // reuse: prefix length
     }
     __syncthreads();
     if (tid == 0) {
@@ -238,8 +284,14 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
     for (int w = tid; w < nwords; w += NT) {
         const long long w0 = (long long)w * 32, w1 = w0 + 32;
         uint32_t word = 0;
-        for (int q = 0; q < nseg; q++) {
+        // the segments lie back to back in ascending order: skip those that end at or before this
+        // word (one 8-byte LDS read each), stop at the first that starts behind it -- most words lie
+        // inside one long residual section
+        int q0 = 0;
+        while (q0 < nseg - 1 && s_seg[q0 + 1].dst <= w0) q0++;
+        for (int q = q0; q < nseg; q++) {
             const AsmSeg sg = s_seg[q];
+            if (sg.dst >= w1) break;
             const long long a = max(sg.dst, w0), b = min(sg.dst + sg.nbits, w1);
             if (a >= b) continue;
             const int cnt = (int)(b - a);
@@ -289,50 +341,41 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
     }
     __syncthreads();                       // the frame body is in memory (same CU)
 
-    // ---- CRC-16 (crc.c:59-94) in parallel -------------------------------------
-    // chunk c covers message bytes [c*L - pad, (c+1)*L - pad): the message is
-    // thought of as left-padded with zero bytes, which leaves a CRC with initial
-    // value 0 unchanged.
-    const int L = (body_bytes + NT - 1) / NT;
-    const int pad = L * NT - body_bytes;
+    // ---- CRC-16 (crc.c:59-94): ONE wave, 64 chunks, merged by shuffles -----------
+    // (round 3.  Round 2 gave every thread a chunk and merged 256 partial CRCs through LDS: a
+    // square-and-multiply for x^(8L) and eight barrier-separated steps with two 16-step GF(2)
+    // products each -- ~2600 of the kernel's ~6000 instructions per wave, on all four waves, for
+    // a frame of a few KB.)  Lane i >= 1 takes the L bytes that end (63 - i) L bytes before the
+    // body's end, L the smallest power of two with 64 L >= body; lane 0 takes what is in front
+    // (lanes whose range lies before the body are empty: crc 0).  crc(A || B) = crc(A) x^(8 |B|) +
+    // crc(B) only asks for the RIGHT part's length, so every merge constant is x^(8 L 2^j) mod P, a
+    // compile-time table entry.
+    if (tid >= WAVE) return;
     {
+        int k = 2;
+        while ((64 << k) < body_bytes) k++;
+        const int L = 1 << k;
+        const int e = body_bytes - (63 - tid) * L;             // end of this lane's chunk
+        const int s0 = max(e - L, 0);
         uint16_t c = 0;
-        const int b0 = tid * L - pad;
-        for (int q = 0; q < L; q++) {
-            const int bi = b0 + q;
-            if (bi >= 0) {
-                // the bytes were stored by other lanes of this workgroup: read past L1
-                const uint32_t wv = __hip_atomic_load(&out32[bi >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t byte = (wv >> (8 * (bi & 3))) & 0xFFu;
-                c = (uint16_t)((c << 8) ^ s_crc_tab[((c >> 8) ^ byte) & 0xFFu]);
-            }
+        uint32_t wv = 0;
+        for (int bi = s0; bi < e; bi++) {
+            // the bytes were stored by other lanes of this workgroup: read past L1
+            if (bi == s0 || (bi & 3) == 0) wv = __hip_atomic_load(&out32[bi >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t byte = (wv >> (8 * (bi & 3))) & 0xFFu;
+            c = (uint16_t)((c << 8) ^ s_crc_tab[((c >> 8) ^ byte) & 0xFFu]);
         }
-        s_part[tid] = c;
-    }
-    // m = x^(8L) mod P by square-and-multiply on x^8
-    uint16_t m;
-    {
-        uint16_t base = 0x100, r = 1;
-        int ex = L;
-        while (ex) { if (ex & 1) r = crc16_mulmod(r, base); base = crc16_mulmod(base, base); ex >>= 1; }
-        m = r;
-    }
-    __syncthreads();
-    for (int step = 1; step < NT; step <<= 1) {
-        // left node (tid) absorbs its right neighbour: crc(A||B) = crc(A)*x^(8|B|) + crc(B)
-        uint16_t v = 0;
-        const bool act = (tid % (2 * step)) == 0;
-        if (act) v = (uint16_t)(crc16_mulmod(s_part[tid], m) ^ s_part[tid + step]);
-        __syncthreads();
-        if (act) s_part[tid] = v;
-        __syncthreads();
-        m = crc16_mulmod(m, m);
-    }
-    if (tid == 0) {
-        const uint16_t crc = s_part[0];
-        out[body_bytes] = (uint8_t)(crc >> 8);
-        out[body_bytes + 1] = (uint8_t)crc;
-        frame_bytes[f] = body_bytes + 2;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            // lanes = 0 mod 2^(j+1) absorb the node 2^j lanes to their right (2^j chunks of L bytes)
+            const uint16_t right = (uint16_t)__shfl_down((int)c, 1 << j, WAVE);
+            c = (uint16_t)(crc16_mulmod(c, crc16_pow8(k + j)) ^ right);
+        }
+        if (tid == 0) {
+            out[body_bytes] = (uint8_t)(c >> 8);
+            out[body_bytes + 1] = (uint8_t)c;
+            frame_bytes[f] = body_bytes + 2;
+        }
     }
 }
 

@@ -31,7 +31,8 @@ struct SrchLds {
     unsigned long long *sums;   // [G][512] heap order per candidate slot; in leaf mode G per-wave heaps of 128
                                 // and behind them the G x T thread sums as 32-bit leaves
     unsigned long long *wtot;   // [G][16]  per-wave totals
-    double *coefd;              // [G][32]  candidate rows as doubles, zero past the order
+    double *coefd;              // [G][SRCH_CROW] candidate rows as doubles, zero past the order -- and past 32:
+                                // fir_lpc's tap blocks of 20 / 28 (runs of 20, 28) read up to tap 36
     int32_t *smp;               // SmpImg<C, T>
     uint32_t *lvl_bits;         // [2][G][12] (double-buffered by round parity)
     uint32_t *lvl_meth;         // [2][G]
@@ -44,8 +45,9 @@ struct SrchLds {
 
 // MM (the SEARCH method's FIRs on the int8 matrix pipe, k_order_search<.., true>): three planes of
 // sample limbs (bytes, MM_HIST zeros in front), the coefficient limbs of all 32 candidate rows, four
-// per-wave heaps for the Rice search and two small tables; the leaves of the 16 candidates of a
-// pass lie over the general way's sums (16 KB).
+// a heap per wave for the Rice search and two small tables; the leaves of the 16 candidates of a
+// pass lie over the general way's sums (16 KB; 32 KB with 512 leaves).
+constexpr int SRCH_CROW = 40;          // doubles per candidate row in LDS
 constexpr int MM_HIST = 32;
 __host__ __device__ constexpr int mm_plane_bytes(int n) { return n + MM_HIST + 16; }
 
@@ -55,9 +57,11 @@ __host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[16
     size_t o = 0;
     // sums: G x 4 KB for the general way; leaf mode overlays G heaps of 1 KB and G x NL leaves
     const size_t general = 8 * 512 * (size_t)G, leafy = 8 * 128 * (size_t)G + 4 * (size_t)G * (size_t)leaves;
-    off[0] = o; o += general > leafy ? general : leafy;
+    const size_t mm_leaves = mm_n ? 4 * 16 * (size_t)leaves : 0;      // the 16 candidates of a matrix pass
+    const size_t s0 = general > leafy ? general : leafy;
+    off[0] = o; o += s0 > mm_leaves ? s0 : mm_leaves;
     off[1] = o; o += 8 * 16 * G;
-    off[2] = o; o += 8 * 32 * G;
+    off[2] = o; o += 8 * SRCH_CROW * G;
     off[3] = o; o += 4 * img_ints;
     o = (o + 15) & ~(size_t)15;
     off[4] = o; o += 4 * 2 * G * 12;
@@ -73,7 +77,7 @@ __host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[16
     if (mm_n) {
         off[12] = o; o += 3 * (size_t)mm_plane_bytes(mm_n);      // sample limb planes
         off[13] = o; o += 2 * 32 * 32;                          // coefficient limbs [limb][candidate][32]
-        off[14] = o; o += 4 * 128 * 8;                          // a heap per wave
+        off[14] = o; o += (size_t)(leaves / 64) * 128 * 8;       // a heap per wave
         off[15] = o; o += 4 * 64;                               // shift[32], pmin | pmax << 8 [32]
     }
     return (o + 15) & ~(size_t)15;
@@ -212,11 +216,13 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
                                           const int32_t *__restrict__ tab, const int32_t *__restrict__ img,
                                           uint32_t *__restrict__ leaf, unsigned long long *__restrict__ heaps,
                                           uint32_t *__restrict__ trial, int n, int max_order, int obits, int precision,
-                                          int tid)
+                                          int tid, int ct0)
 {
     using Img = SmpImg<C, T>;
     typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v2i __attribute__((ext_vector_type(2)));
     typedef const v4i __attribute__((address_space(3))) *lds_v4;
+    typedef const v2i __attribute__((address_space(3))) *lds_v2;
     typedef const int __attribute__((address_space(3))) *lds_i;
     constexpr int PB = mm_plane_bytes(C * T);
     constexpr int NW = T / WAVE;
@@ -226,7 +232,7 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
     const unsigned xbase = (unsigned)(size_t)(const __attribute__((address_space(3))) int32_t *)img;
 
 #pragma unroll 1
-    for (int ct = 0; ct * 16 < max_order; ct++) {
+    for (int ct = ct0; ct * 16 < max_order; ct++) {
         // ---- the pass's 16 rows as B operands: weight w pairs (c0, x_w) with (c1, x_{w-1}) ----
         v4i Bop[4];
 #pragma unroll
@@ -244,55 +250,86 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
             const int blk = wv * 4 + bq;                     // block of 16 leaves: threads 16 blk .. 16 blk + 15
             const bool first = (blk == 0);                   // only the subframe's first block holds warm-up samples
             uint32_t acc[4] = {0, 0, 0, 0};
-            const unsigned rowoff = (unsigned)(MM_HIST + 256 * blk + 16 * nn - 16 * (h + 1));     // 16-byte aligned
+            // this lane's operand bytes of tile o: 16 bytes from byte rowoff + o of its plane -- a dword-aligned
+            // start (C is a multiple of four), so the misalignment of a tile is the compile-time o & 3
+            const unsigned rowoff = (unsigned)(MM_HIST + C * (16 * blk + nn) - 16 * (h + 1));
+            unsigned ad[4];
 #pragma unroll
-            for (int o4 = 0; o4 < 16; o4 += 4) {
-                __builtin_amdgcn_sched_barrier(0);
+            for (int w = 0; w < 4; w++) {
+                const int pl = (g >> 1) == 0 ? w : w - 1;        // chunks 0,1: x_w; chunks 2,3: x_{w-1}
+                const int plc = pl < 0 ? 0 : (pl > 2 ? 2 : pl);
+                ad[w] = lbase + (unsigned)plc * PB + rowoff;
+            }
+            // up to 16 tiles at a time: their windows are NT + 15 bytes behind ad + OC, read once
+            auto chunk = [&](auto oc_c) {
+                constexpr int OC = decltype(oc_c)::value;
+                constexpr int NT = (C - OC < 16) ? C - OC : 16;
+                constexpr int ND = NT / 4 + 4;
+                int Wd[4][ND];
 #pragma unroll
-                for (int o = o4; o < o4 + 4; o++) {
-                    v4i Aop[4];
+                for (int w = 0; w < 4; w++) {
+                    if constexpr (C % 16 == 0) {
 #pragma unroll
-                    for (int w = 0; w < 4; w++) {
-                        const int pl = (g >> 1) == 0 ? w : w - 1;        // chunks 0,1: x_w; chunks 2,3: x_{w-1}
-                        const int plc = pl < 0 ? 0 : (pl > 2 ? 2 : pl);
-                        const unsigned ad = lbase + (unsigned)plc * PB + rowoff;
-                        const v4i R0 = *(lds_v4)(size_t)ad;
-                        v4i R1 = R0;
-                        if (o) R1 = *(lds_v4)(size_t)(ad + 16);
-                        const int W[8] = {R0.x, R0.y, R0.z, R0.w, R1.x, R1.y, R1.z, R1.w};
-                        const int aa = o >> 2, bb = o & 3;
-                        if (bb == 0) Aop[w] = v4i{W[aa], W[aa + 1], W[aa + 2], W[aa + 3]};
-                        else Aop[w] = v4i{(int)__builtin_amdgcn_alignbyte(W[aa + 1], W[aa], bb),
-                                          (int)__builtin_amdgcn_alignbyte(W[aa + 2], W[aa + 1], bb),
-                                          (int)__builtin_amdgcn_alignbyte(W[aa + 3], W[aa + 2], bb),
-                                          (int)__builtin_amdgcn_alignbyte(W[aa + 4], W[aa + 3], bb)};
-                    }
-                    // the samples of this lane's four rows: element o of the runs of threads 16 blk + 4 g + r
-                    int32_t xs[4];
+                        for (int q = 0; q < ND; q += 4) {
+                            const v4i R = *(lds_v4)(size_t)(ad[w] + OC + 4 * q);
+                            Wd[w][q] = R.x; Wd[w][q + 1] = R.y; Wd[w][q + 2] = R.z; Wd[w][q + 3] = R.w;
+                        }
+                    } else if constexpr (C % 8 == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        xs[r] = *(lds_i)(size_t)(xbase + 4u * (unsigned)((16 * blk + 4 * g + r) * 4 + Img::off(o & ~3) + (o & 3)));
-                    v4i P[4];
+                        for (int q = 0; q < ND; q += 2) {
+                            const v2i R = *(lds_v2)(size_t)(ad[w] + OC + 4 * q);
+                            Wd[w][q] = R.x; Wd[w][q + 1] = R.y;
+                        }
+                    } else {
 #pragma unroll
-                    for (int w = 0; w < 4; w++)
-                        P[w] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aop[w], Bop[w], v4i{0, 0, 0, 0}, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int32_t lo = P[0][r] + (P[1][r] << 8), hi = P[2][r] + (P[3][r] << 8);
-                        const uint32_t q = ((uint32_t)hi << sh16) + (uint32_t)(lo >> sh);
-                        const int32_t res = (int32_t)((uint32_t)xs[r] - q);
-                        const uint32_t u = zigzag32(res);
-                        // rice.c:85-94: partition 0 of every level starts at the order
-                        if (first) acc[r] += (16 * (4 * g + r) + o < ord) ? 0u : u;
-                        else acc[r] += u;
+                        for (int q = 0; q < ND; q++) Wd[w][q] = *(lds_i)(size_t)(ad[w] + OC + 4 * q);
                     }
                 }
-            }
+#pragma unroll
+                for (int o4 = 0; o4 < NT; o4 += 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int oo = o4; oo < o4 + 4; oo++) {
+                        const int o = OC + oo;
+                        const int aa = oo >> 2, bb = oo & 3;
+                        v4i Aop[4];
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            if (bb == 0) Aop[w] = v4i{Wd[w][aa], Wd[w][aa + 1], Wd[w][aa + 2], Wd[w][aa + 3]};
+                            else Aop[w] = v4i{(int)__builtin_amdgcn_alignbyte(Wd[w][aa + 1], Wd[w][aa], bb),
+                                              (int)__builtin_amdgcn_alignbyte(Wd[w][aa + 2], Wd[w][aa + 1], bb),
+                                              (int)__builtin_amdgcn_alignbyte(Wd[w][aa + 3], Wd[w][aa + 2], bb),
+                                              (int)__builtin_amdgcn_alignbyte(Wd[w][aa + 4], Wd[w][aa + 3], bb)};
+                        }
+                        // the samples of this lane's four rows: element o of the runs of threads 16 blk + 4 g + r
+                        int32_t xs[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            xs[r] = *(lds_i)(size_t)(xbase + 4u * (unsigned)((16 * blk + 4 * g + r) * 4 + Img::off(o & ~3) + (o & 3)));
+                        v4i P[4];
+#pragma unroll
+                        for (int w = 0; w < 4; w++)
+                            P[w] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aop[w], Bop[w], v4i{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int32_t lo = P[0][r] + (P[1][r] << 8), hi = P[2][r] + (P[3][r] << 8);
+                            const uint32_t q = ((uint32_t)hi << sh16) + (uint32_t)(lo >> sh);
+                            const int32_t res = (int32_t)((uint32_t)xs[r] - q);
+                            const uint32_t u = zigzag32(res);
+                            // rice.c:85-94: partition 0 of every level starts at the order
+                            if (first) acc[r] += (C * (4 * g + r) + o < ord) ? 0u : u;
+                            else acc[r] += u;
+                        }
+                    }
+                }
+            };
+            chunk(std::integral_constant<int, 0>{});
+            if constexpr (C > 16) chunk(std::integral_constant<int, 16>{});
             // leaves 16 blk + 4 g + r of this lane's candidate
             *reinterpret_cast<uint4 *>(leaf + nn * T + 16 * blk + 4 * g) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
         }
         __syncthreads();
-        // ---- rice.c:105-187 per candidate, a wave each (four per wave) ----
+        // ---- rice.c:105-187 per candidate, a wave each ----
         for (int m = wv; m < 16 && ct * 16 + m < max_order; m += NW) {
             const int o1 = ct * 16 + m + 1;
             const int pmm = tab[32 + ct * 16 + m];
@@ -309,12 +346,16 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
 // two per thread) or the T thread sums; every piece of a variable-block-size stream (k eighths of
 // a 4096 or 8192 block) is 256 leaves of 2k or 4k samples: T = 256 with runs of 4k, T = 128 with
 // runs of 4k for the odd eighths of a 4096 block.
+#ifndef FHIP_MM_NO_HYBRID
+#define FHIP_MM_NO_HYBRID 0
+#endif
 template <int C, int T, int G, bool MM = false>
 // (runs of 20 .. 28 samples at three waves per SIMD, 168 VGPRs: at four they spill up to 200 bytes per lane)
 #ifndef FHIP_SRCH_WLONG
 #define FHIP_SRCH_WLONG 3
 #endif
-__global__ __launch_bounds__(T, (T <= 256) ? ((C >= 20 || MM) ? FHIP_SRCH_WLONG : 4) : (T <= 512) ? 2 : 1)
+// (the matrix instances of runs >= 20 hold two workgroups per CU by their LDS -- image, limb planes, leaves: 59-72 KB)
+__global__ __launch_bounds__(T, (T <= 256) ? ((MM && C >= 20) ? 2 : (C >= 20 || MM) ? FHIP_SRCH_WLONG : 4) : (T <= 512) ? 2 : 1)
 void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                     const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                     int32_t *__restrict__ opt_all, int32_t *__restrict__ fin_all,
@@ -332,7 +373,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 #ifndef LOG_MERGE
 #define LOG_MERGE 1
 #endif
-    static_assert(!MM || (C == 16 && T == 256), "the matrix path: 256 leaves of 16 samples");
+    static_assert(!MM || (T >= 256 && C <= 32), "the matrix path: one leaf per thread, runs of up to 32");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     size_t off[16];
     srch_lds_layout<G>((size_t)Img::SIZE, off, NL, MM ? C * T : 0);
@@ -429,9 +470,28 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             }
             unsigned char *pl = lds_raw + off[12] + MM_HIST + C * tid;
             constexpr int PB = mm_plane_bytes(C * T);
-            *reinterpret_cast<uint4 *>(pl) = make_uint4(b0[0], b0[1], b0[2], b0[3]);
-            *reinterpret_cast<uint4 *>(pl + PB) = make_uint4(b1[0], b1[1], b1[2], b1[3]);
-            *reinterpret_cast<uint4 *>(pl + 2 * PB) = make_uint4(b2[0], b2[1], b2[2], b2[3]);
+            if constexpr (C % 16 == 0) {
+#pragma unroll
+                for (int q = 0; q < C / 4; q += 4) {
+                    *reinterpret_cast<uint4 *>(pl + 4 * q) = make_uint4(b0[q], b0[q + 1], b0[q + 2], b0[q + 3]);
+                    *reinterpret_cast<uint4 *>(pl + PB + 4 * q) = make_uint4(b1[q], b1[q + 1], b1[q + 2], b1[q + 3]);
+                    *reinterpret_cast<uint4 *>(pl + 2 * PB + 4 * q) = make_uint4(b2[q], b2[q + 1], b2[q + 2], b2[q + 3]);
+                }
+            } else if constexpr (C % 8 == 0) {
+#pragma unroll
+                for (int q = 0; q < C / 4; q += 2) {
+                    *reinterpret_cast<uint2 *>(pl + 4 * q) = make_uint2(b0[q], b0[q + 1]);
+                    *reinterpret_cast<uint2 *>(pl + PB + 4 * q) = make_uint2(b1[q], b1[q + 1]);
+                    *reinterpret_cast<uint2 *>(pl + 2 * PB + 4 * q) = make_uint2(b2[q], b2[q + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < C / 4; q++) {
+                    *reinterpret_cast<uint32_t *>(pl + 4 * q) = b0[q];
+                    *reinterpret_cast<uint32_t *>(pl + PB + 4 * q) = b1[q];
+                    *reinterpret_cast<uint32_t *>(pl + 2 * PB + 4 * q) = b2[q];
+                }
+            }
         }
 #pragma unroll
         for (int g4 = 0; g4 < C; g4 += 4)
@@ -496,7 +556,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 #pragma unroll
     for (int w = 0; w < NW; w++) any_differs |= l.misc[4 + w];
     const bool constant = (__builtin_amdgcn_readfirstlane(any_differs) == 0);
-    const int nc = __builtin_amdgcn_readfirstlane(l.misc[0]);
+    int nc = __builtin_amdgcn_readfirstlane(l.misc[0]);
     bool mm_done = false;
     if constexpr (MM) {
         int fits = 1;
@@ -505,10 +565,16 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         // SEARCH (optimize.c:224-238) on samples the limbs hold: bits[order] of every order from the
         // matrix pipe, 16 candidates to a pass
         if (__builtin_amdgcn_readfirstlane(fits) && !constant && omethod == 5) {
+            // 16-bit samples (K0 knows their magnitude): orders 1..16 keep the packed dot products of the
+            // rounds below -- at most eight per sample, cheaper than a matrix pass's epilogue -- and the
+            // matrix pipe takes the orders above, where the vector way is an fp64 FMA per tap
+            const int mb = __builtin_amdgcn_readfirstlane(magbits);
+            const int ct0 = (mb >= 0 && mb <= 15 && max_order > 16 && !FHIP_MM_NO_HYBRID) ? 1 : 0;
             mm_search<C, T>(lds_raw + off[12], mm_cl, mm_tab, l.smp, reinterpret_cast<uint32_t *>(l.sums),
                             reinterpret_cast<unsigned long long *>(lds_raw + off[14]), l.trial, n, max_order,
-                            e.obits, e.precision, tid);
-            mm_done = true;
+                            e.obits, e.precision, tid, ct0);
+            if (ct0 == 0) mm_done = true;
+            else nc = min(nc, 16 * ct0);
         }
     }
 
@@ -573,7 +639,8 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             const int cand = (g >= ng) ? 0 : is_log ? (int)((lg_pack >> (5 * g)) & 31u) : l.list[g0 + g];
             const int ord = cand + 1;
             const int32_t cv = (g < ng && j < ord) ? crow_base[cand * FHIP_MAX_ORDER + j] : 0;
-            l.coefd[g * 32 + j] = (double)cv;
+            l.coefd[g * SRCH_CROW + j] = (double)cv;
+            if (j < SRCH_CROW - 32) l.coefd[g * SRCH_CROW + 32 + j] = 0.0;
             const int32_t nb = __shfl_xor(cv, 1, WAVE);
             if (j < 16 && (j & 1) == 0) l.pairs[g * 8 + (j >> 1)] = (nb & 0xFFFF) | (cv << 16);
             int32_t sa = cv < 0 ? -cv : cv;
@@ -616,7 +683,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             {
             int32_t r[C];
             FastCtx<C, T> eg = e;
-            eg.l.coefd = l.coefd + g * 32;
+            eg.l.coefd = l.coefd + g * SRCH_CROW;
 #if defined(FHIP_SRCH_PROBE) && FHIP_SRCH_PROBE == 1      // timing probe: no FIR
 #pragma unroll
             for (int o = 0; o < C; o++) r[o] = l.smp[tid * 4 + Img::off(o)] + cshift;
@@ -886,15 +953,30 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
     static const bool no_mm = getenv("FHIP_NO_MM") != nullptr;              // measurements only
     // (16-bit samples at orders <= 16 keep the packed dot products: SEARCH 1-12 at 16 bits 0.28 ms that
     // way, 0.43 on the matrix pipe, whose passes always cost 16 candidates x 32 taps)
-    if (!no_mm && fc == 16 && ft == 256 && p.order_method == 5 && p.bits_per_sample <= 24 &&
+    if (!no_mm && ft >= 256 && p.order_method == 5 && p.bits_per_sample <= 24 &&
         (p.bits_per_sample > 16 || p.max_prediction_order > 16)) {
-        const size_t lds = srch_lds_layout<G>((size_t)SmpImg<16, 256>::SIZE, off, 256, 4096);
-        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_order_search<16, 256, G, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (er != hipSuccess) return er;
-        hipLaunchKernelGGL((k_order_search<16, 256, G, true>), dim3(nsub), dim3(256), lds, st, p, n, smp, coefs,
-                           shift, opt_order, fin, prep, narrow_ok ? 1 : 0, dev_sub);
-        return hipGetLastError();
+#define LAUNCH_MM(CC, TT)                                                                    \
+    do {                                                                                     \
+        const size_t lds = srch_lds_layout<G>((size_t)SmpImg<CC, TT>::SIZE, off, TT, CC * TT); \
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_order_search<CC, TT, G, true>), \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (er != hipSuccess) return er;                                                     \
+        hipLaunchKernelGGL((k_order_search<CC, TT, G, true>), dim3(nsub), dim3(TT), lds, st, p, n, smp, coefs, \
+                           shift, opt_order, fin, prep, narrow_ok ? 1 : 0, dev_sub);         \
+        return hipGetLastError();                                                            \
+    } while (0)
+        switch (fc * 10000 + ft) {
+        case 160256: LAUNCH_MM(16, 256);
+        case 160512: LAUNCH_MM(16, 512);
+        case 40256: LAUNCH_MM(4, 256);
+        case 80256: LAUNCH_MM(8, 256);
+        case 120256: LAUNCH_MM(12, 256);
+        case 200256: LAUNCH_MM(20, 256);
+        case 240256: LAUNCH_MM(24, 256);
+        case 280256: LAUNCH_MM(28, 256);
+        default: break;                                      // (n = 16384, the T = 128 pieces: the vector way)
+        }
+#undef LAUNCH_MM
     }
 #define LAUNCH_SRCH(CC, TT)                                                                  \
     do {                                                                                     \

@@ -536,3 +536,36 @@ def test_order_search_kernel(oracle, n, om, mo):
         pcm[3, 3] = full - 1
         pcm[4, :, 1] = pcm[4, :, 0] >> 1
         check(oracle, p, pcm.astype(np.int32), n, f"order search n={n} om={om} mo={mo} bps={bps}")
+
+
+def _many_tones(nframes, n, ch, bps, seed):
+    """Fifteen sinusoids and a little noise: prediction keeps gaining up to order ~30, so the
+    order searches end on the highest orders."""
+    r = np.random.RandomState(seed)
+    t = np.arange(nframes * n, dtype=np.float64)
+    x = np.zeros((nframes * n, ch))
+    for c in range(ch):
+        for _ in range(15):
+            x[:, c] += r.uniform(0.3, 1.0) * np.sin(t * r.uniform(0.02, 3.0) + r.uniform(0, 6.28))
+    x *= (1 << (bps - 1)) / 16.0
+    x += r.uniform(-2, 2, x.shape)
+    return np.round(x).astype(np.int32).reshape(nframes, n, ch)
+
+
+@pytest.mark.parametrize("n", [4096, 8192, 2560, 3584, 5120, 6144, 7168, 1024])
+@pytest.mark.parametrize("om,lo,hi,pmin", [(flake_amd.OM_SEARCH, 1, 32, 0), (flake_amd.OM_8LEVEL, 10, 29, 8),
+                                            (flake_amd.OM_4LEVEL, 10, 29, 8), (flake_amd.OM_8LEVEL, 3, 32, 0),
+                                            (flake_amd.OM_LOG, 1, 32, 0), (flake_amd.OM_SEARCH, 20, 31, 7)])
+def test_order_search_high_orders(oracle, n, om, lo, hi, pmin):
+    """The order searches where the HIGH orders win (a signal of many tones): every run length's FIR at
+    taps 29 .. 32, partition-order windows clamped below the leaves' level (n / order < 2^8), ragged
+    order ranges.  (Round 3 fuzz, seed 3000359: runs of 20 / 28 read candidate rows past tap 32.)"""
+    top = 0
+    for bps in (24, 16):
+        p = flake_amd.level_params(5, bits_per_sample=bps, block_size=n, order_method=om,
+                                   min_prediction_order=lo, max_prediction_order=hi,
+                                   min_partition_order=pmin, max_partition_order=8)
+        pcm = _many_tones(3, n, 2, bps, n + hi + bps)
+        _, exp = check(oracle, p, pcm, n, f"high orders n={n} om={om} {lo}..{hi} pmin={pmin} bps={bps}")
+        top = max(top, int(exp["info"]["order"].max()))
+    assert top >= min(hi, 27), top              # the case did reach up there

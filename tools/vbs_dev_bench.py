@@ -8,7 +8,7 @@ import numpy as np, torch, flake_amd
 nblk = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda", 0)
-for level in (9, 10, 12):
+for level in [int(v) for v in os.environ.get("VBS_LEVELS", "9,10,12").split(",")]:
     p = flake_amd.level_params(level)
     n = p.block_size
     pcm = flake_amd.synth_pcm(nblk, n, 2, 16)

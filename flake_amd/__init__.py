@@ -166,6 +166,7 @@ def load_library() -> C.CDLL:
         "fhip_encode_blocks_vbs_dev": (i, [vp, vp, i, i, C.c_uint32, C.POINTER(VbsOut)]),
         "fhip_lpc_calc_coefs": (i, [vp, vp, i, i, i, i, i, vp, vp, vp, vp]),
         "fhip_encode_residual": (i, [vp, vp, i, i, vp, vp, vp, i64]),
+        "fhip_order_search_bits": (i, [vp, vp, i, i, vp, vp]),
         "fhip_prepare_frames": (i, [vp, vp, i, i, vp, vp]),
         "fhip_calc_rice_params": (i, [vp, vp, i, i, i, i, i, i, i, vp, vp, i64]),
         "fhip_vbs_split": (i, [vp, vp, i, i, vp, vp]),
@@ -188,7 +189,7 @@ ABI_SYMBOLS = (
     "fhip_prepare_frames", "fhip_calc_rice_params", "fhip_vbs_split", "fhip_set_profiling",
     "fhip_get_kernel_times", "fhip_prepare_ahead", "fhip_encode_frames_packed",
     "fhip_frames_packed_begin", "fhip_frames_packed_fetch", "fhip_encode_blocks_vbs_packed",
-    "fhip_encode_blocks_vbs_dev",
+    "fhip_encode_blocks_vbs_dev", "fhip_order_search_bits",
 )
 
 
@@ -355,6 +356,21 @@ class Encoder:
             self._h, _ptr(samples), nsub, n, _ptr(info), _ptr(res), _ptr(bits), slot),
             "fhip_encode_residual")
         return {"info": info, "residual": res, "rice_bits": bits, "slot_bytes": slot}
+
+    def order_search_bits(self, samples: np.ndarray, obits, magbits=None) -> np.ndarray:
+        """The bits[] table of encode_residual()'s LPC order search (optimize.c:201-261) over prepared
+        [nsub][n] blocks: [nsub][32] uint32, 0xFFFFFFFF = order not visited / constant block.
+        magbits (|x| < 2^magbits per block, optional) lets 16-bit blocks take the packed FIRs."""
+        samples = np.ascontiguousarray(samples, dtype=np.int32)
+        nsub, n = samples.shape
+        info = np.zeros(nsub, dtype=INFO_DTYPE)
+        info["obits"] = obits
+        if magbits is not None:
+            info["reserved"] = (1 + np.asarray(magbits, dtype=np.int64)) << 8
+        bits = np.zeros((nsub, 32), dtype=np.uint32)
+        self._check(self.lib.fhip_order_search_bits(self._h, _ptr(samples), nsub, n, _ptr(info), _ptr(bits)),
+                    "fhip_order_search_bits")
+        return bits
 
     def calc_rice_params(self, residual: np.ndarray, pred_order: int, lpc: bool, bps: int,
                          pmin: int, pmax: int, slot_bytes: int = 0) -> dict:

@@ -1183,6 +1183,34 @@ int fhip_encode_residual(fhip_ctx *c, const int32_t *samples, int nsub, int n,
     return fhip_sync(c);
 }
 
+int fhip_order_search_bits(fhip_ctx *c, const int32_t *samples, int nsub, int n,
+                           const fhip_subframe_info *info, uint32_t *bits)
+{
+    if (!c || !samples || !info || !bits) return fail(c, FHIP_E_INVALID, "null argument");
+    const size_t cap = (size_t)c->max_frames * c->p.channels;
+    if (nsub < 0 || (size_t)nsub > cap || n < 1 || n > c->p.block_size)
+        return fail(c, FHIP_E_INVALID, "batch shape out of range");
+    const fhip_params &p = c->p;
+    if (!fhip::order_search_supported(p, n))
+        return fail(c, FHIP_E_UNSUPPORTED, "no order-search kernel for this method / block size (the search then runs inside K3)");
+    if (nsub == 0) return FHIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c, 0);
+    if (rc != FHIP_OK) return rc;
+    const size_t ns = (size_t)nsub;
+    HIP_TRY(c, hipMemcpyAsync(c->d_smp, samples, ns * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_k0rec, info, ns * sizeof(fhip_subframe_info), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, fhip::launch_autocorr(c->stream, c->d_smp, nsub, n, p.max_prediction_order, c->d_autoc));
+    HIP_TRY(c, fhip::launch_lpc(c->stream, c->d_autoc, nsub, p.max_prediction_order,
+                                p.lpc_precision, p.order_method, c->d_coefs, c->d_shift, c->d_opt, c->d_fin));
+    // the residual workspace ([nsub][n] int32, n >= 512 here) holds the table
+    uint32_t *table = reinterpret_cast<uint32_t *>(c->d_res);
+    HIP_TRY(c, fhip::launch_order_search(c->stream, p, c->d_smp, nsub, n, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
+                                         c->d_k0rec, false, nullptr, table));
+    HIP_TRY(c, hipMemcpyAsync(bits, table, ns * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    return fhip_sync(c);
+}
+
 int fhip_vbs_split(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size,
                    int32_t *frames, int32_t *sizes)
 {

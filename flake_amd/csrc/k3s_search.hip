@@ -360,7 +360,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                     const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                     int32_t *__restrict__ opt_all, int32_t *__restrict__ fin_all,
                     const fhip_subframe_info *__restrict__ prep, int narrow_ok,
-                    const int32_t *__restrict__ dev_sub)
+                    const int32_t *__restrict__ dev_sub, uint32_t *__restrict__ table_out)
 {
     static_assert(C % 4 == 0 && T >= 128 && (T & (T - 1)) == 0, "k_order_search: runs of whole groups of four");
     if (dev_sub && (int)blockIdx.x >= dev_count(dev_sub, 0)) return;
@@ -887,6 +887,8 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         l.misc[1] = best;
     }
     __syncthreads();
+    // (stage entry fhip_order_search_bits: the table itself, 0xFFFFFFFF = order not visited)
+    if (table_out && tid < 32) table_out[(size_t)s * 32 + tid] = constant ? 0xFFFFFFFFu : l.trial[tid];
     if (tid < 32) {
         // the winner as K2's compact row (kernels.h: FIN_STRIDE / FIN_DBL / FIN_PAIRS)
         const int best = l.misc[1];
@@ -941,7 +943,7 @@ bool order_search_supported(const fhip_params &p, int n)
 hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32_t *smp, int nsub,
                                int n, const int32_t *coefs, const int32_t *shift,
                                int32_t *opt_order, int32_t *fin, const fhip_subframe_info *prep,
-                               bool narrow_ok, const int32_t *dev_sub)
+                               bool narrow_ok, const int32_t *dev_sub, uint32_t *table_out)
 {
     if (nsub == 0) return hipSuccess;
     int fc = 0, ft = 0;
@@ -962,7 +964,7 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_order_search<CC, TT, G, true>), dim3(nsub), dim3(TT), lds, st, p, n, smp, coefs, \
-                           shift, opt_order, fin, prep, narrow_ok ? 1 : 0, dev_sub);         \
+                           shift, opt_order, fin, prep, narrow_ok ? 1 : 0, dev_sub, table_out); \
         return hipGetLastError();                                                            \
     } while (0)
         switch (fc * 10000 + ft) {
@@ -986,7 +988,7 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_order_search<CC, TT, G>), dim3(nsub), dim3(TT), lds, st, p, n, \
-                           smp, coefs, shift, opt_order, fin, prep, narrow_ok ? 1 : 0, dev_sub); \
+                           smp, coefs, shift, opt_order, fin, prep, narrow_ok ? 1 : 0, dev_sub, table_out); \
     } while (0)
     switch (fc * 10000 + ft) {
     case 160256: LAUNCH_SRCH(16, 256); break;

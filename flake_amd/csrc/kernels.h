@@ -94,7 +94,8 @@ bool order_search_supported(const fhip_params &p, int n);
 hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32_t *smp, int nsub,
                                int n, const int32_t *coefs, const int32_t *shift,
                                int32_t *opt_order, int32_t *fin, const fhip_subframe_info *prep,
-                               bool narrow_ok, const int32_t *dev_sub = nullptr);
+                               bool narrow_ok, const int32_t *dev_sub = nullptr,
+                               uint32_t *table_out = nullptr);
 
 // K4: whole frames on the device (encode.c:718-764, :800-917, :949-964):
 // frames [nframes][frame_stride] bytes, frame_bytes [nframes].

@@ -271,6 +271,17 @@ FHIP_API int fhip_encode_residual(fhip_ctx *ctx, const int32_t *samples, int nsu
                          fhip_subframe_info *info, int32_t *residual,
                          uint8_t *rice_bits, int64_t rice_slot_bytes);
 
+/* The bits[] table of encode_residual()'s LPC order searches (optimize.c:201-261: 2/4/8-LEVEL,
+ * SEARCH, LOG) on prepared samples [nsub][n]: bits[s][order - 1] = the size estimate the
+ * reference computes for that order (encode_residual_lpc + calc_rice_params_lpc, optimize.c:207-212,
+ * :228-233, :250-255) for every order the handle's method visits, 0xFFFFFFFF for the others and
+ * for a constant block.  info[s].obits as for fhip_encode_residual; bits 8..15 of
+ * info[s].reserved may carry 1 + m with |x| < 2^m for every sample (what the feeder stage
+ * records; 0 = unknown), which lets 16-bit blocks take the packed FIRs.  FHIP_E_UNSUPPORTED where
+ * the search runs inside the encode kernel (other block sizes / methods).  bits: [nsub][32]. */
+FHIP_API int fhip_order_search_bits(fhip_ctx *ctx, const int32_t *samples, int nsub, int n,
+                           const fhip_subframe_info *info, uint32_t *bits);
+
 /* calc_rice_params_lpc() / calc_rice_params_fixed(), rice.c:173-187, plus the
  * residual section of output_residual() (encode.c:766-798) on GIVEN residuals
  * [nsub][n]: fills info[].rice_method/porder/rparams/est_bits/rice_nbits. */

@@ -569,3 +569,43 @@ def test_order_search_high_orders(oracle, n, om, lo, hi, pmin):
         _, exp = check(oracle, p, pcm, n, f"high orders n={n} om={om} {lo}..{hi} pmin={pmin} bps={bps}")
         top = max(top, int(exp["info"]["order"].max()))
     assert top >= min(hi, 27), top              # the case did reach up there
+
+
+@pytest.mark.parametrize("n", [512, 1024, 1536, 2048, 2560, 3072, 3584, 4096, 5120, 6144, 7168, 8192, 16384])
+@pytest.mark.parametrize("om,lo,hi", [(flake_amd.OM_SEARCH, 1, 32), (flake_amd.OM_SEARCH, 1, 12),
+                                       (flake_amd.OM_8LEVEL, 3, 32), (flake_amd.OM_LOG, 1, 32)])
+def test_order_search_table(oracle, n, om, lo, hi):
+    """fhip_order_search_bits: EVERY entry of the bits[] table behind the order searches (optimize.c:201-261),
+    not only the winner -- quantised rows (lpc.c:224-257), FIR (optimize.c:70-122) and
+    calc_rice_params_lpc (rice.c:180-187) per visited order from the oracle.  Widths: 16 bits with the
+    feeder's magnitude record (packed FIRs; SEARCH above order 16: the matrix pipe takes the rest),
+    16 bits without it, 24 bits; resonator frames, many tones (high orders win), noise."""
+    for bps, with_mag in ((16, True), (16, False), (24, False)):
+        p = flake_amd.level_params(5, bits_per_sample=bps, block_size=n, order_method=om,
+                                   min_prediction_order=lo, max_prediction_order=hi, max_partition_order=8)
+        r = np.random.RandomState(n * 3 + hi + bps)
+        full = 1 << (bps - 1)
+        blocks = np.concatenate([flake_amd.synth_pcm(2, n, 1, bps, first_frame=11).reshape(2, n),
+                                 _many_tones(1, n, 1, bps, n + bps).reshape(1, n),
+                                 r.randint(-full, full, (1, n)).astype(np.int32)])
+        blocks[1, : n // 3] >>= 5
+        obits = np.full(blocks.shape[0], bps, dtype=np.int32)
+        mag = None
+        if with_mag:
+            mag = [max(1, int(np.abs(b.astype(np.int64)).max()).bit_length()) for b in blocks]
+        with flake_amd.Encoder(p, max_frames=blocks.shape[0]) as enc:
+            table = enc.order_search_bits(blocks, obits, magbits=mag)
+        visited = 0
+        for s in range(blocks.shape[0]):
+            coefs, shift, _ = oracle.lpc_calc_coefs(blocks[s], hi, p.lpc_precision, om)
+            for o in range(1, hi + 1):
+                if table[s, o - 1] == 0xFFFFFFFF:
+                    continue
+                res = oracle.residual_lpc(blocks[s], o, coefs[o - 1], int(shift[o - 1]))
+                bits, _ = oracle.subframe_bits(res, p.min_partition_order, p.max_partition_order, o, bps,
+                                               p.lpc_precision, True)
+                assert int(table[s, o - 1]) == int(bits) & 0xFFFFFFFF, (n, om, bps, with_mag, s, o, table[s, o - 1], bits)
+                visited += 1
+            if om == flake_amd.OM_SEARCH:
+                assert (table[s, :hi] != 0xFFFFFFFF).all(), (n, bps, s)       # every order 1 .. max (optimize.c:226)
+        assert visited >= blocks.shape[0] * 3

@@ -52,6 +52,54 @@ def test_random_configuration(oracle, seed):
     assert_bits_equal(got["rice_bits"], exp["rice_bits"], exp["info"], what)
 
 
+_PIECE_COUNT = int(os.environ.get("FLAKE_FUZZ_PIECE_SEEDS", "96"))
+_PIECES = [512 * k for k in range(1, 15)] + [8192, 8192, 4096]
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + _PIECE_COUNT))
+def test_random_piece_sizes(oracle, seed):
+    """The sizes a variable-block-size stream is made of (k eighths of a 4096 or 8192 block: the
+    order-search kernel's run lengths 4 .. 28 in 128 or 256 threads) with LPC order searches over the
+    full order range -- high orders included, which the sweep above caps for SEARCH -- on signals
+    whose best order is high (many tones) as well as the sweep's kinds.  (Round 3: runs of 20 / 28
+    read candidate rows past tap 32; only a winner above order 28 showed it.)"""
+    r = np.random.RandomState(777000 + seed)
+    n = int(r.choice(_PIECES))
+    ch = int(r.choice([1, 2, 2]))
+    bps = int(r.choice([16, 16, 20, 24, 24, 32]))
+    lo = int(r.randint(1, 33)); hi = int(r.randint(lo, 33))
+    if r.rand() < 0.5:
+        hi = 32
+    om = int(r.choice([2, 3, 4, 5, 5, 6, 6]))
+    plo = int(r.randint(0, 9)); phi = int(r.randint(plo, 9))
+    if r.rand() < 0.5:
+        plo, phi = 0, 8
+    p = flake_amd.level_params(5, channels=ch, bits_per_sample=bps, block_size=n, order_method=om,
+                               min_prediction_order=lo, max_prediction_order=hi,
+                               min_partition_order=plo, max_partition_order=phi,
+                               stereo_method=int(r.randint(0, 2)))
+    nfr = 3
+    kind = int(r.randint(0, 7))
+    if kind >= 5:                                    # many tones: prediction keeps gaining up to order ~30
+        t = np.arange(nfr * n, dtype=np.float64)
+        x = np.zeros((nfr * n, ch))
+        for c in range(ch):
+            for _ in range(int(r.randint(8, 17))):
+                x[:, c] += r.uniform(0.3, 1.0) * np.sin(t * r.uniform(0.02, 3.0) + r.uniform(0, 6.28))
+        x *= (1 << (bps - 1)) / 18.0
+        x += r.uniform(-2, 2, x.shape)
+        pcm = np.round(x).astype(np.int64).clip(-(1 << (bps - 1)), (1 << (bps - 1)) - 1).astype(np.int32).reshape(nfr, n, ch)
+    else:
+        pcm = _signal(r, kind, nfr, n, ch, bps)
+    what = f"piece seed {seed}: n={n} ch={ch} bps={bps} om={om} order {lo}..{hi} porder {plo}..{phi}"
+    with flake_amd.Encoder(p, max_frames=nfr) as enc:
+        got = enc.encode_subframes(pcm, n)
+    exp = oracle.encode_subframes_batch(p, pcm, n, slot_bytes=got["slot_bytes"])
+    assert_info_equal(got["info"], exp["info"], what)
+    assert_residual_equal(got["residual"], exp["residual"], exp["info"], what)
+    assert_bits_equal(got["rice_bits"], exp["rice_bits"], exp["info"], what)
+
+
 _FRAME_COUNT = int(os.environ.get("FLAKE_FUZZ_FRAME_SEEDS", "96"))
 
 

@@ -250,5 +250,22 @@ __device__ __forceinline__ int rice_k_fast_u32(uint32_t sum, int n, uint32_t *bi
     return k;
 }
 
+// rice_k_fast_u32 without divergent branches, for callers that have ruled out its slow corners wave-wide
+// (n <= 0; sum - n/2 >= 0xFFE00000): the three cases as selects.  __clz(0) = 32.
+__device__ __forceinline__ int rice_k_u32_nb(uint32_t sum, uint32_t n, uint32_t *bits_out)
+{
+    const uint32_t half = n >> 1;
+    const uint32_t S = sum - half;                   // wraps when sum < half: then nothing below is used
+    const uint32_t two = 2u * n;
+    int k = (int)__clz((int)two) - (int)__clz((int)S);
+    k = max(k, 0);                                   // S <= two: no shift
+    k += ((S >> k) > two) ? 1 : 0;
+    k = min(k, 30);
+    const uint32_t hi = n * (uint32_t)(k + 1) + (S >> k);
+    const bool low = sum < half;
+    *bits_out = low ? n - (half - sum) : hi;
+    return low ? 0 : k;
+}
+
 }  // namespace
 }  // namespace fhip

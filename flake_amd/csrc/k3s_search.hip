@@ -40,7 +40,7 @@ struct SrchLds {
     int32_t *rowi;              // [G][4]   order index, shift, sum |coef|, spare
     uint32_t *trial;            // [32]     bits[order index], 0xFFFFFFFF = not evaluated
     int32_t *list;              // [32]     candidate order indices of this subframe
-    int32_t *misc;              // [32]: count, winner, two overflow flags, one "differs" word per wave (<= 16), ...
+    int32_t *misc;              // [32]: 0 count, 1 winner, 4.. a flag word per wave (<= 16), 24/25 overflow flags
 };
 
 // MM (the SEARCH method's FIRs on the int8 matrix pipe, k_order_search<.., true>): three planes of
@@ -71,7 +71,8 @@ __host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[16
     off[8] = o; o += 4 * 32;
     off[9] = o; o += 4 * 32;
     off[10] = o; o += 4 * 32;
-    off[11] = 0;
+    o = (o + 15) & ~(size_t)15;
+    off[11] = o; o += 2 * 32 * 32 + 4 * 32;                     // every candidate row as int16, the shifts
     o = (o + 15) & ~(size_t)15;
     off[12] = off[13] = off[14] = off[15] = 0;
     if (mm_n) {
@@ -115,69 +116,86 @@ __device__ __forceinline__ uint32_t wave_candidate_bits(const uint32_t *__restri
     const unsigned long long s7[2] = {s8[0] + s8[1], s8[2] + s8[3]};
     const unsigned long long s6 = s7[0] + s7[1];
 
-    auto node = [&](unsigned long long sum, int p, int jn, uint32_t *b) -> int {
-        const int cnt = (n >> p) - (jn == 0 ? ord : 0);
-        return (sum >> 32) ? rice_k_fast(sum, cnt, b) : rice_k_fast_u32((uint32_t)sum, cnt, b);
-    };
+    // The usual case -- every sum below 0xFFE00000 and no empty first partition -- takes the node
+    // evaluation as straight-line 32-bit code (rice_k_u32_nb); the corners (32-bit noise summed over
+    // four leaves, n >> p == order) keep the general form.  The choice is wave-uniform.
+    const bool corners = __any(s6 >= 0xFFE00000ull) || ((n >> pmax) - ord) <= 0;
     uint32_t lb[9];
 #pragma unroll
     for (int p = 0; p < 9; p++) lb[p] = 0;
     uint32_t rice2 = 0;                         // bit p: some parameter of level p is above 14
-    // ---- lane-local levels 8, 7, 6 ----
-    {
-        uint32_t b8 = 0, b7 = 0, b6 = 0;
-        bool k8 = false, k7 = false, k6 = false;
-        if (pmax >= 8 && pmin <= 8) {
+    auto levels = [&](auto fast_c) {
+        constexpr bool FAST = decltype(fast_c)::value;
+        auto node = [&](unsigned long long sum, int p, int jn, uint32_t *b) -> int {
+            const int cnt = (n >> p) - (jn == 0 ? ord : 0);
+            if constexpr (FAST) return rice_k_u32_nb((uint32_t)sum, (uint32_t)cnt, b);
+            else return (sum >> 32) ? rice_k_fast(sum, cnt, b) : rice_k_fast_u32((uint32_t)sum, cnt, b);
+        };
+        // ---- lane-local levels 8, 7, 6 ----
+        {
+            uint32_t b8 = 0, b7 = 0, b6 = 0;
+            bool k8 = false, k7 = false, k6 = false;
+            if (pmax >= 8 && pmin <= 8) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) { uint32_t b; k8 |= node(s8[i], 8, 4 * lane + i, &b) > 14; b8 += b; }
-        }
-        if (pmax >= 7 && pmin <= 7) {
+                for (int i = 0; i < 4; i++) { uint32_t b; k8 |= node(s8[i], 8, 4 * lane + i, &b) > 14; b8 += b; }
+            }
+            if (pmax >= 7 && pmin <= 7) {
 #pragma unroll
-            for (int i = 0; i < 2; i++) { uint32_t b; k7 |= node(s7[i], 7, 2 * lane + i, &b) > 14; b7 += b; }
-        }
-        if (pmax >= 6 && pmin <= 6) { uint32_t b; k6 = node(s6, 6, lane, &b) > 14; b6 = b; }
-        uint32_t t8 = b8, t7 = b7, t6 = b6;
+                for (int i = 0; i < 2; i++) { uint32_t b; k7 |= node(s7[i], 7, 2 * lane + i, &b) > 14; b7 += b; }
+            }
+            if (pmax >= 6 && pmin <= 6) { uint32_t b; k6 = node(s6, 6, lane, &b) > 14; b6 = b; }
+            uint32_t t8 = b8, t7 = b7, t6 = b6;
 #define WSUM(X_) do { X_ += dpp_u32<0x111>(X_); X_ += dpp_u32<0x112>(X_); X_ += dpp_u32<0x114>(X_);       \
                       X_ += dpp_u32<0x118>(X_); X_ += dpp_u32<0x142, 0xA>(X_); X_ += dpp_u32<0x143, 0xC>(X_); } while (0)
-        WSUM(t8); WSUM(t7); WSUM(t6);
+            WSUM(t8); WSUM(t7); WSUM(t6);
 #undef WSUM
-        lb[8] = (uint32_t)__builtin_amdgcn_readlane((int)t8, 63);
-        lb[7] = (uint32_t)__builtin_amdgcn_readlane((int)t7, 63);
-        lb[6] = (uint32_t)__builtin_amdgcn_readlane((int)t6, 63);
-        if (__any(k8)) rice2 |= 1u << 8;
-        if (__any(k7)) rice2 |= 1u << 7;
-        if (__any(k6)) rice2 |= 1u << 6;
-    }
-    // ---- levels 5 .. 0: a 127-entry heap of this wave (entry 2^p - 1 + j = node j of level p) ----
-    if (pmin <= 5) {
-        heap[63 + lane] = s6;
+            lb[8] = (uint32_t)__builtin_amdgcn_readlane((int)t8, 63);
+            lb[7] = (uint32_t)__builtin_amdgcn_readlane((int)t7, 63);
+            lb[6] = (uint32_t)__builtin_amdgcn_readlane((int)t6, 63);
+            if (__any(k8)) rice2 |= 1u << 8;
+            if (__any(k7)) rice2 |= 1u << 7;
+            if (__any(k6)) rice2 |= 1u << 6;
+        }
+        // ---- levels 5 .. 0: a 127-entry heap of this wave (entry 2^p - 1 + j = node j of level p) ----
+        if (pmin <= 5) {
+            heap[63 + lane] = s6;
 #pragma unroll
-        for (int p = 5; p >= 0; p--) {
+            for (int p = 5; p >= 0; p--) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane < (1 << p)) {
+                    const int c = (2 << p) - 1 + 2 * lane;
+                    heap[(1 << p) - 1 + lane] = heap[c] + heap[c + 1];
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (lane < (1 << p)) {
-                const int c = (2 << p) - 1 + 2 * lane;
-                heap[(1 << p) - 1 + lane] = heap[c] + heap[c + 1];
+            const int p = ilog2_dev((uint32_t)(lane + 1));           // lanes 0..62: node `lane`, level p
+            uint32_t b = 0;
+            bool big = false;
+            const unsigned long long hs = heap[min(lane, 62)];
+            const unsigned long long total = heap[0];       // the block's total bounds every node of the heap
+            if (lane < 63 && p >= pmin && p <= pmax) {
+                const int jn = lane + 1 - (1 << p);
+                const int cnt = (n >> p) - (jn == 0 ? ord : 0);
+                if (FAST && total < 0xFFE00000ull) big = rice_k_u32_nb((uint32_t)hs, (uint32_t)cnt, &b) > 14;
+                else big = ((hs >> 32) ? rice_k_fast(hs, cnt, &b) : rice_k_fast_u32((uint32_t)hs, cnt, &b)) > 14;
             }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int p = ilog2_dev((uint32_t)(lane + 1));           // lanes 0..62: node `lane`, level p
-        uint32_t b = 0;
-        bool big = false;
-        if (lane < 63 && p >= pmin && p <= pmax) big = node(heap[lane], p, lane + 1 - (1 << p), &b) > 14;
-        const uint32_t sc = wave_incl_scan_u32_dpp(b);
-        const unsigned long long bigm = __ballot(big);
+            const uint32_t sc = wave_incl_scan_u32_dpp(b);
+            const unsigned long long bigm = __ballot(big);
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)sc, (2 << q) - 2);
-            const uint32_t lo = q ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (1 << q) - 2) : 0u;
-            lb[q] = hi - lo;
-            const unsigned long long lvl = ((1ull << ((2 << q) - 1)) - 1) & ~((1ull << ((1 << q) - 1)) - 1);
-            if (bigm & lvl) rice2 |= 1u << q;
+            for (int q = 0; q < 6; q++) {
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)sc, (2 << q) - 2);
+                const uint32_t lo = q ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (1 << q) - 2) : 0u;
+                lb[q] = hi - lo;
+                const unsigned long long lvl = ((1ull << ((2 << q) - 1)) - 1) & ~((1ull << ((1 << q) - 1)) - 1);
+                if (bigm & lvl) rice2 |= 1u << q;
+            }
+            __builtin_amdgcn_wave_barrier();                        // the heap is reused by the next candidate
         }
-        __builtin_amdgcn_wave_barrier();                        // the heap is reused by the next candidate
-    }
+    };
+    if (!corners) levels(std::true_type{});
+    else levels(std::false_type{});
     // rice.c:127-138, :157-171, :180-187
     uint32_t best = 0, method = 0;
 #pragma unroll
@@ -389,12 +407,15 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     l.trial = reinterpret_cast<uint32_t *>(lds_raw + off[8]);
     l.list = reinterpret_cast<int32_t *>(lds_raw + off[9]);
     l.misc = reinterpret_cast<int32_t *>(lds_raw + off[10]);
+    int16_t *crows = reinterpret_cast<int16_t *>(lds_raw + off[11]);            // [32][32] K2's rows (|coef| < 2^15)
+    int32_t *cshifts = reinterpret_cast<int32_t *>(lds_raw + off[11] + 2 * 32 * 32);
 
     // fp64 rounding toward -inf: fir_lpc's floor (see k_encode_pow2)
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2" ::: "memory");
 
     const int s = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: what only wave 0 does stays scalar code
     FastCtx<C, T> e;
     e.l.smp = l.smp; e.l.sums = nullptr; e.l.kpar = nullptr; e.l.coefd = l.coefd; e.l.wtot = nullptr;
     e.l.lvl_bits = nullptr; e.l.lvl_meth = nullptr; e.l.coef = nullptr; e.l.misc = nullptr;
@@ -500,6 +521,17 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     }
     if (tid < Img::COL0 * C) l.smp[Img::at(tid / C, tid % C)] = 0;
     if (tid < 32) l.trial[tid] = 0xFFFFFFFFu;
+    {
+        // K2's 32 x 32 rows and their shifts into LDS once, beside the samples: a round then stages its
+        // candidates from LDS -- a global load per round sat on the round's critical path
+        const int32_t *cb = coefs_all + (size_t)s * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
+        for (int q = tid; q < FHIP_MAX_ORDER * FHIP_MAX_ORDER / 4; q += T) {
+            const int4 v = reinterpret_cast<const int4 *>(cb)[q];
+            *reinterpret_cast<uint2 *>(crows + 4 * q) =
+                make_uint2(((uint32_t)v.x & 0xFFFFu) | ((uint32_t)v.y << 16), ((uint32_t)v.z & 0xFFFFu) | ((uint32_t)v.w << 16));
+        }
+        if (tid < FHIP_MAX_ORDER) cshifts[tid] = shift_all[(size_t)s * FHIP_MAX_ORDER + tid];
+    }
     if (tid < 2) l.misc[24 + tid] = 0;                 // rounds: "a thread sum left 32 bits", per round parity
 
     const int omethod = P.order_method;
@@ -546,22 +578,19 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             unsigned char *z = lds_raw + off[12] + (tid >> 1) * mm_plane_bytes(C * T) + 16 * (tid & 1);
             *reinterpret_cast<uint4 *>(z) = make_uint4(0, 0, 0, 0);
         }
-        const int wave_fits = __all(mm_fits) ? 1 : 0;
-        if (lane == 0) l.misc[26 + wv] = wave_fits;
     }
-    const int wave_differs = (__ballot(differs) != 0ull) ? 1 : 0;
-    if (lane == 0) l.misc[4 + wv] = wave_differs;
+    // per wave: bit 0 "some sample differs from the first", bit 1 (matrix instances) "the limbs hold every sample"
+    const int wave_flags = ((__ballot(differs) != 0ull) ? 1 : 0) | ((MM && __all(mm_fits)) ? 2 : 0);
+    if (lane == 0) l.misc[4 + wv] = wave_flags;
     __syncthreads();
-    int any_differs = 0;
+    int any_differs = 0, all_fit = 2;
 #pragma unroll
-    for (int w = 0; w < NW; w++) any_differs |= l.misc[4 + w];
+    for (int w = 0; w < NW; w++) { any_differs |= l.misc[4 + w] & 1; all_fit &= l.misc[4 + w]; }
     const bool constant = (__builtin_amdgcn_readfirstlane(any_differs) == 0);
     int nc = __builtin_amdgcn_readfirstlane(l.misc[0]);
     bool mm_done = false;
     if constexpr (MM) {
-        int fits = 1;
-#pragma unroll
-        for (int w = 0; w < NW; w++) fits &= l.misc[26 + w];
+        const int fits = all_fit;
         // SEARCH (optimize.c:224-238) on samples the limbs hold: bits[order] of every order from the
         // matrix pipe, 16 candidates to a pass
         if (__builtin_amdgcn_readfirstlane(fits) && !constant && omethod == 5) {
@@ -634,11 +663,14 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         }
         const int par = round & 1;
         // ---- the round's rows: doubles, int16 pairs, sum |coef|, shift ----
+        // (the LOG walk planned and replayed by wave 0 alone, with the rows staged by that wave, saved
+        // a third of the kernel's scalar instructions and made it SLOWER -- level 8's search 264 -> 276 us:
+        // the kernel waits on its per-round critical path, not on instruction issue)
         if (tid < G * 32) {
             const int g = tid >> 5, j = tid & 31;
             const int cand = (g >= ng) ? 0 : is_log ? (int)((lg_pack >> (5 * g)) & 31u) : l.list[g0 + g];
             const int ord = cand + 1;
-            const int32_t cv = (g < ng && j < ord) ? crow_base[cand * FHIP_MAX_ORDER + j] : 0;
+            const int32_t cv = (g < ng && j < ord) ? (int32_t)crows[cand * FHIP_MAX_ORDER + j] : 0;
             l.coefd[g * SRCH_CROW + j] = (double)cv;
             if (j < SRCH_CROW - 32) l.coefd[g * SRCH_CROW + 32 + j] = 0.0;
             const int32_t nb = __shfl_xor(cv, 1, WAVE);
@@ -649,7 +681,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             sa += __shfl_xor(sa, 16, WAVE);
             if (j == 0) {
                 l.rowi[g * 4 + 0] = cand;
-                l.rowi[g * 4 + 1] = (g < ng) ? srow[cand] : 0;
+                l.rowi[g * 4 + 1] = (g < ng) ? cshifts[cand] : 0;
                 l.rowi[g * 4 + 2] = sa;
                 // rice.c:148-155 for this order, once (an integer division each)
                 l.rowi[g * 4 + 3] = clamp_porder(e.pmin_req, n, ord) | (clamp_porder(e.pmax_req, n, ord) << 8);

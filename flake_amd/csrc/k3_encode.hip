@@ -1546,12 +1546,15 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     } else {
         if constexpr (MODE == 1) {
             if (five_wide) {
+                STAMP(2);
                 best = fixed_search5<C, T>(e, min_order, max_order, &est_bits, &porder, &method);
+                STAMP(3);
                 fir_fixed<C, T>(e, r, best);
                 fold_residuals<C, T>(e, r, u, best);
                 umax_run = 0;
 #pragma unroll
                 for (int o = 0; o < C; o++) umax_run = max(umax_run, u[o]);
+                STAMP(8);
             }
         }
         if (!five_wide) for (;;) {

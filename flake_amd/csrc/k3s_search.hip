@@ -31,7 +31,7 @@ struct SrchLds {
     unsigned long long *sums;   // [G][512] heap order per candidate slot; in leaf mode G per-wave heaps of 128
                                 // and behind them the G x T thread sums as 32-bit leaves
     unsigned long long *wtot;   // [G][16]  per-wave totals
-    double *coefd;              // [G][SRCH_CROW] candidate rows as doubles, zero past the order -- and past 32:
+    double *coefd;              // [G][srch_crow(C)] candidate rows as doubles, zero past the order -- and past 32:
                                 // fir_lpc's tap blocks of 20 / 28 (runs of 20, 28) read up to tap 36
     int32_t *smp;               // SmpImg<C, T>
     uint32_t *lvl_bits;         // [2][G][12] (double-buffered by round parity)
@@ -47,12 +47,13 @@ struct SrchLds {
 // sample limbs (bytes, MM_HIST zeros in front), the coefficient limbs of all 32 candidate rows, four
 // a heap per wave for the Rice search and two small tables; the leaves of the 16 candidates of a
 // pass lie over the general way's sums (16 KB; 32 KB with 512 leaves).
-constexpr int SRCH_CROW = 40;          // doubles per candidate row in LDS
+// doubles per candidate row in LDS: fir_lpc's tap blocks of 20 / 28 (runs of 20, 28) read up to tap 36
+__host__ __device__ constexpr int srch_crow(int c) { return (c % 8 == 4 && c > 16) ? 40 : 32; }
 constexpr int MM_HIST = 32;
 __host__ __device__ constexpr int mm_plane_bytes(int n) { return n + MM_HIST + 16; }
 
 template <int G>
-__host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[16], int leaves, int mm_n = 0)
+__host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[16], int leaves, int mm_n = 0, int crow = 32)
 {
     size_t o = 0;
     // sums: G x 4 KB for the general way; leaf mode overlays G heaps of 1 KB and G x NL leaves
@@ -61,7 +62,7 @@ __host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[16
     const size_t s0 = general > leafy ? general : leafy;
     off[0] = o; o += s0 > mm_leaves ? s0 : mm_leaves;
     off[1] = o; o += 8 * 16 * G;
-    off[2] = o; o += 8 * SRCH_CROW * G;
+    off[2] = o; o += 8 * (size_t)crow * G;
     off[3] = o; o += 4 * img_ints;
     o = (o + 15) & ~(size_t)15;
     off[4] = o; o += 4 * 2 * G * 12;
@@ -72,7 +73,8 @@ __host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[16
     off[9] = o; o += 4 * 32;
     off[10] = o; o += 4 * 32;
     o = (o + 15) & ~(size_t)15;
-    off[11] = o; o += 2 * 32 * 32 + 4 * 32;                     // every candidate row as int16, the shifts
+    off[11] = o; o += mm_n ? 0 : 2 * 32 * 32 + 4 * 32;          // every candidate row as int16, the shifts (the
+                                                                // matrix instances keep their LDS for three workgroups per CU)
     o = (o + 15) & ~(size_t)15;
     off[12] = off[13] = off[14] = off[15] = 0;
     if (mm_n) {
@@ -119,7 +121,10 @@ __device__ __forceinline__ uint32_t wave_candidate_bits(const uint32_t *__restri
     // The usual case -- every sum below 0xFFE00000 and no empty first partition -- takes the node
     // evaluation as straight-line 32-bit code (rice_k_u32_nb); the corners (32-bit noise summed over
     // four leaves, n >> p == order) keep the general form.  The choice is wave-uniform.
-    const bool corners = __any(s6 >= 0xFFE00000ull) || ((n >> pmax) - ord) <= 0;
+#ifndef FHIP_NODE_FAST
+#define FHIP_NODE_FAST 1
+#endif
+    const bool corners = !FHIP_NODE_FAST || __any(s6 >= 0xFFE00000ull) || ((n >> pmax) - ord) <= 0;
     uint32_t lb[9];
 #pragma unroll
     for (int p = 0; p < 9; p++) lb[p] = 0;
@@ -234,7 +239,7 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
                                           const int32_t *__restrict__ tab, const int32_t *__restrict__ img,
                                           uint32_t *__restrict__ leaf, unsigned long long *__restrict__ heaps,
                                           uint32_t *__restrict__ trial, int n, int max_order, int obits, int precision,
-                                          int tid, int ct0)
+                                          int tid)
 {
     using Img = SmpImg<C, T>;
     typedef int v4i __attribute__((ext_vector_type(4)));
@@ -250,7 +255,7 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
     const unsigned xbase = (unsigned)(size_t)(const __attribute__((address_space(3))) int32_t *)img;
 
 #pragma unroll 1
-    for (int ct = ct0; ct * 16 < max_order; ct++) {
+    for (int ct = 0; ct * 16 < max_order; ct++) {
         // ---- the pass's 16 rows as B operands: weight w pairs (c0, x_w) with (c1, x_{w-1}) ----
         v4i Bop[4];
 #pragma unroll
@@ -283,26 +288,9 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
                 constexpr int OC = decltype(oc_c)::value;
                 constexpr int NT = (C - OC < 16) ? C - OC : 16;
                 constexpr int ND = NT / 4 + 4;
-                int Wd[4][ND];
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    if constexpr (C % 16 == 0) {
-#pragma unroll
-                        for (int q = 0; q < ND; q += 4) {
-                            const v4i R = *(lds_v4)(size_t)(ad[w] + OC + 4 * q);
-                            Wd[w][q] = R.x; Wd[w][q + 1] = R.y; Wd[w][q + 2] = R.z; Wd[w][q + 3] = R.w;
-                        }
-                    } else if constexpr (C % 8 == 0) {
-#pragma unroll
-                        for (int q = 0; q < ND; q += 2) {
-                            const v2i R = *(lds_v2)(size_t)(ad[w] + OC + 4 * q);
-                            Wd[w][q] = R.x; Wd[w][q + 1] = R.y;
-                        }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < ND; q++) Wd[w][q] = *(lds_i)(size_t)(ad[w] + OC + 4 * q);
-                    }
-                }
+                // The window's dwords are read INSIDE the tile loop, at compile-time offsets from ad[w]: the
+                // same addresses for every tile, the compiler keeps one copy.  (Preloaded into an array ahead of
+                // the loop they cost the kernel 50-76 spilled registers and configs[2] 0.2 ms.)
 #pragma unroll
                 for (int o4 = 0; o4 < NT; o4 += 4) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -313,11 +301,38 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
                         v4i Aop[4];
 #pragma unroll
                         for (int w = 0; w < 4; w++) {
-                            if (bb == 0) Aop[w] = v4i{Wd[w][aa], Wd[w][aa + 1], Wd[w][aa + 2], Wd[w][aa + 3]};
-                            else Aop[w] = v4i{(int)__builtin_amdgcn_alignbyte(Wd[w][aa + 1], Wd[w][aa], bb),
-                                              (int)__builtin_amdgcn_alignbyte(Wd[w][aa + 2], Wd[w][aa + 1], bb),
-                                              (int)__builtin_amdgcn_alignbyte(Wd[w][aa + 3], Wd[w][aa + 2], bb),
-                                              (int)__builtin_amdgcn_alignbyte(Wd[w][aa + 4], Wd[w][aa + 3], bb)};
+                            int W[8];
+                            if constexpr (C % 16 == 0) {
+                                const v4i R0 = *(lds_v4)(size_t)(ad[w] + OC);
+                                v4i R1 = R0;
+                                if (oo) R1 = *(lds_v4)(size_t)(ad[w] + OC + 16);
+                                W[0] = R0.x; W[1] = R0.y; W[2] = R0.z; W[3] = R0.w;
+                                W[4] = R1.x; W[5] = R1.y; W[6] = R1.z; W[7] = R1.w;
+                            } else if constexpr (C % 8 == 0) {
+                                // dwords aa .. aa + 4 of the window: three 8-byte reads at even dword offsets
+                                const int e0 = aa & ~1;
+#pragma unroll
+                                for (int q = 0; q < 6; q += 2) {
+                                    v2i R = v2i{0, 0};
+                                    if (e0 + q < ND) R = *(lds_v2)(size_t)(ad[w] + OC + 4 * (e0 + q));
+                                    W[q] = R.x; W[q + 1] = R.y;
+                                }
+                                W[6] = W[7] = 0;
+                                if (aa & 1) {
+#pragma unroll
+                                    for (int q = 0; q < 5; q++) W[q] = W[q + 1];
+                                }
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 8; q++)
+                                    W[q] = (q < 5 && aa + q < ND) ? *(lds_i)(size_t)(ad[w] + OC + 4 * (aa + q)) : 0;
+                            }
+                            const int a0 = (C % 16 == 0) ? aa : 0;
+                            if (bb == 0) Aop[w] = v4i{W[a0], W[a0 + 1], W[a0 + 2], W[a0 + 3]};
+                            else Aop[w] = v4i{(int)__builtin_amdgcn_alignbyte(W[a0 + 1], W[a0], bb),
+                                              (int)__builtin_amdgcn_alignbyte(W[a0 + 2], W[a0 + 1], bb),
+                                              (int)__builtin_amdgcn_alignbyte(W[a0 + 3], W[a0 + 2], bb),
+                                              (int)__builtin_amdgcn_alignbyte(W[a0 + 4], W[a0 + 3], bb)};
                         }
                         // the samples of this lane's four rows: element o of the runs of threads 16 blk + 4 g + r
                         int32_t xs[4];
@@ -364,9 +379,6 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
 // two per thread) or the T thread sums; every piece of a variable-block-size stream (k eighths of
 // a 4096 or 8192 block) is 256 leaves of 2k or 4k samples: T = 256 with runs of 4k, T = 128 with
 // runs of 4k for the odd eighths of a 4096 block.
-#ifndef FHIP_MM_NO_HYBRID
-#define FHIP_MM_NO_HYBRID 0
-#endif
 template <int C, int T, int G, bool MM = false>
 // (runs of 20 .. 28 samples at three waves per SIMD, 168 VGPRs: at four they spill up to 200 bytes per lane)
 #ifndef FHIP_SRCH_WLONG
@@ -394,7 +406,8 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     static_assert(!MM || (T >= 256 && C <= 32), "the matrix path: one leaf per thread, runs of up to 32");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     size_t off[16];
-    srch_lds_layout<G>((size_t)Img::SIZE, off, NL, MM ? C * T : 0);
+    constexpr int SRCH_CROW = srch_crow(C);
+    srch_lds_layout<G>((size_t)Img::SIZE, off, NL, MM ? C * T : 0, SRCH_CROW);
     SrchLds<G> l;
     l.sums = reinterpret_cast<unsigned long long *>(lds_raw + off[0]);
     l.wtot = reinterpret_cast<unsigned long long *>(lds_raw + off[1]);
@@ -415,7 +428,11 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 
     const int s = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef FHIP_WV_VECTOR
+    const int wv = tid >> 6;
+#else
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: what only wave 0 does stays scalar code
+#endif
     FastCtx<C, T> e;
     e.l.smp = l.smp; e.l.sums = nullptr; e.l.kpar = nullptr; e.l.coefd = l.coefd; e.l.wtot = nullptr;
     e.l.lvl_bits = nullptr; e.l.lvl_meth = nullptr; e.l.coef = nullptr; e.l.misc = nullptr;
@@ -521,7 +538,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     }
     if (tid < Img::COL0 * C) l.smp[Img::at(tid / C, tid % C)] = 0;
     if (tid < 32) l.trial[tid] = 0xFFFFFFFFu;
-    {
+    if constexpr (!MM) {
         // K2's 32 x 32 rows and their shifts into LDS once, beside the samples: a round then stages its
         // candidates from LDS -- a global load per round sat on the round's critical path
         const int32_t *cb = coefs_all + (size_t)s * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
@@ -587,23 +604,21 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 #pragma unroll
     for (int w = 0; w < NW; w++) { any_differs |= l.misc[4 + w] & 1; all_fit &= l.misc[4 + w]; }
     const bool constant = (__builtin_amdgcn_readfirstlane(any_differs) == 0);
-    int nc = __builtin_amdgcn_readfirstlane(l.misc[0]);
+    const int nc = __builtin_amdgcn_readfirstlane(l.misc[0]);
     bool mm_done = false;
     if constexpr (MM) {
         const int fits = all_fit;
         // SEARCH (optimize.c:224-238) on samples the limbs hold: bits[order] of every order from the
         // matrix pipe, 16 candidates to a pass
         if (__builtin_amdgcn_readfirstlane(fits) && !constant && omethod == 5) {
-            // 16-bit samples (K0 knows their magnitude): orders 1..16 keep the packed dot products of the
-            // rounds below -- at most eight per sample, cheaper than a matrix pass's epilogue -- and the
-            // matrix pipe takes the orders above, where the vector way is an fp64 FMA per tap
-            const int mb = __builtin_amdgcn_readfirstlane(magbits);
-            const int ct0 = (mb >= 0 && mb <= 15 && max_order > 16 && !FHIP_MM_NO_HYBRID) ? 1 : 0;
+            // (16-bit blocks too: leaving their orders 1..16 to the packed dot products of the rounds below and
+            // only the orders above to the matrix pipe measured SLOWER -- SEARCH 1-32 at 16 bits 0.99 against
+            // 0.89 ms, level 12 1.43 against 1.30 -- and a run-time choice between the two cost the 24-bit
+            // path 6 %: the compiler must then keep the rounds' state alive across the matrix passes)
             mm_search<C, T>(lds_raw + off[12], mm_cl, mm_tab, l.smp, reinterpret_cast<uint32_t *>(l.sums),
                             reinterpret_cast<unsigned long long *>(lds_raw + off[14]), l.trial, n, max_order,
-                            e.obits, e.precision, tid, ct0);
-            if (ct0 == 0) mm_done = true;
-            else nc = min(nc, 16 * ct0);
+                            e.obits, e.precision, tid);
+            mm_done = true;
         }
     }
 
@@ -670,7 +685,8 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             const int g = tid >> 5, j = tid & 31;
             const int cand = (g >= ng) ? 0 : is_log ? (int)((lg_pack >> (5 * g)) & 31u) : l.list[g0 + g];
             const int ord = cand + 1;
-            const int32_t cv = (g < ng && j < ord) ? (int32_t)crows[cand * FHIP_MAX_ORDER + j] : 0;
+            const int32_t cv = !(g < ng && j < ord) ? 0 : MM ? crow_base[cand * FHIP_MAX_ORDER + j]
+                                                             : (int32_t)crows[cand * FHIP_MAX_ORDER + j];
             l.coefd[g * SRCH_CROW + j] = (double)cv;
             if (j < SRCH_CROW - 32) l.coefd[g * SRCH_CROW + 32 + j] = 0.0;
             const int32_t nb = __shfl_xor(cv, 1, WAVE);
@@ -681,7 +697,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             sa += __shfl_xor(sa, 16, WAVE);
             if (j == 0) {
                 l.rowi[g * 4 + 0] = cand;
-                l.rowi[g * 4 + 1] = (g < ng) ? cshifts[cand] : 0;
+                l.rowi[g * 4 + 1] = !(g < ng) ? 0 : MM ? srow[cand] : cshifts[cand];
                 l.rowi[g * 4 + 2] = sa;
                 // rice.c:148-155 for this order, once (an integer division each)
                 l.rowi[g * 4 + 3] = clamp_porder(e.pmin_req, n, ord) | (clamp_porder(e.pmax_req, n, ord) << 8);
@@ -991,7 +1007,7 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
         (p.bits_per_sample > 16 || p.max_prediction_order > 16)) {
 #define LAUNCH_MM(CC, TT)                                                                    \
     do {                                                                                     \
-        const size_t lds = srch_lds_layout<G>((size_t)SmpImg<CC, TT>::SIZE, off, TT, CC * TT); \
+        const size_t lds = srch_lds_layout<G>((size_t)SmpImg<CC, TT>::SIZE, off, TT, CC * TT, srch_crow(CC)); \
         hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_order_search<CC, TT, G, true>), \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (er != hipSuccess) return er;                                                     \
@@ -1014,7 +1030,7 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
     }
 #define LAUNCH_SRCH(CC, TT)                                                                  \
     do {                                                                                     \
-        const size_t lds = srch_lds_layout<G>((size_t)SmpImg<CC, TT>::SIZE, off, TT < 256 ? 256 : TT); \
+        const size_t lds = srch_lds_layout<G>((size_t)SmpImg<CC, TT>::SIZE, off, TT < 256 ? 256 : TT, 0, srch_crow(CC)); \
         hipError_t er = hipFuncSetAttribute(                                                 \
             reinterpret_cast<const void *>(&k_order_search<CC, TT, G>),                      \
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \

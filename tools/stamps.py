@@ -27,7 +27,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "level7":
     p = fa.level_params(7)
 if len(sys.argv) > 1 and sys.argv[1] == "search":
     p = fa.level_params(5, bits_per_sample=24, order_method=fa.OM_SEARCH, max_prediction_order=32, max_partition_order=8)
-pcm = fa.synth_pcm(2048, 4096, 2, p.bits_per_sample)
+nch = 2
+if len(sys.argv) > 1 and sys.argv[1] == "fixed":          # configs[0] on the GPU: mono, fixed orders 0..4
+    p = fa.level_params(2, block_size=4096, channels=1); nch = 1
+pcm = fa.synth_pcm(2048, 4096, nch, p.bits_per_sample)
 enc = fa.Encoder(p, max_frames=2048)
 for _ in range(3):
     out = enc.encode_subframes(pcm, 4096, want_residual=False)

@@ -744,7 +744,9 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
     // (s_setprio for the walk -- consumers ahead of the staging wave on their SIMD -- changed nothing:
     // 55.6 vs 56.1 us, round 3)
     const int pi = lane >> 5, sl = lane & 31;
-    const int l0 = grp.l0[wv], nch = grp.nch[wv];       // wave-uniform
+    // (selects, not grp.l0[wv]: a kernel argument indexed at run time is copied to scratch first)
+    const int l0 = wv == 0 ? grp.l0[0] : wv == 1 ? grp.l0[1] : wv == 2 ? grp.l0[2] : grp.l0[3];       // wave-uniform
+    const int nch = wv == 0 ? grp.nch[0] : wv == 1 ? grp.nch[1] : wv == 2 ? grp.nch[2] : grp.nch[3];
     const bool live = (sub0 + sl < nsub) && nch > 0;
     const int pib = pi ^ (l0 & 1);                      // parity array that holds d[p - l0]
     const int sft = (l0 + pib - pi) / 2;                // index shift inside that array

@@ -1330,9 +1330,12 @@ template <int C, int T, int MODE>
 // Waves per SIMD (the second launch bound; VGPR cap 4 -> 128, 5 -> 96).  The kernel is bound by
 // vector-ALU issue (PMC: ~850 VALU instructions per wave, > 80 % of the issue slots) with a
 // barrier after every phase, and a fifth workgroup per CU fills what the barriers leave idle:
-// the 256-thread instances with runs of 16 fit 96 VGPRs without scratch (the compiler takes 106
-// when allowed 128) and their LDS (31 KB at n = 4096) fits five times: configs[1] 63.1 -> 57.1 us
-// (round 2; round 1 had backed off to four at C >= 14 when the packed FIR first spilled).
+// the lean 256-thread instance with runs of 16 (MODE 0, the headline) fits 96 VGPRs without
+// scratch (the compiler takes 106 when allowed 128) and its LDS (31 KB at n = 4096) fits five
+// times: configs[1] 63.1 -> 57.1 us (round 2; round 1 had backed off to four at C >= 14 when the
+// packed FIR first spilled).  MODE 3 / MODE 1 at (16, 256) do spill a little at five (6 / 1
+// registers, 20 / 8 bytes of scratch: profiles/r03_kernel_resources.txt) and are still faster there
+// (configs[3] K3 342 -> 320 us, round 2).
 // Four where five would spill (the order-search instance MODE 2; runs of 18) or where the LDS
 // of a 512- / 1024-thread workgroup stops at four waves per SIMD anyway.
 // Geometry for n = 4096, measured: (C,T) = (16,256) 94 us, (8,512) 137, (4,1024)

@@ -1966,6 +1966,10 @@ bool fast_geometry(const fhip_params &p, int n, int *C, int *T)
         c = 3; t = 1 << lg;
         if (t > 1024) { c = 6; t >>= 1; }
         if (t > 1024) { c = 0; }
+        // 3072, 6144 (three / six eighths of a 4096 / 8192 block): runs of 12 in 256 / 512 threads -- a
+        // workgroup of 1024 threads per subframe left the CU to one or two subframes at a time
+        // (round 3: k_encode_pow2<3,1024> 84 us, <6,1024> 131 us per VBS batch of 1024 blocks)
+        if (lg == 10 || lg == 11) { c = 12; t = 1 << (lg - 2); }
     } else if ((odd == 5 || odd == 7) && (lg == 9 || lg == 10)) {
         // 2560, 3584, 5120, 7168: five or seven eighths of a 4096 / 8192 block, the pieces
         // the VBS splitter (vbs.c:36-83) makes most often besides the plain power-of-two ones
@@ -2065,6 +2069,8 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
         case 30512: LAUNCH_FAST(3, 512); break;
         case 31024: LAUNCH_FAST(3, 1024); break;
         case 61024: LAUNCH_FAST(6, 1024); break;
+        case 120256: LAUNCH_FAST(12, 256); break;
+        case 120512: LAUNCH_FAST(12, 512); break;
         default: return hipErrorInvalidValue;
         }
 #undef LAUNCH_FAST

@@ -1,12 +1,8 @@
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import flake_amd
-from ablate import run
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); 
+import bench, flake_amd
 P = flake_amd.level_params
-which = sys.argv[1]
-if which == "1152":
-    run("lvl2 n=1152", P(2), nframes=4096 * 4096 // 1152, steps=5)
-    run("lvl5max n=1152", P(5, block_size=1152, order_method=flake_amd.OM_MAX), nframes=4096 * 4096 // 1152, steps=5)
-else:
-    run("lvl5max n=4608", P(5, block_size=4608, order_method=flake_amd.OM_MAX), nframes=4096 * 4096 // 4608, steps=5)
-    run("lvl2 n=4608", P(2, block_size=4608), nframes=4096 * 4096 // 4608, steps=5)
+for n in (3072, 3584, 2560, 6144):
+    p = P(10, block_size=n, variable_block_size=0)
+    r = bench.subframe_case(0, f"n={n}", p, 1024 * 4096 // n, 10, cpu=False)
+    print(n, os.environ.get("FHIP_K3_GEOM"), r["ms_per_step"], r["kernel_ms"], flush=True)

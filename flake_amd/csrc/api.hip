@@ -897,15 +897,18 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
     if (lpc_path && fhip::autocorr_bins_supported(p.max_prediction_order, vb.n, 8)) {
         const bool prof = c->profiling;
         bool narrow[8];
-        // ---- K0 per bin ----
-        if (fan) HIP_TRY(c, fj.fork());
+        // ---- K0 per bin, back to back on the handle's stream (eight launches of ~10 us; fanned over the
+        // internal streams they ran in 55 us but the fork and the join around them cost 60: the kernel
+        // trace of a level-12 batch, round 3) ----
+        static const bool k0_fan = getenv("FHIP_VBS_K0_FAN") != nullptr;                 // measurements only
+        if (fan && k0_fan) HIP_TRY(c, fj.fork());
         for (int k = 7; k >= 0; k--) {
             const size_t sub0 = (size_t)vb.slot0[k] * nch;
             narrow[k] = fhip::narrow_rows_ok(p, hint_frames * (int)nch, vb.n[k], true, true);
             MaybeProf pr(c, prof, 0);
-            HIP_TRY(c, fhip::launch_prepare(pick_stream(k), p, pcm, vb.cap[k], vb.n[k], c->d_smp + vb.smp_off[k],
-                                            c->d_k0rec + sub0, false, narrow[k], c->d_frame_src + vb.slot0[k],
-                                            cnt_frames + k));
+            HIP_TRY(c, fhip::launch_prepare((fan && k0_fan) ? pick_stream(k) : c->stream, p, pcm, vb.cap[k], vb.n[k],
+                                            c->d_smp + vb.smp_off[k], c->d_k0rec + sub0, false, narrow[k],
+                                            c->d_frame_src + vb.slot0[k], cnt_frames + k));
         }
         HIP_TRY(c, fj.join());
         // ---- K1 (+ K2) over all bins, longest chains first ----
@@ -929,6 +932,10 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
         m1.wg0[8] = wg;
         const fhip::autocorr_lpc_out lo{p.lpc_precision, p.order_method, c->d_coefs, c->d_shift, c->d_opt, c->d_fin};
         {
+            // (orders above 12: the bins of six eighths and more as a launch of their own with two workgroups
+            // per tile -- even / odd lags, five chains per wave instead of nine -- beside the other bins' took
+            // K1 from 184 to 131 us in the kernel trace and the batch from 1.245 to 1.23 ms: within the
+            // noise, for a second fork / join; not kept)
             MaybeProf pr(c, prof, 1);
             HIP_TRY(c, fhip::launch_autocorr_bins(c->stream, m1, c->d_smp, p.max_prediction_order, c->d_autoc,
                                                   c->d_k0rec, lpc_tail ? &lo : nullptr));

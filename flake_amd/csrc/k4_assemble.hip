@@ -150,6 +150,7 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
     __shared__ int s_nseg, s_verbatim, s_hdr_bits;
     __shared__ long long s_total_bits;
     __shared__ uint16_t s_crc_tab[256];
+    __shared__ uint16_t s_crc_zk[3][256];        // CRC of byte x followed by 1, 2, 3 zero bytes (word steps below)
     __shared__ int s_info[FHIP_MAX_CH][8];       // type, type_code, order, shift, obits, wasted, rice_nbits, ch_mode
 
     const int tid = threadIdx.x;
@@ -173,6 +174,14 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
         s_info[tid][6] = i->rice_nbits; s_info[tid][7] = i->ch_mode;
     }
     __syncthreads();
+    {
+        uint16_t v = s_crc_tab[tid];
+#pragma unroll
+        for (int z = 0; z < 3; z++) {
+            v = (uint16_t)((v << 8) ^ s_crc_tab[v >> 8]);
+            s_crc_zk[z][tid] = v;                 // read first behind later barriers
+        }
+    }
 
     // ---- does the frame take the verbatim fallback? (encode.c:949) -----------
     if (tid == 0) {
@@ -359,9 +368,22 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
         const int s0 = max(e - L, 0);
         uint16_t c = 0;
         uint32_t wv = 0;
-        for (int bi = s0; bi < e; bi++) {
-            // the bytes were stored by other lanes of this workgroup: read past L1
-            if (bi == s0 || (bi & 3) == 0) wv = __hip_atomic_load(&out32[bi >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the bytes were stored by other lanes of this workgroup: read past L1)
+        int bi = s0;
+        for (; bi < e && (bi & 3) != 0; bi++) {                  // up to the first whole word
+            if (bi == s0) wv = __hip_atomic_load(&out32[bi >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t byte = (wv >> (8 * (bi & 3))) & 0xFFu;
+            c = (uint16_t)((c << 8) ^ s_crc_tab[((c >> 8) ^ byte) & 0xFFu]);
+        }
+        // four bytes a step: the state only meets the first two, the four table reads are independent
+        // (a byte a step is a dependent LDS read per byte: 512 in a row for a 20 KB frame)
+        for (; bi + 4 <= e; bi += 4) {
+            wv = __hip_atomic_load(&out32[bi >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t x0 = ((c >> 8) ^ wv) & 0xFFu, x1 = (c ^ (wv >> 8)) & 0xFFu;
+            c = (uint16_t)(s_crc_zk[2][x0] ^ s_crc_zk[1][x1] ^ s_crc_zk[0][(wv >> 16) & 0xFFu] ^ s_crc_tab[wv >> 24]);
+        }
+        for (; bi < e; bi++) {
+            if ((bi & 3) == 0) wv = __hip_atomic_load(&out32[bi >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t byte = (wv >> (8 * (bi & 3))) & 0xFFu;
             c = (uint16_t)((c << 8) ^ s_crc_tab[((c >> 8) ^ byte) & 0xFFu]);
         }

@@ -901,16 +901,39 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
         // internal streams they ran in 55 us but the fork and the join around them cost 60: the kernel
         // trace of a level-12 batch, round 3) ----
         static const bool k0_fan = getenv("FHIP_VBS_K0_FAN") != nullptr;                 // measurements only
-        if (fan && k0_fan) HIP_TRY(c, fj.fork());
-        for (int k = 7; k >= 0; k--) {
-            const size_t sub0 = (size_t)vb.slot0[k] * nch;
-            narrow[k] = fhip::narrow_rows_ok(p, hint_frames * (int)nch, vb.n[k], true, true);
+        static const bool k0_per_bin = getenv("FHIP_VBS_K0_PER_BIN") != nullptr;         // measurements only
+        for (int k = 0; k < 8; k++) narrow[k] = fhip::narrow_rows_ok(p, hint_frames * (int)nch, vb.n[k], true, true);
+        if (!k0_per_bin && !k0_fan && fhip::prepare_bins_supported(p, vb.n, 8)) {
+            // stereo: one launch over all bins, the longest pieces first
+            fhip::MultiBin m0{};
+            m0.nbins = 8;
+            m0.cnt = cnt_frames;
+            int wg = 0;
+            for (int j = 0; j < 8; j++) {
+                const int k = 7 - j;
+                m0.cnt_ix[j] = k;
+                m0.wg0[j] = wg;
+                wg += fhip::prepare_bins_workgroups(vb.n[k], vb.cap[k]);
+                m0.n[j] = vb.n[k];
+                m0.unit0[j] = vb.slot0[k];
+                m0.cap[j] = vb.cap[k];
+                m0.narrow[j] = narrow[k] ? 1 : 0;
+                m0.smp_off[j] = vb.smp_off[k];
+            }
+            m0.wg0[8] = wg;
             MaybeProf pr(c, prof, 0);
-            HIP_TRY(c, fhip::launch_prepare((fan && k0_fan) ? pick_stream(k) : c->stream, p, pcm, vb.cap[k], vb.n[k],
-                                            c->d_smp + vb.smp_off[k], c->d_k0rec + sub0, false, narrow[k],
-                                            c->d_frame_src + vb.slot0[k], cnt_frames + k));
+            HIP_TRY(c, fhip::launch_prepare_bins(c->stream, p, pcm, m0, c->d_smp, c->d_k0rec, c->d_frame_src));
+        } else {
+            if (fan && k0_fan) HIP_TRY(c, fj.fork());
+            for (int k = 7; k >= 0; k--) {
+                const size_t sub0 = (size_t)vb.slot0[k] * nch;
+                MaybeProf pr(c, prof, 0);
+                HIP_TRY(c, fhip::launch_prepare((fan && k0_fan) ? pick_stream(k) : c->stream, p, pcm, vb.cap[k], vb.n[k],
+                                                c->d_smp + vb.smp_off[k], c->d_k0rec + sub0, false, narrow[k],
+                                                c->d_frame_src + vb.slot0[k], cnt_frames + k));
+            }
+            HIP_TRY(c, fj.join());
         }
-        HIP_TRY(c, fj.join());
         // ---- K1 (+ K2) over all bins, longest chains first ----
         const bool lpc_tail = p.max_prediction_order <= 12 && getenv("FHIP_NO_LPC_TAIL") == nullptr;
         fhip::MultiBin m1{};

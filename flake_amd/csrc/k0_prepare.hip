@@ -304,26 +304,24 @@ void k_prepare_multi_reg(const int32_t *__restrict__ pcm, int32_t *__restrict__ 
 // waves per frame three quarters of the threads idled and K0 took 5.7x its time per
 // sample).  Thread t of a frame owns quads t + 64 WPF m.
 template <int M, int WPF, bool APPLY>
-__global__ __launch_bounds__(NT)
 // allow_narrow: a channel whose samples (after the shift) all fit 16 bits is stored
 // as int16[n] at the start of its row (info.reserved = 1 tells K1's producers and
 // K3's staging; K3 resets the field) -- half the bytes written here and read there.
-void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
-                      fhip_subframe_info *__restrict__ info, int n, int bps, int estimate,
-                      int allow_narrow, int nframes, const long long *__restrict__ frame_src,
-                      const int32_t *__restrict__ dev_frames)
+// blk: the workgroup's index within its batch (or within its bin of a ragged batch).
+__device__ __forceinline__
+void prepare_stereo_body(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
+                         fhip_subframe_info *__restrict__ info, int n, int bps, int estimate,
+                         int allow_narrow, int nframes, const long long *__restrict__ frame_src, int blk)
 {
     __shared__ unsigned long long s_sum[4][4];
     __shared__ uint32_t s_or[4][4];
-    __shared__ int s_mode;
-    nframes = dev_count(dev_frames, nframes);
-    if ((int)blockIdx.x * (4 / WPF) >= nframes) return;          // (a ragged batch's grid is its bin's capacity)
+    if (blk * (4 / WPF) >= nframes) return;                      // (a ragged batch's grid is its bin's capacity)
 
     constexpr int TF = WAVE * WPF;                       // threads per frame
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wb = (wv / WPF) * WPF;                     // first wave of this thread's frame
     const int tid = threadIdx.x - wb * WAVE;             // thread index inside the frame
-    const int fq = blockIdx.x * (4 / WPF) + wv / WPF;
+    const int fq = blk * (4 / WPF) + wv / WPF;
     const bool fvalid = fq < nframes;                    // a partial last workgroup computes a copy of the last frame
     const int f = min(fq, nframes - 1);
     const int4 *src = reinterpret_cast<const int4 *>(pcm + (frame_src ? (size_t)frame_src[f] : (size_t)f * n * 2));
@@ -504,6 +502,57 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
     }
 }
 
+template <int M, int WPF, bool APPLY>
+__global__ __launch_bounds__(NT)
+void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
+                      fhip_subframe_info *__restrict__ info, int n, int bps, int estimate,
+                      int allow_narrow, int nframes, const long long *__restrict__ frame_src,
+                      const int32_t *__restrict__ dev_frames)
+{
+    prepare_stereo_body<M, WPF, APPLY>(pcm, smp, info, n, bps, estimate, allow_narrow,
+                                       dev_count(dev_frames, nframes), frame_src, (int)blockIdx.x);
+}
+
+// quads per thread M and waves per frame WPF of a stereo block of n samples (n % 4 == 0, n <= 8192): the
+// fullest threads win for short blocks.  One rule for the launcher and for the kernel of a ragged batch.
+#define FHIP_STEREO_GEOM(QUADS_, DO_)                                                       \
+    do {                                                                                    \
+        if ((QUADS_) <= 64) DO_(1, 1);              /* n <= 256: one wave per frame */      \
+        else if ((QUADS_) <= 128) DO_(1, 2);        /* 512 */                               \
+        else if ((QUADS_) <= 192) DO_(3, 1);        /* 576, 768 */                          \
+        else if ((QUADS_) <= NT) DO_(1, 4);         /* 1024 */                              \
+        else if ((QUADS_) <= 320) DO_(5, 1);        /* 1152 */                              \
+        else if ((QUADS_) <= 2 * NT) DO_(2, 4);                                             \
+        else if ((QUADS_) <= 3 * NT) DO_(3, 4);     /* 2304, 3072 */                        \
+        else if ((QUADS_) <= 4 * NT) DO_(4, 4);                                             \
+        else if ((QUADS_) <= 5 * NT) DO_(5, 4);     /* 4608 */                              \
+        else DO_(8, 4);                             /* 8192 */                              \
+    } while (0)
+
+// K0 for every bin of a ragged (variable-block-size) stereo batch in ONE launch (kernels.h: MultiBin;
+// unit0 = the bin's first frame slot, cnt = live frames per bin on the device): eight launches of
+// ~10 us each were 55-80 us of a batch whose other stages already run once over all bins.
+__global__ __launch_bounds__(NT, 2)          // (the variant of eight quads per thread holds 96 samples in registers)
+void k_prepare_stereo_bins(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
+                           fhip_subframe_info *__restrict__ info, int bps, int estimate,
+                           const long long *__restrict__ frame_src, MultiBin mb)
+{
+    int blk = blockIdx.x;
+    const int k = find_bin(mb, blk);
+    blk -= mb.wg0[k];
+    const int n = mb.n[k];
+    const int nframes = __builtin_amdgcn_readfirstlane(mb.cnt[mb.cnt_ix[k]]);
+    const size_t f0 = (size_t)mb.unit0[k];
+    int32_t *smp_k = smp + mb.smp_off[k];
+    fhip_subframe_info *info_k = info + f0 * 2;
+    const long long *src_k = frame_src + f0;
+    const int nar = mb.narrow[k];
+    const int quads = n >> 2;
+#define BODY_(M_, W_) prepare_stereo_body<M_, W_, true>(pcm, smp_k, info_k, n, bps, estimate, nar, nframes, src_k, blk)
+    FHIP_STEREO_GEOM(quads, BODY_);
+#undef BODY_
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -524,17 +573,9 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
         if (decide_only) {
             if (quads <= NT) LAUNCH_PS(1, 4, false); else if (quads <= 2 * NT) LAUNCH_PS(2, 4, false); else LAUNCH_PS(4, 4, false);
         } else {
-            // quads per thread M and waves per frame: the fullest threads win for short blocks
-            if (quads <= 64) LAUNCH_PS(1, 1, true);              // n <= 256: one wave per frame
-            else if (quads <= 128) LAUNCH_PS(1, 2, true);        // 512
-            else if (quads <= 192) LAUNCH_PS(3, 1, true);        // 576, 768
-            else if (quads <= NT) LAUNCH_PS(1, 4, true);         // 1024
-            else if (quads <= 320) LAUNCH_PS(5, 1, true);        // 1152
-            else if (quads <= 2 * NT) LAUNCH_PS(2, 4, true);
-            else if (quads <= 3 * NT) LAUNCH_PS(3, 4, true);     // 2304, 3072
-            else if (quads <= 4 * NT) LAUNCH_PS(4, 4, true);
-            else if (quads <= 5 * NT) LAUNCH_PS(5, 4, true);     // 4608
-            else LAUNCH_PS(8, 4, true);                          // 8192
+#define LAUNCH_PSA(M_, W_) LAUNCH_PS(M_, W_, true)
+            FHIP_STEREO_GEOM(quads, LAUNCH_PSA);
+#undef LAUNCH_PSA
         }
 #undef LAUNCH_PS
         return hipGetLastError();
@@ -577,6 +618,34 @@ hipError_t launch_prepare(hipStream_t st, const fhip_params &p, const int32_t *p
     if (er != hipSuccess) return er;
     hipLaunchKernelGGL(k_prepare<true>, dim3(blocks), dim3(NT), lds, st, pcm, smp, info, n, nch,
                        p.bits_per_sample, p.stereo_method == 1 ? 1 : 0, frame_src, dev_frames);
+    return hipGetLastError();
+}
+
+bool prepare_bins_supported(const fhip_params &p, const int *n, int nbins)
+{
+    if (p.channels != 2) return false;
+    for (int k = 0; k < nbins; k++) if ((n[k] & 3) != 0 || n[k] > 8192 || n[k] < 4) return false;
+    return true;
+}
+
+int prepare_bins_workgroups(int n, int cap)
+{
+    int wpf = 4;
+#define WPF_(M_, W_) wpf = W_
+    FHIP_STEREO_GEOM(n >> 2, WPF_);
+#undef WPF_
+    const int fpw = 4 / wpf;                       // frames per workgroup
+    return (cap + fpw - 1) / fpw;
+}
+
+hipError_t launch_prepare_bins(hipStream_t st, const fhip_params &p, const int32_t *pcm, const MultiBin &mb,
+                               int32_t *smp, fhip_subframe_info *info, const long long *frame_src)
+{
+    if (!prepare_bins_supported(p, mb.n, mb.nbins) || !frame_src) return hipErrorInvalidValue;
+    const int blocks = mb.wg0[mb.nbins];
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prepare_stereo_bins, dim3(blocks), dim3(NT), 0, st, pcm, smp, info, p.bits_per_sample,
+                       p.stereo_method == 1 ? 1 : 0, frame_src, mb);
     return hipGetLastError();
 }
 

@@ -468,7 +468,7 @@ def vbs_case(dev_index, level, nblocks, steps, cpu=True):
         "dominant_kernel": dom,
         "algorithmic_bytes": alg,
         "hbm_frac_step": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-        "note": "eight bins of equal piece length; K1 / K2 / K4 one launch over all bins, K0 / order search / "
+        "note": "eight bins of equal piece length; K0 / K1 / K2 / K4 one launch over all bins, order search / "
                 "K3 per bin on three internal streams; no host synchronisation inside",
     }
     enc.close()

@@ -73,7 +73,7 @@ __host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[16
     off[9] = o; o += 4 * 32;
     off[10] = o; o += 4 * 32;
     o = (o + 15) & ~(size_t)15;
-    off[11] = o; o += mm_n ? 0 : 2 * 32 * 32 + 4 * 32;          // every candidate row as int16, the shifts (the
+    off[11] = o; o += mm_n ? 0 : 2 * 32 * 32 + 4 * 64;          // every candidate row as int16, shifts, partition-order windows (the
                                                                 // matrix instances keep their LDS for three workgroups per CU)
     o = (o + 15) & ~(size_t)15;
     off[12] = off[13] = off[14] = off[15] = 0;
@@ -163,16 +163,18 @@ __device__ __forceinline__ uint32_t wave_candidate_bits(const uint32_t *__restri
         }
         // ---- levels 5 .. 0: a 127-entry heap of this wave (entry 2^p - 1 + j = node j of level p) ----
         if (pmin <= 5) {
-            heap[63 + lane] = s6;
-#pragma unroll
-            for (int p = 5; p >= 0; p--) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (lane < (1 << p)) {
-                    const int c = (2 << p) - 1 + 2 * lane;
-                    heap[(1 << p) - 1 + lane] = heap[c] + heap[c + 1];
-                }
-            }
+            // the sums of levels 5 .. 0 by a pyramid in registers (after step s, lanes = 0 mod 2^s hold level
+            // 6 - s), ONE trip through the heap to hand node q to lane q (round 3; before: six dependent
+            // store / load steps through LDS on the round's critical path)
+            unsigned long long v = s6;
+#define HEAP_STORE(S_) do { if ((lane & ((1 << (S_)) - 1)) == 0) heap[(1 << (6 - (S_))) - 1 + (lane >> (S_))] = v; } while (0)
+            v += row_shl_u64<1>(v); HEAP_STORE(1);
+            v += row_shl_u64<2>(v); HEAP_STORE(2);
+            v += row_shl_u64<4>(v); HEAP_STORE(3);
+            v += row_shl_u64<8>(v); HEAP_STORE(4);
+            v += __shfl_down(v, 16, WAVE); HEAP_STORE(5);
+            v += __shfl_down(v, 32, WAVE); HEAP_STORE(6);
+#undef HEAP_STORE
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int p = ilog2_dev((uint32_t)(lane + 1));           // lanes 0..62: node `lane`, level p
@@ -547,7 +549,11 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             *reinterpret_cast<uint2 *>(crows + 4 * q) =
                 make_uint2(((uint32_t)v.x & 0xFFFFu) | ((uint32_t)v.y << 16), ((uint32_t)v.z & 0xFFFFu) | ((uint32_t)v.w << 16));
         }
-        if (tid < FHIP_MAX_ORDER) cshifts[tid] = shift_all[(size_t)s * FHIP_MAX_ORDER + tid];
+        if (tid < FHIP_MAX_ORDER) {
+            cshifts[tid] = shift_all[(size_t)s * FHIP_MAX_ORDER + tid];
+            // rice.c:148-155 for every order, once (an integer division each: off the rounds' path)
+            cshifts[32 + tid] = clamp_porder(P.min_partition_order, n, tid + 1) | (clamp_porder(P.max_partition_order, n, tid + 1) << 8);
+        }
     }
     if (tid < 2) l.misc[24 + tid] = 0;                 // rounds: "a thread sum left 32 bits", per round parity
 
@@ -651,20 +657,23 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             // same for EVERY order that could be the winner by then (the winner on entry or any
             // candidate of the round), while they fit G.  The replay below then visits exactly the
             // reference's candidates in the reference's order.  All scalar (uniform) arithmetic.
+            // Lane b (mod 32) works out the step's set for winner b, a read-lane and a ballot compare them:
+            // the scalar loops over (possible winner x three orders) were ~500 dependent scalar
+            // instructions per round on the round's critical path.
             ng = 0;
             uint32_t poss = 1u << lg_best, seen = lg_seen;
             int st = lg_step;
+            const int bl = lane & 31;
             while (st > 0) {
-                uint32_t set0 = 0;
-                bool first = true, same = true;
-                for (uint32_t pm = poss; pm; pm &= pm - 1) {
-                    const int b = __builtin_ctz(pm);
-                    uint32_t sb = 0;
-                    for (int i = b - st; i <= b + st; i += st)
-                        if (i >= min_order - 1 && i < max_order && !((seen >> i) & 1u)) sb |= 1u << i;
-                    if (first) { set0 = sb; first = false; }
-                    else if (sb != set0) same = false;
+                uint32_t sb = 0;
+#pragma unroll
+                for (int d = -1; d <= 1; d++) {
+                    const int i = bl + d * st;
+                    const bool in = i >= min_order - 1 && i < max_order;
+                    if (in && !((seen >> (i & 31)) & 1u)) sb |= 1u << (i & 31);
                 }
+                const uint32_t set0 = (uint32_t)__builtin_amdgcn_readlane((int)sb, __builtin_ctz(poss));
+                const bool same = __ballot(((poss >> bl) & 1u) != 0u && sb != set0) == 0ull;
                 const int cnt = __builtin_popcount(set0);
                 if (!same || ng + cnt > G) break;          // (never on a round's first step: one winner, <= 3 orders)
                 if (ng > 0 && !LOG_MERGE) break;
@@ -699,8 +708,9 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                 l.rowi[g * 4 + 0] = cand;
                 l.rowi[g * 4 + 1] = !(g < ng) ? 0 : MM ? srow[cand] : cshifts[cand];
                 l.rowi[g * 4 + 2] = sa;
-                // rice.c:148-155 for this order, once (an integer division each)
-                l.rowi[g * 4 + 3] = clamp_porder(e.pmin_req, n, ord) | (clamp_porder(e.pmax_req, n, ord) << 8);
+                // rice.c:148-155 for this order
+                if constexpr (MM) l.rowi[g * 4 + 3] = clamp_porder(e.pmin_req, n, ord) | (clamp_porder(e.pmax_req, n, ord) << 8);
+                else l.rowi[g * 4 + 3] = cshifts[32 + cand];
             }
         }
         if (tid < G * 12) l.lvl_bits[par * G * 12 + tid] = 0;
@@ -890,14 +900,16 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         // round; the general way is the rare fall-back).
         __syncthreads();
         if (is_log) {
-            // optimize.c:249-259: the step's orders in ascending order against the winner so far
+            // optimize.c:249-259: the step's orders in ascending order against the winner so far.  The table
+            // is read once (lane i holds bits[i]); its entries come by read-lane, not by LDS round trips.
+            const int tr = (int)l.trial[lane & 31];
             for (int sidx = 0; sidx < lg_merged; sidx++) {
                 const int last = lg_best;
                 for (int i = last - lg_step; i <= last + lg_step; i += lg_step) {
                     if (i < min_order - 1 || i >= max_order || ((lg_seen >> i) & 1u)) continue;
-                    const uint32_t cur = ((lg_seen >> lg_best) & 1u) ? l.trial[lg_best] : 0xFFFFFFFFu;
+                    const uint32_t cur = ((lg_seen >> lg_best) & 1u) ? (uint32_t)__builtin_amdgcn_readlane(tr, lg_best) : 0xFFFFFFFFu;
                     lg_seen |= 1u << i;
-                    if (l.trial[i] < cur) lg_best = i;
+                    if ((uint32_t)__builtin_amdgcn_readlane(tr, i) < cur) lg_best = i;
                 }
                 lg_step >>= 1;
             }

@@ -3,6 +3,10 @@
 #include "device_util.h"
 #include "k3_common.h"
 
+#ifdef FHIP_STAMPS
+FHIP_DEFINE_STAMP_READER(fhip_debug_read_stamps_k3s)     // tools/stamps_k3s.py: phases of workgroup 0's rounds
+#endif
+
 namespace fhip {
 namespace {
 
@@ -86,6 +90,10 @@ __host__ __device__ inline size_t srch_lds_layout(size_t img_ints, size_t off[16
     return (o + 15) & ~(size_t)15;
 }
 
+
+// The first round of a LOG walk (optimize.c:240-261) depends on nothing but the order range: the host plans
+// it once per launch (log_plan_round0 below) instead of every workgroup on its critical path.
+struct LogPlan0 { uint32_t pack; int ng, merged; };
 
 // rice.c:105-187 for ONE candidate by ONE wave, from the finest-level sums a round of
 // k_order_search left in LDS (leaf[t] = the sum of thread t's run): no barrier, no atomics.  A lane
@@ -392,7 +400,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                     const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
                     int32_t *__restrict__ opt_all, int32_t *__restrict__ fin_all,
                     const fhip_subframe_info *__restrict__ prep, int narrow_ok,
-                    const int32_t *__restrict__ dev_sub, uint32_t *__restrict__ table_out)
+                    const int32_t *__restrict__ dev_sub, uint32_t *__restrict__ table_out, LogPlan0 lg0)
 {
     static_assert(C % 4 == 0 && T >= 128 && (T & (T - 1)) == 0, "k_order_search: runs of whole groups of four");
     if (dev_sub && (int)blockIdx.x >= dev_count(dev_sub, 0)) return;
@@ -557,6 +565,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     }
     if (tid < 2) l.misc[24 + tid] = 0;                 // rounds: "a thread sum left 32 bits", per round parity
 
+    STAMP(0);
     const int omethod = P.order_method;
     const int min_order = P.min_prediction_order, max_order = P.max_prediction_order;
     const int32_t *crow_base = coefs_all + (size_t)s * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
@@ -610,6 +619,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 #pragma unroll
     for (int w = 0; w < NW; w++) { any_differs |= l.misc[4 + w] & 1; all_fit &= l.misc[4 + w]; }
     const bool constant = (__builtin_amdgcn_readfirstlane(any_differs) == 0);
+    STAMP(1);
     const int nc = __builtin_amdgcn_readfirstlane(l.misc[0]);
     bool mm_done = false;
     if constexpr (MM) {
@@ -651,41 +661,30 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             if (ng <= 0) break;
         } else {
             // The next steps' orders not yet evaluated (last - step, last, last + step).  What a step
-            // visits depends on the winner so far -- but often not at all: from order index 3 of
-            // 1..12 the walk visits 3, then 11, then 7 whoever wins.  So a round takes the first
-            // step that has candidates and then every following step whose candidate set is the
-            // same for EVERY order that could be the winner by then (the winner on entry or any
-            // candidate of the round), while they fit G.  The replay below then visits exactly the
-            // reference's candidates in the reference's order.  All scalar (uniform) arithmetic.
-            // Lane b (mod 32) works out the step's set for winner b, a read-lane and a ballot compare them:
-            // the scalar loops over (possible winner x three orders) were ~500 dependent scalar
-            // instructions per round on the round's critical path.
+            // visits depends on the winner so far -- but at the start often not at all: from order index 3
+            // of 1..12 the walk visits 3, then 11, then 7 whoever wins; log_plan_round0 (below, on the host)
+            // merges such steps into round 0.  The replay behind every round then visits exactly the
+            // reference's candidates in the reference's order.
+            // Round 0 comes planned from the host (lg0).  Later rounds take ONE step -- whether further steps could
+            // be merged depends on this round's winner, and in practice they cannot --: the orders
+            // last - step, last, last + step not yet evaluated, after the steps that have none.  Scalar, ~30
+            // instructions (round 3: the general merging planner cost every round 1.5-3 k cycles of its path).
             ng = 0;
-            uint32_t poss = 1u << lg_best, seen = lg_seen;
-            int st = lg_step;
-            const int bl = lane & 31;
-            while (st > 0) {
-                uint32_t sb = 0;
-#pragma unroll
-                for (int d = -1; d <= 1; d++) {
-                    const int i = bl + d * st;
-                    const bool in = i >= min_order - 1 && i < max_order;
-                    if (in && !((seen >> (i & 31)) & 1u)) sb |= 1u << (i & 31);
+            if (round == 0) {
+                ng = lg0.ng; lg_pack = lg0.pack; lg_merged = lg0.merged;
+            } else {
+                int st = lg_step;
+                while (st > 0 && ng == 0) {
+                    for (int i = lg_best - st; i <= lg_best + st; i += st)
+                        if (i >= min_order - 1 && i < max_order && !((lg_seen >> i) & 1u)) lg_pack |= (uint32_t)i << (5 * ng++);
+                    lg_merged++;
+                    st >>= 1;
                 }
-                const uint32_t set0 = (uint32_t)__builtin_amdgcn_readlane((int)sb, __builtin_ctz(poss));
-                const bool same = __ballot(((poss >> bl) & 1u) != 0u && sb != set0) == 0ull;
-                const int cnt = __builtin_popcount(set0);
-                if (!same || ng + cnt > G) break;          // (never on a round's first step: one winner, <= 3 orders)
-                if (ng > 0 && !LOG_MERGE) break;
-                for (uint32_t m = set0; m; m &= m - 1) lg_pack |= (uint32_t)__builtin_ctz(m) << (5 * ng++);
-                seen |= set0;
-                poss |= set0;
-                lg_merged++;
-                st >>= 1;
             }
             if (ng == 0) break;                            // every step consumed, nothing left to visit
         }
         const int par = round & 1;
+        STAMP(2 + 6 * (round & 3));
         // ---- the round's rows: doubles, int16 pairs, sum |coef|, shift ----
         // (the LOG walk planned and replayed by wave 0 alone, with the rows staged by that wave, saved
         // a third of the kernel's scalar instructions and made it SLOWER -- level 8's search 264 -> 276 us:
@@ -717,6 +716,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         if (tid < G) l.lvl_meth[par * G + tid] = 0;
         if (tid == 0) l.misc[24 + (par ^ 1)] = 0;
         __syncthreads();
+        STAMP(3 + 6 * (round & 3));
 
         // The search behind the thread sums, two ways.  Leaf mode (T <= 512): the thread sums
         // -- the finest partition sums there are, T of them -- go to LDS as 32-bit leaves and
@@ -813,7 +813,9 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 #undef SPYR_STORE
             if (lane == 0) l.wtot[g * 16 + wv] = v;
         }
+        STAMP(4 + 6 * (round & 3));
         __syncthreads();
+        STAMP(5 + 6 * (round & 3));
         if (leaf_mode) {
             if (l.misc[24 + par] != 0) { leaf_mode = false; continue; }      // workgroup-uniform
             // one wave per candidate (two candidates per wave where the workgroup has only two waves)
@@ -824,6 +826,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                                                            pmm >> 8, e.obits, e.precision, lane);
                 if (lane == 0) l.trial[ord - 1] = b;
             }
+            STAMP(6 + 6 * (round & 3));
             break;
         }
 
@@ -899,6 +902,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         // node pass's barrier, and the next round's row staging would overwrite it (one barrier per
         // round; the general way is the rare fall-back).
         __syncthreads();
+        STAMP(7 + 6 * (round & 3));
         if (is_log) {
             // optimize.c:249-259: the step's orders in ascending order against the winner so far.  The table
             // is read once (lane i holds bits[i]); its entries come by read-lane, not by LDS round trips.
@@ -919,6 +923,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     }
     __syncthreads();
 
+    STAMP(30);
     // ---- the method's walk over the table (optimize.c:201-261) ----
     if (tid == 0) {
         int best = 0;
@@ -970,6 +975,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             opt_all[s] = order;
         }
     }
+    STAMP(31);
 }
 
 }  // namespace
@@ -978,6 +984,34 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
 // are 256 leaves of a whole number of sample pairs: the power-of-two blocks from 2048 up (runs
 // of 8 or 16) and every piece the VBS splitter makes of a 4096 or 8192 block (k eighths: 256
 // level-8 partitions of 2k or 4k samples; vbs.c:36-83).
+// Round 0 of the LOG walk: the first step that has candidates and then every following step whose
+// candidate set is the same for EVERY order that could be the winner by then (the winner on entry or any
+// candidate of the round), while they fit G rows.
+static LogPlan0 log_plan_round0(int min_order, int max_order, int G)
+{
+    LogPlan0 r{0u, 0, 0};
+    uint32_t poss = 1u << (min_order - 1 + (max_order - min_order) / 3), seen = 0;
+    for (int st = 16; st > 0; st >>= 1) {
+        uint32_t set0 = 0;
+        bool first = true, same = true;
+        for (uint32_t pm = poss; pm; pm &= pm - 1) {
+            const int b = __builtin_ctz(pm);
+            uint32_t sb = 0;
+            for (int i = b - st; i <= b + st; i += st)
+                if (i >= min_order - 1 && i < max_order && !((seen >> i) & 1u)) sb |= 1u << i;
+            if (first) { set0 = sb; first = false; }
+            else if (sb != set0) same = false;
+        }
+        const int cnt = __builtin_popcount(set0);
+        if (!same || r.ng + cnt > G) break;           // (never on the first step: one winner, <= 3 orders)
+        for (uint32_t m = set0; m; m &= m - 1) r.pack |= (uint32_t)__builtin_ctz(m) << (5 * r.ng++);
+        seen |= set0;
+        poss |= set0;
+        r.merged++;
+    }
+    return r;
+}
+
 static bool search_geometry(int n, int *C, int *T)
 {
     if (n == 16384) { *C = 16; *T = 1024; return true; }
@@ -1010,6 +1044,7 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
     if (!order_search_supported(p, n) || !search_geometry(n, &fc, &ft)) return hipErrorInvalidValue;
     constexpr int G = 4;
     size_t off[16];
+    const LogPlan0 lg0 = (p.order_method == 6) ? log_plan_round0(p.min_prediction_order, p.max_prediction_order, G) : LogPlan0{0u, 0, 0};
     // SEARCH on 4096-sample blocks: the FIRs on the int8 matrix pipe (samples beyond 24 bits, constant
     // subframes and the other methods take the vector way inside the same kernel)
     static const bool no_mm = getenv("FHIP_NO_MM") != nullptr;              // measurements only
@@ -1024,7 +1059,7 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_order_search<CC, TT, G, true>), dim3(nsub), dim3(TT), lds, st, p, n, smp, coefs, \
-                           shift, opt_order, fin, prep, narrow_ok ? 1 : 0, dev_sub, table_out); \
+                           shift, opt_order, fin, prep, narrow_ok ? 1 : 0, dev_sub, table_out, lg0); \
         return hipGetLastError();                                                            \
     } while (0)
         switch (fc * 10000 + ft) {
@@ -1048,7 +1083,7 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         if (er != hipSuccess) return er;                                                     \
         hipLaunchKernelGGL((k_order_search<CC, TT, G>), dim3(nsub), dim3(TT), lds, st, p, n, \
-                           smp, coefs, shift, opt_order, fin, prep, narrow_ok ? 1 : 0, dev_sub, table_out); \
+                           smp, coefs, shift, opt_order, fin, prep, narrow_ok ? 1 : 0, dev_sub, table_out, lg0); \
     } while (0)
     switch (fc * 10000 + ft) {
     case 160256: LAUNCH_SRCH(16, 256); break;

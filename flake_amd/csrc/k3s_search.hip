@@ -907,13 +907,15 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             // optimize.c:249-259: the step's orders in ascending order against the winner so far.  The table
             // is read once (lane i holds bits[i]); its entries come by read-lane, not by LDS round trips.
             const int tr = (int)l.trial[lane & 31];
+            // bits[] of the winner so far (optimize.c:243: UINT32_MAX until it has been evaluated itself)
+            uint32_t cur = ((lg_seen >> lg_best) & 1u) ? (uint32_t)__builtin_amdgcn_readlane(tr, lg_best) : 0xFFFFFFFFu;
             for (int sidx = 0; sidx < lg_merged; sidx++) {
                 const int last = lg_best;
                 for (int i = last - lg_step; i <= last + lg_step; i += lg_step) {
                     if (i < min_order - 1 || i >= max_order || ((lg_seen >> i) & 1u)) continue;
-                    const uint32_t cur = ((lg_seen >> lg_best) & 1u) ? (uint32_t)__builtin_amdgcn_readlane(tr, lg_best) : 0xFFFFFFFFu;
                     lg_seen |= 1u << i;
-                    if ((uint32_t)__builtin_amdgcn_readlane(tr, i) < cur) lg_best = i;
+                    const uint32_t bi = (uint32_t)__builtin_amdgcn_readlane(tr, i);
+                    if (bi < cur) { lg_best = i; cur = bi; }
                 }
                 lg_step >>= 1;
             }
@@ -959,7 +961,9 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         const int best = l.misc[1];
         const int order = best + 1;
         int32_t *f = fin_all + (size_t)s * FIN_STRIDE;
-        const int32_t cv = (tid < order) ? crow_base[best * FHIP_MAX_ORDER + tid] : 0;
+        // (the row from LDS where it lies there: no global load at the end of the workgroup's path)
+        const int32_t cv = !(tid < order) ? 0 : MM ? crow_base[best * FHIP_MAX_ORDER + tid]
+                                                     : (int32_t)crows[best * FHIP_MAX_ORDER + tid];
         f[tid] = cv;
         int32_t sa = cv < 0 ? -cv : cv;
         sa += __shfl_xor(sa, 1, WAVE); sa += __shfl_xor(sa, 2, WAVE);
@@ -969,7 +973,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
         if (tid < 16) reinterpret_cast<double *>(f + FIN_DBL)[tid] = (double)cv;
         if (tid < 8 && (tid & 1) == 0) f[FIN_PAIRS + (tid >> 1)] = (nb & 0xFFFF) | (int32_t)((uint32_t)cv << 16);
         if (tid == 0) {
-            f[32] = srow[best];
+            f[32] = MM ? srow[best] : cshifts[best];
             f[33] = order;
             f[34] = sa;
             opt_all[s] = order;

@@ -184,15 +184,47 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
     }
 
     // ---- does the frame take the verbatim fallback? (encode.c:949) -----------
-    if (tid == 0) {
-        // frame header (encode.c:718-764) + CRC-8
-        MiniSink hs{s_hdr, 0};
-        int bs0 = -1, bs1 = -1;
+    // The frame's length follows from lengths alone; the header's bytes (below, thread 64) and the
+    // subframe prefixes (threads 0 .. channels-1) are then written side by side, in different waves.
+    int bs0 = -1, bs1 = -1;
+    {
         const int bs_tab[15] = {0, 192, 576, 1152, 2304, 4608, 0, 0, 256, 512, 1024, 2048, 4096, 8192, 16384};
         for (int q = 0; q < 15; q++) if (n == bs_tab[q]) { bs0 = q; break; }
         if (bs0 < 0) { bs0 = (n <= 256) ? 6 : 7; bs1 = n - 1; }
+    }
+    const uint32_t number = numbers ? numbers[f] : number_base + (uint32_t)f * number_step;
+    if (tid == 0) {
+        // header length: 32 fixed bits, the UTF-8 style number (encode.c:696-716), the optional block
+        // size / sample rate fields, CRC-8
+        const int nbytes = (number < 0x80) ? 1 : (ilog2_dev(number) + 4) / 5;
+        const int hdr_bits = 32 + 8 * nbytes + (bs1 >= 0 ? (bs1 < 256 ? 8 : 16) : 0) +
+                             (sr_code1 > 0 ? (sr_code1 < 256 ? 8 : 16) : 0) + 8;
+        s_hdr_bits = hdr_bits;
+        long long bits = hdr_bits;
+        int verb = 0;
+        for (int c = 0; c < nch; c++) {
+            const int type = s_info[c][0], order = s_info[c][2], obits = s_info[c][4];
+            const int wasted = s_info[c][5], rn = s_info[c][6];
+            bits += 8 + (wasted ? wasted : 0);
+            if (type == FHIP_SUB_CONSTANT) bits += obits;
+            else if (type == FHIP_SUB_VERBATIM) bits += (long long)n * obits;
+            else {
+                if (rn < 0) verb = 1;
+                bits += (long long)order * obits + rn;
+                if (type == FHIP_SUB_LPC) bits += 9 + order * P.lpc_precision;
+            }
+        }
+        const long long bytes = ((bits + 7) >> 3) + 2;
+        if (bytes > verbatim_size) verb = 1;
+        s_verbatim = verb;
+    }
+    __syncthreads();
+    const int verbatim = s_verbatim;
+
+    if (tid == WAVE) {
+        // frame header (encode.c:718-764) + CRC-8
+        MiniSink hs{s_hdr, 0};
         const int ch_mode = s_info[0][7];
-        const uint32_t number = numbers ? numbers[f] : number_base + (uint32_t)f * number_step;
         hs.put(15, 0x7FFC);
         hs.put(1, (uint32_t)P.allow_vbs);
         hs.put(4, (uint32_t)bs0);
@@ -216,29 +248,7 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
             for (int b = 0; b < 8; b++) c8 = (uint8_t)((c8 & 0x80) ? ((c8 << 1) ^ 0x07) : (c8 << 1));
         }
         hs.put(8, c8);
-        s_hdr_bits = hs.bits();
-
-        long long bits = hs.bits();
-        int verb = 0;
-        for (int c = 0; c < nch; c++) {
-            const int type = s_info[c][0], order = s_info[c][2], obits = s_info[c][4];
-            const int wasted = s_info[c][5], rn = s_info[c][6];
-            bits += 8 + (wasted ? wasted : 0);
-            if (type == FHIP_SUB_CONSTANT) bits += obits;
-            else if (type == FHIP_SUB_VERBATIM) bits += (long long)n * obits;
-            else {
-                if (rn < 0) verb = 1;
-                bits += (long long)order * obits + rn;
-                if (type == FHIP_SUB_LPC) bits += 9 + order * P.lpc_precision;
-            }
-        }
-        const long long bytes = ((bits + 7) >> 3) + 2;
-        if (bytes > verbatim_size) verb = 1;
-        s_verbatim = verb;
     }
-    __syncthreads();
-    const int verbatim = s_verbatim;
-
     // ---- per-subframe prefixes (encode.c:871-905, 800-869), one thread each --
     if (tid < nch) {
         const fhip_subframe_info *i = &fi[tid];
@@ -616,7 +626,7 @@ void k_vbs_plan(const int32_t *__restrict__ nfr, const int32_t *__restrict__ siz
                 int32_t *__restrict__ cnt, int32_t *__restrict__ order, long long *__restrict__ frame_src,
                 long long *__restrict__ src_off, uint32_t *__restrict__ numbers, int32_t *__restrict__ first)
 {
-    __shared__ int32_t s_scan[9][PLAN_NT];
+    __shared__ int32_t s_wtot[9][PLAN_NT / 64 + 1];
     const int tid = threadIdx.x;
     const int per = (nblocks + PLAN_NT - 1) / PLAN_NT;
     const int b0 = min(tid * per, nblocks), b1 = min(b0 + per, nblocks);
@@ -634,26 +644,34 @@ void k_vbs_plan(const int32_t *__restrict__ nfr, const int32_t *__restrict__ siz
             c[8]++;
         }
     }
+    // nine exclusive scans over the 1024 threads: inside a wave by DPP, the sixteen wave totals by the
+    // first lanes of wave 0 -- two barriers (round 3; a Hillis-Steele scan through LDS took twenty)
+    const int lane = tid & 63, wv = tid >> 6;
+    int incl[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) s_scan[k][tid] = c[k];
-    __syncthreads();
-    for (int off = 1; off < PLAN_NT; off <<= 1) {                 // Hillis-Steele, nine rows at once
-        int v[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) v[k] = (tid >= off) ? s_scan[k][tid - off] : 0;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 9; k++) s_scan[k][tid] += v[k];
-        __syncthreads();
+    for (int k = 0; k < 9; k++) {
+        incl[k] = (int)wave_incl_scan_u32_dpp((uint32_t)c[k]);
+        if (lane == 63) s_wtot[k][wv] = incl[k];
     }
-    int run[9];
+    __syncthreads();
+    if (wv == 0) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) run[k] = s_scan[k][tid] - c[k];    // exclusive
+        for (int k = 0; k < 9; k++) {
+            const int t = (lane < PLAN_NT / 64) ? s_wtot[k][lane] : 0;
+            const int sc = (int)wave_incl_scan_u32_dpp((uint32_t)t);
+            if (lane < PLAN_NT / 64) s_wtot[k][lane] = sc - t;     // exclusive prefix of the wave
+            if (lane == PLAN_NT / 64 - 1) s_wtot[k][PLAN_NT / 64] = sc;   // the grand total
+        }
+    }
+    __syncthreads();
+    int run[9], total[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { run[k] = s_wtot[k][wv] + incl[k] - c[k]; total[k] = s_wtot[k][PLAN_NT / 64]; }
     if (tid == PLAN_NT - 1) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) { cnt[k] = s_scan[k][tid]; cnt[8 + k] = s_scan[k][tid] * nch; }
-        cnt[16] = s_scan[8][tid];
-        first[nblocks] = s_scan[8][tid];
+        for (int k = 0; k < 8; k++) { cnt[k] = total[k]; cnt[8 + k] = total[k] * nch; }
+        cnt[16] = total[8];
+        first[nblocks] = total[8];
     }
     for (int b = b0; b < b1; b++) {
         int f = nfr[b];

@@ -105,6 +105,21 @@ __device__ __forceinline__ uint32_t emit_fold32(int32_t x)
     return (uint32_t)v;
 }
 
+// (a << sh) + b and (a ^ b) + c as the one instruction each they are on gfx950; written out where the
+// compiler's own association of a longer expression costs instructions (k_order_search's matrix epilogue)
+__device__ __forceinline__ uint32_t lshl_add_u32(uint32_t a, uint32_t sh, uint32_t b)
+{
+    uint32_t d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(sh), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t xad_u32(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 __device__ __forceinline__ int32_t wrap_abs(int32_t a)
 {
     return a < 0 ? (int32_t)(0u - (uint32_t)a) : a;

@@ -259,7 +259,8 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
     typedef const int __attribute__((address_space(3))) *lds_i;
     constexpr int PB = mm_plane_bytes(C * T);
     constexpr int NW = T / WAVE;
-    const int lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the first block's branch below is wave-uniform
     const int g = lane >> 4, nn = lane & 15, h = g & 1;
     const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)planes;
     const unsigned xbase = (unsigned)(size_t)(const __attribute__((address_space(3))) int32_t *)img;
@@ -278,10 +279,12 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
         }
         const int cand = ct * 16 + nn;                       // this lane's candidate: order cand + 1
         const int sh = tab[cand], sh16 = 16 - sh, ord = cand + 1;
-#pragma unroll 1
-        for (int bq = 0; bq < 4; bq++) {
-            const int blk = wv * 4 + bq;                     // block of 16 leaves: threads 16 blk .. 16 blk + 15
-            const bool first = (blk == 0);                   // only the subframe's first block holds warm-up samples
+        // One block of 16 leaves (256 / 16 per wave and pass).  FIRST: the subframe's first block, the only one
+        // with warm-up samples -- its own copy of the code behind a wave-uniform branch, so that the other
+        // blocks carry no per-element masks (round 4: as selects in one body they were four vector
+        // instructions per element, 16 of the 76 a tile cost).
+        auto block = [&](auto first_c, const int blk) {
+            constexpr bool FIRST = decltype(first_c)::value;
             uint32_t acc[4] = {0, 0, 0, 0};
             // this lane's operand bytes of tile o: 16 bytes from byte rowoff + o of its plane -- a dword-aligned
             // start (C is a multiple of four), so the misalignment of a tile is the compile-time o & 3
@@ -353,15 +356,21 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
 #pragma unroll
                         for (int w = 0; w < 4; w++)
                             P[w] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Aop[w], Bop[w], v4i{0, 0, 0, 0}, 0, 0, 0);
+                        // eight vector instructions per element: lo, hi (shift-adds), lo >> sh, (hi << (16 - sh)) + that
+                        // (one shift-add: written as such, the compiler's own order negates and shifts separately), the
+                        // subtraction, the fold's two shifts, and xor-and-accumulate in one
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
                             const int32_t lo = P[0][r] + (P[1][r] << 8), hi = P[2][r] + (P[3][r] << 8);
-                            const uint32_t q = ((uint32_t)hi << sh16) + (uint32_t)(lo >> sh);
+                            const uint32_t q = lshl_add_u32((uint32_t)hi, (uint32_t)sh16, (uint32_t)(lo >> sh));
                             const int32_t res = (int32_t)((uint32_t)xs[r] - q);
-                            const uint32_t u = zigzag32(res);
                             // rice.c:85-94: partition 0 of every level starts at the order
-                            if (first) acc[r] += (C * (4 * g + r) + o < ord) ? 0u : u;
-                            else acc[r] += u;
+                            if constexpr (FIRST) {
+                                const uint32_t u = zigzag32(res);
+                                acc[r] += (C * (4 * g + r) + o < ord) ? 0u : u;
+                            } else {
+                                acc[r] = xad_u32((uint32_t)res << 1, (uint32_t)(res >> 31), acc[r]);       // += zigzag32(res)
+                            }
                         }
                     }
                 }
@@ -370,6 +379,12 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
             if constexpr (C > 16) chunk(std::integral_constant<int, 16>{});
             // leaves 16 blk + 4 g + r of this lane's candidate
             *reinterpret_cast<uint4 *>(leaf + nn * T + 16 * blk + 4 * g) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+        };
+#pragma unroll 1
+        for (int bq = 0; bq < 4; bq++) {
+            const int blk = wv * 4 + bq;                     // block of 16 leaves: threads 16 blk .. 16 blk + 15 (wave-uniform)
+            if (blk == 0) block(std::true_type{}, 0);
+            else block(std::false_type{}, blk);
         }
         __syncthreads();
         // ---- rice.c:105-187 per candidate, a wave each ----

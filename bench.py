@@ -112,7 +112,54 @@ def load_pmc():
         return None
 
 
-def per_kernel_bounds(p, n, nframes, kernel_ms, rice_bytes, pmc, with_residual=False):
+def load_pmc_cases():
+    """profiles/pmc_cases.json: SQ counters per wave of every kernel instance of the other_configs workloads
+    (tools/r04_measure.sh -> tools/r04_collect.py); `_current` says whether they belong to this source tree."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_cases.json")))
+        from flake_amd.srcid import kernel_sources_sha1
+        tj["_current"] = (tj.get("_src_sha1") == kernel_sources_sha1())
+        return tj
+    except Exception:
+        return None
+
+
+MFMA_ISSUE_CYCLES = 8            # a 16x16x64 int8 MFMA holds its SIMD's vector issue for 8 of its 16 cycles (MI355X_MICROARCH.md)
+
+
+def issue_bound(short, case_ent, ms_per_step):
+    """A kernel priced by its instruction issue (the search and encode kernels are not HBM problems):
+    bound time = sum over its instances of launches x waves / 1024 SIMDs x (4 cycles per vector instruction + 8
+    per matrix instruction) at 2.4 GHz; frac = bound time / measured time.  `parked` = share of wave cycles spent
+    at barriers / waits (SQ_WAIT_ANY), `issue_stalled` = SQ_WAIT_INST_ANY's share."""
+    inst = {k: v for k, v in case_ent.items() if short in k}
+    if not inst:
+        return None
+    tb = vi = mi = wc = wa = wi = wv = 0.0
+    for v in inst.values():
+        w = v["launches_per_step"] * v["waves_per_launch"]
+        vi += w * v["valu_per_wave"]
+        mi += w * v["mfma_per_wave"]
+        wc += w * v["wave_cycles"]
+        wa += w * v["wait_any_cycles"]
+        wi += w * v["wait_inst_cycles"]
+        wv += w
+    tb = (vi * ISSUE_CYCLES + mi * MFMA_ISSUE_CYCLES) / SIMDS / CLOCK_HZ
+    t = ms_per_step * 1e-3
+    parked = wa / wc if wc else None
+    frac = tb / t if t > 0 else None
+    out = {"ms": round(ms_per_step, 4),
+           "bound": "valu_issue" if (frac or 0) >= 0.5 or (parked or 0) < 0.4 else "barrier",
+           "frac": round(frac, 4) if frac is not None else None,
+           "valu_per_wave": round(vi / wv, 1), "mfma_per_wave": round(mi / wv, 1), "waves_per_step": int(wv),
+           "mfma_pipe_frac": round(mi * 16 / SIMDS / CLOCK_HZ / t, 4) if mi else 0.0,
+           "parked": round(parked, 3) if parked is not None else None,
+           "issue_stalled": round(wi / wc, 3) if wc else None,
+           "instances": len(inst)}
+    return out
+
+
+def per_kernel_bounds(p, n, nframes, kernel_ms, rice_bytes, pmc, with_residual=False, case=None, cases=None):
     """What binds each kernel of the step, and how close to that bound it runs.
 
     hbm         least bytes the kernel must move / 8 TB/s
@@ -144,6 +191,10 @@ def per_kernel_bounds(p, n, nframes, kernel_ms, rice_bytes, pmc, with_residual=F
             tb = ops / 64 * ISSUE_CYCLES / SIMDS / CLOCK_HZ
             out[k] = {"ms": round(ms, 4), "bound": "fp64_issue", "fp64_ops": ops, "frac": round(tb / t, 4),
                       "note": "one lane per subframe: latency, not issue, sets its time"}
+        elif cases and case and isinstance(cases.get(case), dict) and issue_bound(k, cases[case], ms):
+            out[k] = issue_bound(k, cases[case], ms)
+            out[k]["source"] = f"profiles/pmc_cases.json [{case}], tag {cases.get('_tag')}"
+            out[k]["current"] = cases.get("_current")
         else:
             ent = (pmc or {}).get(k, {}) if pmc else {}
             vpw, waves = ent.get("valu_per_wave"), ent.get("waves_per_launch")
@@ -200,10 +251,86 @@ def host_cores():
     return max(1, min(n, cap)), n
 
 
-def small_cpu_baseline(params, n, frames, pcm=None, budget_s=2.0):
-    """The CPU restatement (kind "port", one thread) on a small sample of a workload: the figure
-    every `other_configs` row carries.  Whole frames through the oracle's flake_encode_frame()
-    (encode_block: the VBS driver included) when the row's outputs are frames."""
+REF_BENCH = os.path.join(ROOT, "build", "ref", "ref_bench")     # oracle/Makefile `refbench`: the reference's own CMake build
+REF_CLI = os.path.join(ROOT, "build", "ref", "flake")
+
+
+def reference_leg(params, n, frames, seconds=1.0, transient=False):
+    """TIMING ONLY: the reference's own flake_encode_frame() loop (flake/flake.c:624-663) over the same
+    synthetic frames, as a child process -- build/ref/ref_bench, linked against the libflake_static.a
+    the reference's CMake build makes (oracle/Makefile target `refbench`; git-ignored, built where
+    /root/reference exists and shipped as a binary).  Never a parity witness: nothing compares its
+    bytes.  Its calls include the stream MD5 (encode.c:1006), as every libflake caller's do."""
+    import subprocess
+    if not os.path.exists(REF_BENCH):
+        return None
+    args = [REF_BENCH, params.channels, params.bits_per_sample, params.sample_rate, n, params.order_method,
+            params.stereo_method, params.prediction_type, params.min_prediction_order, params.max_prediction_order,
+            params.min_partition_order, params.max_partition_order, params.variable_block_size, params.allow_vbs,
+            frames, seconds, 1 if transient else 0]
+    try:
+        r = subprocess.run([str(a) for a in args], capture_output=True, text=True, timeout=120 + 20 * seconds)
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": repr(e)}
+    return {"value": round(j["samples"] / j["seconds"] / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+            "kind": "reference (timing only)",
+            "sample": f"{j['frames']} calls of the reference's flake_encode_frame() on this workload's frames "
+                      f"({j['samples'] / 1e6:.1f} Msamples, {j['seconds']:.2f} s; stream MD5 included, as in every call "
+                      "of libflake), build/ref/ref_bench = oracle/ref_bench.c + the reference's CMake-built libflake_static.a"}
+
+
+def reference_cli_leg(nframes=16384, n=4096):
+    """TIMING ONLY, BASELINE configs[0] as it is defined: the reference's `flake` CLI on a mono 16-bit WAV in
+    tmpfs (`flake -q -2 -b 4096 in.wav -o out.flac`), wall time of the child process (WAV parsing, encode,
+    MD5, file output included)."""
+    import subprocess
+    import tempfile
+    import wave
+    import flake_amd
+    if not os.path.exists(REF_CLI):
+        return None
+    tmp = tempfile.mkdtemp(prefix="flake_ref_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    wav, out = os.path.join(tmp, "in.wav"), os.path.join(tmp, "out.flac")
+    try:
+        pcm = flake_amd.synth_pcm(nframes, n, 1, 16).astype(np.int16)
+        with wave.open(wav, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(44100)
+            w.writeframes(pcm.tobytes())
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run([REF_CLI, "-q", "-2", "-b", str(n), wav, "-o", out], capture_output=True, timeout=300)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": f"flake CLI rc {r.returncode}: {r.stderr[-200:]!r}"}
+            best = dt if best is None else min(best, dt)
+        samples = nframes * n
+        return {"value": round(samples / best / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                "kind": "reference (timing only)",
+                "sample": f"`flake -q -2 -b {n} in.wav -o out.flac` on a {samples / 1e6:.1f} Msample mono 16-bit WAV in "
+                          f"tmpfs, best of 2 runs ({best:.2f} s wall: WAV parsing, encode, MD5 and file output included), "
+                          f"{os.path.getsize(out)} bytes out; build/ref/flake = the reference's CMake build"}
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        for f in (wav, out):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+        try:
+            os.rmdir(tmp)
+        except OSError:
+            pass
+
+
+def small_cpu_baseline(params, n, frames, pcm=None, budget_s=1.0, transient=False):
+    """The CPU figures every `other_configs` row carries, each over AT LEAST `budget_s` seconds of CPU work
+    (round 3 timed 0.00-0.02 s here): the CPU restatement (kind "port", one thread; whole frames through the
+    oracle's flake_encode_frame() -- encode_block, the VBS driver included -- when the row's outputs are frames)
+    repeated over a small sample until the budget is spent, and under "reference" the reference's own loop
+    (reference_leg: timing only)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib
     import flake_amd
@@ -214,28 +341,37 @@ def small_cpu_baseline(params, n, frames, pcm=None, budget_s=2.0):
     frames = pcm.shape[0]
     t0 = time.perf_counter()
     done = 0
-    if params.variable_block_size:
-        fc = 0
-        for b in range(frames):
-            rc, _, fc = orc.encode_block(params, fc, pcm[b], n, 8 * n * ch * 4 + 4096)
-            if rc <= 0:
-                raise RuntimeError("oracle encode_block failed")
-            done += 1
-            if time.perf_counter() - t0 > budget_s:
-                break
-    else:
-        slot = flake_amd.rice_slot_bytes(params, n)
-        step = max(1, frames // 8)
-        for f0 in range(0, frames, step):
-            orc.encode_subframes_batch(params, pcm[f0:f0 + step], n, want_residual=False, slot_bytes=slot)
-            done += min(step, frames - f0)
-            if time.perf_counter() - t0 > budget_s:
-                break
+    passes = 0
+    while True:
+        if params.variable_block_size:
+            fc = 0
+            for b in range(frames):
+                rc, _, fc = orc.encode_block(params, fc, pcm[b], n, 8 * n * ch * 4 + 4096)
+                if rc <= 0:
+                    raise RuntimeError("oracle encode_block failed")
+                done += 1
+                if passes and time.perf_counter() - t0 > budget_s:
+                    break
+        else:
+            slot = flake_amd.rice_slot_bytes(params, n)
+            step = max(1, frames // 8)
+            for f0 in range(0, frames, step):
+                orc.encode_subframes_batch(params, pcm[f0:f0 + step], n, want_residual=False, slot_bytes=slot)
+                done += min(step, frames - f0)
+                if passes and time.perf_counter() - t0 > budget_s:
+                    break
+        passes += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
     dt = time.perf_counter() - t0
     samples = done * n * ch
-    return {"value": round(samples / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": f"{done} frames of this workload ({samples / 1e6:.2f} Msamples, {dt:.2f} s), "
-                      "oracle/flake_oracle.c"}
+    out = {"value": round(samples / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "sample": f"{done} frames ({frames} distinct, repeated) of this workload ({samples / 1e6:.2f} Msamples, "
+                     f"{dt:.2f} s), oracle/flake_oracle.c"}
+    ref = reference_leg(params, n, frames, budget_s, transient)
+    if ref is not None:
+        out["reference"] = ref
+    return out
 
 
 def cpu_baseline(params, n, budget_s, gpu_bits_per_frame=None):
@@ -249,8 +385,10 @@ def cpu_baseline(params, n, budget_s, gpu_bits_per_frame=None):
                      (oracle/_ref: lpc.c, rice.c, bitio.h, crc.c) timed as the reference's code,
                      one thread, on prepared subframes of the same sample; the integer FIR
                      (optimize.c, not buildable here -- DESIGN.md 4) is a plain C loop beside them.
-    The reference binary itself (flake CLI / libflake) cannot be built under the rules of this
-    build (encode.h includes a CMake-generated config.h), so no leg is kind "reference"."""
+    reference        TIMING ONLY (round 4): the reference's own flake_encode_frame() loop on the same frames
+                     (reference_leg above: build/ref/ref_bench on the libflake_static.a of the reference's CMake
+                     build; a child process; never a parity witness -- parity is pinned by oracle/_ref, which is
+                     built without the reference's build system).  Includes the stream MD5."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib
     import flake_amd
@@ -277,6 +415,29 @@ def cpu_baseline(params, n, budget_s, gpu_bits_per_frame=None):
                   f"({samples / 1e6:.1f} Msamples, {dt:.1f} s), oracle/flake_oracle.c, "
                   "prepare + encode_residual + Rice emit",
     }
+
+    ref = reference_leg(params, n, frames, max(3.0, budget_s * 0.4))
+    if ref is not None:
+        out["reference"] = ref
+        try:                                   # the same on every host core this process may use, one process each
+            import subprocess
+            ncores, navail = host_cores()
+            args = [REF_BENCH, params.channels, params.bits_per_sample, params.sample_rate, n, params.order_method,
+                    params.stereo_method, params.prediction_type, params.min_prediction_order,
+                    params.max_prediction_order, params.min_partition_order, params.max_partition_order,
+                    params.variable_block_size, params.allow_vbs, 256, 3.0, 0]
+            procs = [subprocess.Popen([str(a) for a in args], stdout=subprocess.PIPE, text=True) for _ in range(ncores)]
+            rates = []
+            for pr in procs:
+                o, _ = pr.communicate(timeout=120)
+                j = json.loads(o.strip().splitlines()[-1])
+                rates.append(j["samples"] / j["seconds"] / 1e6)
+            out["reference_all_cores"] = {"value": round(sum(rates), 1), "unit": "Msamples/s", "cores": ncores,
+                                          "cores_available": navail, "kind": "reference (timing only)",
+                                          "sample": f"{ncores} processes of build/ref/ref_bench side by side, 256 frames "
+                                                    "repeated for 3 s each; sum of their rates"}
+        except Exception as e:
+            out["reference_all_cores"] = {"error": repr(e)}
 
     # ---- every host core, one process each (spawned: this process holds the GPU)
     try:
@@ -385,7 +546,13 @@ def kernel_profile(enc, step, steps, per_step=False):
     return per
 
 
-def subframe_case(dev_index, tag, p, nframes, steps, with_residual=False, cpu=True, cpu_frames=48):
+def dominant_bound(per_kernel, dom):
+    """The dominant kernel against ITS bound (the row's answer to "how close to speed of light")."""
+    e = per_kernel.get(dom) or {}
+    return {"kernel": dom, "bound": e.get("bound"), "frac": e.get("frac"), "current": e.get("current")}
+
+
+def subframe_case(dev_index, tag, p, nframes, steps, with_residual=False, cpu=True, cpu_frames=48, case=None, cases=None):
     """One uniform-batch workload through fhip_encode_subframes_dev: ms per step at settled
     clocks, hipEvent time per kernel, what binds each, and a small CPU figure beside it."""
     import torch
@@ -418,9 +585,10 @@ def subframe_case(dev_index, tag, p, nframes, steps, with_residual=False, cpu=Tr
         "algorithmic_bytes": alg,
         "hbm_frac_dominant": round(alg / (per[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
         "hbm_frac_step": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-        "per_kernel": per_kernel_bounds(p, n, nframes, per, rice_bytes, None, with_residual),
+        "per_kernel": per_kernel_bounds(p, n, nframes, per, rice_bytes, None, with_residual, case, cases),
         "bits_per_sample_out": round(float(info_np["rice_nbits"].clip(min=0).sum()) / samples, 3),
     }
+    row["dominant_bound"] = dominant_bound(row["per_kernel"], dom)
     enc.close()
     del pcm, info, bits, resid
     torch.cuda.empty_cache()
@@ -432,7 +600,7 @@ def subframe_case(dev_index, tag, p, nframes, steps, with_residual=False, cpu=Tr
     return row
 
 
-def vbs_case(dev_index, level, nblocks, steps, cpu=True):
+def vbs_case(dev_index, level, nblocks, steps, cpu=True, case=None, cases=None):
     """BASELINE configs[4] shape: variable block size (vbs.c) + exhaustive order / partition
     search, blocks and stream device-resident through fhip_encode_blocks_vbs_dev (no host
     synchronisation inside): ms per batch at settled clocks and the serial per-kernel sums."""
@@ -471,12 +639,24 @@ def vbs_case(dev_index, level, nblocks, steps, cpu=True):
         "note": "eight bins of equal piece length; K0 / K1 / K2 / K4 one launch over all bins, order search / "
                 "K3 per bin on three internal streams; no host synchronisation inside",
     }
+    if cases and case and isinstance(cases.get(case), dict):
+        # the order searches and K3 of all bins against their instruction issue (sums over the bins' instances)
+        pk = {}
+        for k in ("k_order_search", "k_encode", "k_assemble"):
+            if k in per:
+                b = issue_bound(k, cases[case], per[k])
+                if b:
+                    b["source"] = f"profiles/pmc_cases.json [{case}], tag {cases.get('_tag')}"
+                    b["current"] = cases.get("_current")
+                    pk[k] = b
+        row["per_kernel"] = pk
+        row["dominant_bound"] = dominant_bound(pk, dom)
     enc.close()
     del pcm, packed
     torch.cuda.empty_cache()
     if cpu:
         try:
-            row["cpu_baseline"] = small_cpu_baseline(p, n, 24, pcm=pcm_h[:24])
+            row["cpu_baseline"] = small_cpu_baseline(p, n, 24, pcm=pcm_h[:24], transient=True)
         except Exception as e:
             row["cpu_baseline"] = {"error": repr(e)}
     return row
@@ -485,29 +665,40 @@ def vbs_case(dev_index, level, nblocks, steps, cpu=True):
 def other_configs(dev_index, steps, cpu=True):
     """The BASELINE configs the headline is NOT quoted on, at their full sizes, two more presets,
     and stage A of the headline (int32 residual out): reported next to the headline, never as
-    `value`; every row carries a small CPU figure (port, one core)."""
+    `value`; every row carries CPU figures over >= 1 s each (port, one core; the reference's own loop,
+    timing only) and prices its search / encode kernels by instruction issue from profiles/pmc_cases.json."""
     import flake_amd
     P = flake_amd.level_params
     rows = []
+    pc = load_pmc_cases()
     cases = [
         ("configs[2]: stereo 24-bit 96 kHz, n 4096, LPC order SEARCH 1-32, partition orders 0-8",
          P(5, bits_per_sample=24, sample_rate=96000, order_method=flake_amd.OM_SEARCH,
-           max_prediction_order=32, max_partition_order=8), 4096, False, 6),
+           max_prediction_order=32, max_partition_order=8), 4096, False, 6, "c2"),
         ("configs[3]: 8-channel 24-bit 192 kHz, n 4096, LPC-12 (MAX), 32768 subframes",
          P(5, channels=8, bits_per_sample=24, sample_rate=192000, order_method=flake_amd.OM_MAX,
-           max_prediction_order=12), 4096, False, 16),
+           max_prediction_order=12), 4096, False, 16, "c3"),
         ("configs[0] (the reference's CPU case) on the GPU: mono 16-bit, n 4096, fixed orders 0-4, "
-         "partition orders 0-3", P(2, channels=1, block_size=4096), 8192, False, 64),
-        ("level 8: stereo 16-bit, n 4096, LPC <= 12 LOG search, partition orders 0-6", P(8), 4096, False, 24),
+         "partition orders 0-3", P(2, channels=1, block_size=4096), 8192, False, 64, "c0"),
+        ("level 8: stereo 16-bit, n 4096, LPC <= 12 LOG search, partition orders 0-6", P(8), 4096, False, 24, "l8"),
         ("level 2: stereo 16-bit, n 1152, fixed orders 0-4, partition orders 0-3", P(2),
-         4096 * 4096 // 1152, False, 128),
+         4096 * 4096 // 1152, False, 128, "l2"),
         ("configs[1], stage A (SURVEY 8d): the headline workload with the int32 residual written too",
-         P(5, order_method=flake_amd.OM_MAX), 4096, True, 48),
+         P(5, order_method=flake_amd.OM_MAX), 4096, True, 48, None),
     ]
-    for tag, p, nframes, with_res, cpu_frames in cases:
-        rows.append(subframe_case(dev_index, tag, p, nframes, steps, with_res, cpu, cpu_frames))
+    for tag, p, nframes, with_res, cpu_frames, case in cases:
+        row = subframe_case(dev_index, tag, p, nframes, steps, with_res, cpu, cpu_frames, case, pc)
+        if case == "c0" and cpu:
+            # BASELINE configs[0] as it is defined: "CPU reference via flake CLI, no GPU"
+            cli = reference_cli_leg()
+            if cli is not None:
+                row["cpu_reference_cli"] = cli
+        rows.append(row)
     for level in (10, 12):
-        rows.append(vbs_case(dev_index, level, 1024, max(5, steps // 2), cpu))
+        rows.append(vbs_case(dev_index, level, 1024, max(5, steps // 2), cpu, f"l{level}", pc))
+    # the size SURVEY 8d gives configs[4] per GPU (>= 65536 blocks over 8 GPUs): 1024 blocks are latency-bound
+    for level in (10, 12):
+        rows.append(vbs_case(dev_index, level, 8192, 5, False, f"l{level}x8", pc))
     return rows
 
 

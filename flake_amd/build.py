@@ -6,6 +6,9 @@
 Targets
   hip   flake_amd/lib/libflakehip.so   gfx950 kernels + C ABI (include/flakehip.h)
   host  flake_amd/lib/libflake_amd.so  host C layer (include/flake_amd.h) on top of it
+  probes  the K1 timing-probe libraries tools/k1_sq.sh and tools/k1run.sh load (libflakehip_noprod.so,
+          _nowalk.so, _nob.so: -DFHIP_PROBE_*; their RESULTS ARE WRONG, measurements only -- never
+          built by default, never loaded by the package unless FHIP_LIB points at one)
 """
 from __future__ import annotations
 
@@ -116,8 +119,19 @@ def build_all(force: bool = False) -> None:
     build_cli(force)
 
 
+PROBE_LIBS = {"libflakehip_noprod.so": "-DFHIP_PROBE_NOPROD", "libflakehip_nowalk.so": "-DFHIP_PROBE_NOWALK",
+              "libflakehip_nob.so": "-DFHIP_PROBE_NOB"}
+
+
+def build_probes() -> None:
+    for name, flag in PROBE_LIBS.items():
+        build_hip(force=True, extra=[flag], out_name=name)
+
+
 if __name__ == "__main__":
     targets = sys.argv[1:] or ["hip", "host"]
+    if "probes" in targets:
+        build_probes()
     if "hip" in targets:
         build_hip(force=True, extra=["-Rpass-analysis=kernel-resource-usage"] if os.environ.get("FHIP_REMARKS") else None)
     if "host" in targets:

@@ -1052,12 +1052,21 @@ int vbs_check(fhip_ctx *c, const void *pcm, int nblocks, int block_size)
     return FHIP_OK;
 }
 
+// the device entry reads the caller's blocks where they lie, with 16-byte loads (k_vbs_split, K0)
+int vbs_check_dev_pcm(fhip_ctx *c, const void *pcm)
+{
+    if (reinterpret_cast<uintptr_t>(pcm) & 15)
+        return fail(c, FHIP_E_INVALID, "device pcm must be 16-byte aligned (flakehip.h: fhip_encode_blocks_vbs_dev)");
+    return FHIP_OK;
+}
+
 }  // namespace
 
 int fhip_encode_blocks_vbs_dev(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size,
                                uint32_t first_frame_number, const fhip_vbs_out *out)
 {
     int rc = vbs_check(c, pcm, nblocks, block_size);
+    if (rc == FHIP_OK) rc = vbs_check_dev_pcm(c, pcm);
     if (rc != FHIP_OK) return rc;
     if (!out || !out->packed || !out->totals || out->packed_cap < 0)
         return fail(c, FHIP_E_INVALID, "null output argument");
@@ -1117,10 +1126,13 @@ int fhip_encode_blocks_vbs_packed(fhip_ctx *c, const int32_t *pcm, int nblocks, 
         HIP_TRY(c, hipMemcpyAsync(block_frames, c->d_blk_frames, (size_t)nblocks * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     rc = fhip_sync(c);
     if (rc != FHIP_OK) return rc;
-    if (totals[1] > out_cap) return fail(c, FHIP_E_INVALID, "output buffer too small for the batch's frames");
-    HIP_TRY(c, hipMemcpy(out, c->d_packed, (size_t)totals[1], hipMemcpyDeviceToHost));
+    // every FRAME is checked (k_frame_offsets_perm, totals[3] bit 1), before anything is copied out: a piece that
+    // failed inside a block of several pieces does not show in the block's byte count
+    if (totals[3] & 2) return fail(c, FHIP_E_GENERIC, "a frame of the batch was not encoded");
     for (int b = 0; b < nblocks; b++)
         if (block_bytes[b] <= 0) return fail(c, FHIP_E_GENERIC, "a frame of the batch was not encoded");
+    if (totals[1] > out_cap) return fail(c, FHIP_E_INVALID, "output buffer too small for the batch's frames");
+    HIP_TRY(c, hipMemcpy(out, c->d_packed, (size_t)totals[1], hipMemcpyDeviceToHost));
     if (max_frame_bytes) *max_frame_bytes = (int32_t)totals[2];
     if (next_frame_number) *next_frame_number = first_frame_number + (uint32_t)((long long)nblocks * block_size);
     *out_bytes = totals[1];

@@ -75,10 +75,12 @@ __device__ __forceinline__ int dev_count(const int32_t *__restrict__ dev, int ho
 // its bin?  (per lane)
 __device__ __forceinline__ bool bin_unit_live(const MultiBin &mb, int s)
 {
-    int k = 0;
+    // (entries may list the bins in any order -- K1 lists the longest first --: a range test per entry)
+    bool live = false;
 #pragma unroll
-    for (int q = 1; q < 8; q++) if (q < mb.nbins && s >= mb.unit0[q]) k = q;
-    return s - mb.unit0[k] < mb.cnt[mb.cnt_ix[k]];
+    for (int q = 0; q < 8; q++)
+        if (q < mb.nbins && s >= mb.unit0[q] && s - mb.unit0[q] < mb.cap[q]) live = (s - mb.unit0[q]) < mb.cnt[mb.cnt_ix[q]];
+    return live;
 }
 
 // kernels.h MultiBin: which bin a workgroup belongs to (wave-uniform)

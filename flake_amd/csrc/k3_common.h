@@ -114,14 +114,14 @@ struct FastCtx {
 // FIR residual of this thread's C samples x[] for an LPC candidate
 // (optimize.c:70-122).  l.coefd holds the coefficients as doubles, zero past
 // `order`, so the tap loop runs in whole blocks of 8.
-template <int C, int T>
+template <int C, int T, int OBMAX = 8>
 __device__ __forceinline__ void fir_lpc(const FastCtx<C, T> &e, int32_t (&r)[C], int order, int shift)
 {
     using Img = SmpImg<C, T>;
     const FastLds &l = e.l;
     const double inv = __builtin_ldexp(1.0, -shift);
-    // outputs per register block: a divisor of C
-    constexpr int OB = (C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : (C % 5 == 0) ? 5 : (C % 7 == 0) ? 7 : 1;
+    // outputs per register block: a divisor of C (OBMAX = 4: the caller is short of registers)
+    constexpr int OB = (C % 8 == 0 && OBMAX >= 8) ? 8 : (C % 4 == 0) ? 4 : (C % 3 == 0) ? 3 : (C % 5 == 0) ? 5 : (C % 7 == 0) ? 7 : 1;
     // taps per block: a multiple of C (going back C*k samples is going back k
     // columns of the image, so every block sees the same immediate offsets)
     constexpr int TB = (16 % C == 0) ? 16 : C * ((8 + C - 1) / C);
@@ -281,30 +281,33 @@ __device__ __forceinline__ void fir_lpc_o16(const FastCtx<C, T> &e, int32_t (&r)
 {
     using Img = SmpImg<C, T>;
     static_assert(Img::V4 && C % 8 == 0 && (TAPS == 12 || TAPS == 16), "fir_lpc_o16: runs of 8 or 16");
+    // outputs per register block: eight at 12 taps; four at 16 (a window of 24 doubles beside eight accumulators
+    // and the run's residuals does not fit the 96 registers of five waves per SIMD: two were spilled)
+    constexpr int OBW = (TAPS == 16) ? 4 : 8;
     const double inv = __builtin_ldexp(1.0, -shift);
     const int32_t *mine = e.l.smp + e.tid * Img::CS;
     double cf[TAPS];
 #pragma unroll
     for (int jj = 0; jj < TAPS; jj++) cf[jj] = cd[jj];
 #pragma unroll
-    for (int ob = 0; ob < C; ob += 8) {
+    for (int ob = 0; ob < C; ob += OBW) {
         __builtin_amdgcn_sched_barrier(0);
-        double acc[8];
+        double acc[OBW];
 #pragma unroll
-        for (int o = 0; o < 8; o++) acc[o] = 0.0;
-        double W[TAPS + 8];                                // samples ob-TAPS .. ob+7 (the last one unused)
+        for (int o = 0; o < OBW; o++) acc[o] = 0.0;
+        double W[TAPS + OBW];                              // samples ob-TAPS .. ob+OBW-1 (the last one unused)
 #pragma unroll
-        for (int m4 = 0; m4 < TAPS + 8; m4 += 4) {
+        for (int m4 = 0; m4 < TAPS + OBW; m4 += 4) {
             const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob - TAPS + m4));
             W[m4] = (double)v.x; W[m4 + 1] = (double)v.y; W[m4 + 2] = (double)v.z; W[m4 + 3] = (double)v.w;
         }
 #pragma unroll
         for (int jj = 0; jj < TAPS; jj++)
 #pragma unroll
-            for (int o = 0; o < 8; o++)
+            for (int o = 0; o < OBW; o++)
                 acc[o] = __builtin_fma(cf[jj], W[o + TAPS - 1 - jj], acc[o]);      // tap jj+1: sample ob+o-(jj+1)
 #pragma unroll
-        for (int o = 0; o < 8; o++) {
+        for (int o = 0; o < OBW; o++) {
             const double z = __builtin_fma(acc[o], inv, 6755399441055744.0);   // floor under round-down, see fir_lpc
             const uint32_t qlo = (uint32_t)__double2loint(z);
             const int4 v = *reinterpret_cast<const int4 *>(mine + Img::off(ob + (o & ~3)));

@@ -1373,7 +1373,8 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2" ::: "memory");
 
     const int tid = threadIdx.x;
-    e.n = n; e.tid = tid; e.lane = tid & 63; e.wv = tid >> 6;
+    e.n = n; e.tid = tid; e.lane = tid & 63;
+    e.wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: a scalar, not a vector register
     e.i0 = tid * C;
     e.precision = P.lpc_precision;
     e.pmin_req = P.min_partition_order;
@@ -1660,7 +1661,9 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                         if (ord <= 12) { fir_lpc_o16<C, T, 12>(e, r, ord, cshift, cd); wide_done = true; }
                         else if (ord <= 16) { fir_lpc_o16<C, T, 16>(e, r, ord, cshift, cd); wide_done = true; }
                     }
-                    if (!wide_done) fir_lpc<C, T>(e, r, ord, cshift);     // (MODE 0 is launched for maximum orders <= 8 only)
+                    // (MODE 0 is launched for maximum orders <= 8 only; MODE 3 -- five waves per SIMD, 96 registers --
+                    // takes the general FIR in register blocks of four outputs: eight spilled six registers)
+                    if (!wide_done) fir_lpc<C, T, (MODE == 3) ? 4 : 8>(e, r, ord, cshift);
                 }
                 STAMP(3);
                 b = rice_search_fast<C, T>(e, r, u, ord, true, &porder, &method, &umax_run);

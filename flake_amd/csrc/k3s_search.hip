@@ -366,8 +366,13 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
                             const int32_t res = (int32_t)((uint32_t)xs[r] - q);
                             // rice.c:85-94: partition 0 of every level starts at the order
                             if constexpr (FIRST) {
+                                // o < ord - C (4 g + r).  The limit goes through an opaque move so that the 16 x 4 compares of
+                                // the block stay where they are used: hoisted out of the tile loop they were 64 scalar pairs
+                                // (150 scalar spills into vector lanes in this instance)
+                                int lim = ord - C * (4 * g + r);
+                                asm volatile("" : "+v"(lim));
                                 const uint32_t u = zigzag32(res);
-                                acc[r] += (C * (4 * g + r) + o < ord) ? 0u : u;
+                                acc[r] += (o < lim) ? 0u : u;
                             } else {
                                 acc[r] = xad_u32((uint32_t)res << 1, (uint32_t)(res >> 31), acc[r]);       // += zigzag32(res)
                             }

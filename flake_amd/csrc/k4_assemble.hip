@@ -701,18 +701,24 @@ void k_frame_offsets_perm(const int32_t *__restrict__ fbytes, const int32_t *__r
                           long long cap, long long *__restrict__ totals)
 {
     __shared__ long long s_part[SCAN_NT];
-    __shared__ int s_max;
+    __shared__ int s_max, s_bad;
     const int tid = threadIdx.x;
     const int nframes = dev_count(dev_frames, 0);
     const int per = (nframes + SCAN_NT - 1) / SCAN_NT;
     const int f0 = min(tid * per, nframes), f1 = min(f0 + per, nframes);
     long long sum = 0;
-    int mx = 0;
-    if (tid == 0) s_max = 0;
-    for (int f = f0; f < f1; f++) { const int b = max(fbytes[order[f]], 0); sum += b; mx = max(mx, b); }
+    int mx = 0, bad = 0;
+    if (tid == 0) { s_max = 0; s_bad = 0; }
+    for (int f = f0; f < f1; f++) {
+        const int raw = fbytes[order[f]];
+        const int b = max(raw, 0);
+        bad |= (raw <= 0);                         // a frame K4 did not produce: the stream would be short of it
+        sum += b; mx = max(mx, b);
+    }
     s_part[tid] = sum;
     __syncthreads();
     if (mx > 0) atomicMax(&s_max, mx);
+    if (bad) atomicOr(&s_bad, 1);
     for (int off = 1; off < SCAN_NT; off <<= 1) {
         const long long v = (tid >= off) ? s_part[tid - off] : 0;
         __syncthreads();
@@ -723,11 +729,12 @@ void k_frame_offsets_perm(const int32_t *__restrict__ fbytes, const int32_t *__r
     for (int f = f0; f < f1; f++) { offsets[f] = run; run += max(fbytes[order[f]], 0); }
     if (tid == SCAN_NT - 1) {
         offsets[nframes] = s_part[tid];
-        // totals: frames, bytes, largest frame, 1 = the stream does not fit `cap`
+        // totals: frames, bytes, largest frame, flags: 1 = the stream does not fit `cap`, 2 = some frame of the
+        // stream was not encoded (frame_bytes <= 0: its bytes are missing from the packed stream)
         totals[0] = nframes;
         totals[1] = s_part[tid];
         totals[2] = s_max;                     // encode.c:967 (ordered by the scan's barriers)
-        totals[3] = (s_part[tid] > cap) ? 1 : 0;
+        totals[3] = ((s_part[tid] > cap) ? 1 : 0) | (s_bad ? 2 : 0);
     }
 }
 

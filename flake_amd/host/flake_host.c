@@ -844,8 +844,15 @@ static long long encode_batch(FlakeAmdContext *s, host_ctx *c, const int32_t *pc
             for (int i = 0; i < np; i++) c->fnum[i] = num_of[i];
             b.frame_numbers = c->fnum;
             int64_t wrote = 0;
-            if (c->hip2_state == 0 && c->chunk_frames > 0 && np >= 2 * c->chunk_frames)
-                c->hip2_state = (fhip_create(&c->hip2, c->device, &c->hp, c->chunk_frames) == FHIP_OK) ? 1 : -1;
+            if (c->hip2_state == 0 && c->chunk_frames > 0 && np >= 2 * c->chunk_frames) {
+                /* the chunk handle only ever runs uniform batches (fhip_encode_frames_packed_begin): without
+                 * variable_block_size its subframe-indexed workspaces are sized for max_frames, not for the 2.5 x
+                 * max_frames slots a variable-block-size batch's eight bins need (allow_vbs, which the frame
+                 * headers depend on, stays) */
+                fhip_params hp2 = c->hp;
+                hp2.variable_block_size = 0;
+                c->hip2_state = (fhip_create(&c->hip2, c->device, &hp2, c->chunk_frames) == FHIP_OK) ? 1 : -1;
+            }
             if (c->hip2_state < 0) c->hip2 = NULL;                 /* fine: one handle, one pass */
             if (c->hip2 && c->chunk_frames > 0 && np >= 2 * c->chunk_frames) {
                 wrote = run_chunked(c, pieces[0].pcm, np, pieces[0].n, nch, out, cap);

@@ -219,9 +219,16 @@ FHIP_API int fhip_encode_blocks_vbs_packed(fhip_ctx *ctx, const int32_t *pcm, in
  *   frame_bytes   optional [8 * nblocks]: size of the stream's i-th frame, i < totals[0]
  *   block_bytes   optional [nblocks]: bytes of block b's frames (flake_encode_frame's return value)
  *   block_frames  optional [nblocks]: frames block b became (1 = left whole, vbs.c:100)
- *   totals        [4] int64: frames, bytes, largest frame (encode.c:967), 1 if the stream was cut
+ *   totals        [4] int64: frames, bytes, largest frame (encode.c:967), flags -- bit 0: the stream was cut
+ *                 (did not fit packed_cap), bit 1: some frame of the stream was not encoded (frame_bytes <= 0;
+ *                 its bytes are missing from packed)
+ * pcm must be 16-BYTE ALIGNED (the splitter and the feeder stage read the blocks where they lie with
+ * 16-byte loads); a misaligned pointer is refused with FHIP_E_INVALID.
  * Frame numbers as in fhip_encode_blocks_vbs_packed.  The handle: variable_block_size and
- * allow_vbs set, max_frames >= 8 * nblocks. */
+ * allow_vbs set, max_frames >= 8 * nblocks.  Such a handle sizes its subframe-indexed workspaces
+ * (autoc, coefs 4 KB, shift, fin, K0 records) for 20 frame slots per block -- 2.5 x max_frames frames --
+ * in fhip_create, whether or not a variable-block-size batch is ever run on it: create handles that
+ * only see uniform batches without variable_block_size. */
 typedef struct fhip_vbs_out {
     uint8_t  *packed;
     int64_t   packed_cap;

@@ -9,9 +9,9 @@
  * The PCM is the repository's generator (flake_amd/host/synth.c, compiled in), so the reference
  * encodes the very frames the GPU leg encodes.
  *
- * usage: ref_bench channels bps rate level block_size order_method max_order min_porder max_porder
- *                  vbs frames seconds transient
- *        (a negative value keeps what flake_set_defaults() chose for the level)
+ * usage: ref_bench channels bps rate block_size order_method stereo_method prediction_type min_order
+ *                  max_order min_porder max_porder variable_block_size allow_vbs frames seconds transient
+ *        (every FlakeEncodeParams field the hot path reads, flake.h:59-160, as the caller sets them)
  * prints one JSON line: frames encoded, samples, seconds, bytes written.
  */
 #include <stdint.h>
@@ -33,16 +33,15 @@ static double now(void)
 
 int main(int argc, char **argv)
 {
-    if (argc < 14) {
-        fprintf(stderr, "usage: ref_bench ch bps rate level block order_method max_order min_porder max_porder vbs frames seconds transient\n");
+    if (argc < 17) {
+        fprintf(stderr, "usage: ref_bench ch bps rate block order_method stereo_method prediction_type min_order max_order "
+                        "min_porder max_porder vbs allow_vbs frames seconds transient\n");
         return 2;
     }
-    const int ch = atoi(argv[1]), bps = atoi(argv[2]), rate = atoi(argv[3]), level = atoi(argv[4]);
-    const int block = atoi(argv[5]), om = atoi(argv[6]), maxo = atoi(argv[7]);
-    const int minp = atoi(argv[8]), maxp = atoi(argv[9]), vbs = atoi(argv[10]);
-    const int frames = atoi(argv[11]);
-    const double seconds = atof(argv[12]);
-    const int transient = atoi(argv[13]);
+    const int ch = atoi(argv[1]), bps = atoi(argv[2]), rate = atoi(argv[3]);
+    const int frames = atoi(argv[14]);
+    const double seconds = atof(argv[15]);
+    const int transient = atoi(argv[16]);
 
     FlakeContext s;
     memset(&s, 0, sizeof(s));
@@ -50,14 +49,18 @@ int main(int argc, char **argv)
     s.sample_rate = rate;
     s.bits_per_sample = bps;
     s.samples = 0;
-    s.params.compression = level;
+    s.params.compression = 5;
     if (flake_set_defaults(&s.params) < 0) { fprintf(stderr, "flake_set_defaults failed\n"); return 1; }
-    if (block > 0) s.params.block_size = block;
-    if (om >= 0) s.params.order_method = om;
-    if (maxo >= 0) s.params.max_prediction_order = maxo;
-    if (minp >= 0) s.params.min_partition_order = minp;
-    if (maxp >= 0) s.params.max_partition_order = maxp;
-    if (vbs >= 0) s.params.variable_block_size = vbs;
+    s.params.block_size = atoi(argv[4]);
+    s.params.order_method = atoi(argv[5]);
+    s.params.stereo_method = atoi(argv[6]);
+    s.params.prediction_type = atoi(argv[7]);
+    s.params.min_prediction_order = atoi(argv[8]);
+    s.params.max_prediction_order = atoi(argv[9]);
+    s.params.min_partition_order = atoi(argv[10]);
+    s.params.max_partition_order = atoi(argv[11]);
+    s.params.variable_block_size = atoi(argv[12]);
+    s.params.allow_vbs = atoi(argv[13]);
     s.params.padding_size = 0;
     if (flake_validate_params(&s) < 0) { fprintf(stderr, "flake_validate_params failed\n"); return 1; }
     if (flake_encode_init(&s) < 0) { fprintf(stderr, "flake_encode_init failed\n"); return 1; }

@@ -118,6 +118,27 @@ def test_vbs_dev_frame_numbers_and_reuse(oracle, decoder):
     assert (out == allpcm).all()
 
 
+def test_vbs_dev_refuses_misaligned_pcm():
+    """The device entry reads the blocks with 16-byte loads: a view that starts on an odd stereo
+    sample-frame (8-byte aligned only) is refused, not read (include/flakehip.h)."""
+    p = flake_amd.level_params(9)
+    n = p.block_size
+    dev = torch.device("cuda", 0)
+    buf = torch.zeros(2 * n * 2 + 2, dtype=torch.int32, device=dev)
+    view = buf[2:]                                   # 8 bytes past a 16-byte boundary
+    assert view.data_ptr() % 16 == 8
+    packed = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+    totals = torch.zeros(4, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)
+    with flake_amd.Encoder(p, max_frames=16) as enc:
+        with pytest.raises(flake_amd.FlakeHipError) as ei:
+            enc.encode_blocks_vbs_dev(view, 2, n, packed, packed.numel(), totals)
+        assert ei.value.code == flake_amd.E_INVALID
+        enc.encode_blocks_vbs_dev(buf, 2, n, packed, packed.numel(), totals)      # the aligned buffer is fine
+        enc.sync()
+    assert int(totals.cpu()[3]) == 0
+
+
 def test_vbs_dev_buffer_too_small():
     """A stream that does not fit packed_cap: flagged in totals[3], frames past the end are not
     written, nothing is written behind the buffer."""

@@ -1,7 +1,9 @@
 # SQ LDS counters of K1 per probe build (who causes the bank conflicts): rocprofv3 --pmc with --kernel-trace only
+# the probe libraries: `python -m flake_amd.build probes` (here, before gpurun: built .so files travel); a missing one is skipped
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for lib in libflakehip.so libflakehip_noprod.so libflakehip_nowalk.so libflakehip_nob.so; do
 export FHIP_LIB=$PWD/flake_amd/lib/$lib
+[ -f $FHIP_LIB ] || { echo "$lib missing: python -m flake_amd.build probes"; continue; }
 rocprofv3 --pmc SQ_WAVES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d gpurun_out/r03_sq_$lib -- python3 bench.py --steps 3 --warmup 1 --settle-ms 0 --profile-steps 0 --no-cpu-baseline --no-other-configs > gpurun_out/r03_sq_$lib.log 2>&1
 python - <<PY
 import csv,glob,collections,re

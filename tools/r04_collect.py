@@ -42,6 +42,33 @@ for c in cases:
             row[cn + "_per_wave"] = round(v / w, 1) if w else None
         rows[k] = row
     out[c] = rows
+# profiles/pmc_cases.json: what bench.py's other_configs rows price their kernels with (per_kernel bounds)
+sys.path.insert(0, R)
+from flake_amd.srcid import kernel_sources_sha1
+STEPS = 3          # tools/r04_measure.sh runs the SQ passes over three steps of the case
+pc = {"_note": "per workload case (tools/sq_case.py) and kernel instance: SQ counters per wave of one rocprofv3 --pmc pass "
+               "(--kernel-trace only beside it), cycles = 4 x the quad-cycle counters; launches_per_step = dispatches / steps",
+      "_tag": tag, "_src_sha1": kernel_sources_sha1()}
+try:
+    old = json.load(open(f"{R}/profiles/pmc_cases.json"))
+    if old.get("_src_sha1") == pc["_src_sha1"]:
+        pc.update({k: v for k, v in old.items() if not k.startswith("_")})      # cases measured in an earlier call
+except Exception:
+    pass
+for c, rows in out.items():
+    pc[c] = {}
+    for k, r in rows.items():
+        if not r.get("SQ_INSTS_VALU_per_wave"):
+            continue
+        pc[c][k] = {"launches_per_step": round(r["launches"] / STEPS, 2), "waves_per_launch": r["waves_per_launch"],
+                    "valu_per_wave": r["SQ_INSTS_VALU_per_wave"], "salu_per_wave": r.get("SQ_INSTS_SALU_per_wave"),
+                    "lds_per_wave": r.get("SQ_INSTS_LDS_per_wave"), "mfma_per_wave": r.get("SQ_INSTS_MFMA_per_wave") or 0.0,
+                    "mfma_busy_cycles_per_wave": r.get("SQ_VALU_MFMA_BUSY_CYCLES_per_wave") or 0.0,
+                    "wave_cycles": round(4 * (r.get("SQ_WAVE_CYCLES_per_wave") or 0)),
+                    "wait_any_cycles": round(4 * (r.get("SQ_WAIT_ANY_per_wave") or 0)),
+                    "wait_inst_cycles": round(4 * (r.get("SQ_WAIT_INST_ANY_per_wave") or 0)),
+                    "vgprs": r.get("vgprs")}
+json.dump(pc, open(f"{R}/profiles/pmc_cases.json", "w"), indent=1)
 p = f"{R}/profiles/{tag}_sq_counters.json"
 json.dump({"_note": "per kernel instance: counter totals / SQ_WAVES of the same pass (quad-cycle counters as read: x4 = cycles); "
                     "tools/r04_measure.sh, sq_case.py cases", **out}, open(p, "w"), indent=1)

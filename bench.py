@@ -38,7 +38,39 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 SIMDS = 1024                     # 256 CUs x 4
 CLOCK_HZ = 2.4e9                 # max clock: issue bounds below are the least time the work can take
-ISSUE_CYCLES = 4                 # one wave64 vector instruction per 4 cycles and SIMD (MI355X_MICROARCH.md)
+# A gfx950 SIMD is 32 lanes wide (MI355X_MICROARCH.md): with several waves resident it issues a wave64 vector instruction
+# of the simple classes (v_add_u32, v_sub_u32, v_ashrrev, and / or / xor, mov, fp32) every 2 cycles and one of the
+# half-rate classes (three-operand integer forms, v_lshlrev, min / max, compares, cndmask, carries, multiplies, dot
+# products, alignbyte / perm, DPP forms, lane reads, every fp64 instruction) every 4 -- measured with
+# tools/ubench_valu.hip, profiles/r04_ubench_valu.txt.  A kernel's price per vector instruction is its own static mix of
+# the two (tools/valu_mix.py -> profiles/valu_mix.json); without one it is the optimistic 2.  (Rounds 1-3 priced every
+# vector instruction at 4 cycles: their valu_issue fractions read 20-35 % too high.)
+ISSUE_CYCLES_FULL = 2
+ISSUE_CYCLES = 4                 # the half-rate classes; fp64 (K1, K2) is all of this class
+
+
+def load_valu_mix():
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
+        from flake_amd.srcid import kernel_sources_sha1
+        tj["_current"] = (tj.get("_src_sha1") == kernel_sources_sha1())
+        return tj
+    except Exception:
+        return {}
+
+
+_VALU_MIX = None
+
+
+def valu_cycles(symbol_fragment):
+    """Average issue cycles per vector instruction of the kernel instance whose name contains the fragment."""
+    global _VALU_MIX
+    if _VALU_MIX is None:
+        _VALU_MIX = load_valu_mix()
+    for k, v in _VALU_MIX.items():
+        if not k.startswith("_") and symbol_fragment and k.startswith(symbol_fragment):
+            return float(v["avg_cycles"])
+    return float(ISSUE_CYCLES_FULL)
 
 
 def parse_args():
@@ -129,29 +161,31 @@ MFMA_ISSUE_CYCLES = 8            # a 16x16x64 int8 MFMA holds its SIMD's vector 
 
 def issue_bound(short, case_ent, ms_per_step):
     """A kernel priced by its instruction issue (the search and encode kernels are not HBM problems):
-    bound time = sum over its instances of launches x waves / 1024 SIMDs x (4 cycles per vector instruction + 8
-    per matrix instruction) at 2.4 GHz; frac = bound time / measured time.  `parked` = share of wave cycles spent
+    bound time = sum over its instances of launches x waves / 1024 SIMDs x (the instance's cycles per vector
+    instruction, valu_cycles() above: 2 .. 4, + 8 per matrix instruction) at 2.4 GHz; frac = bound time / measured time.  `parked` = share of wave cycles spent
     at barriers / waits (SQ_WAIT_ANY), `issue_stalled` = SQ_WAIT_INST_ANY's share."""
     inst = {k: v for k, v in case_ent.items() if short in k}
     if not inst:
         return None
-    tb = vi = mi = wc = wa = wi = wv = 0.0
-    for v in inst.values():
+    tb = vi = mi = wc = wa = wi = wv = vcyc = 0.0
+    for name, v in inst.items():
         w = v["launches_per_step"] * v["waves_per_launch"]
         vi += w * v["valu_per_wave"]
+        vcyc += w * v["valu_per_wave"] * valu_cycles(name)
         mi += w * v["mfma_per_wave"]
         wc += w * v["wave_cycles"]
         wa += w * v["wait_any_cycles"]
         wi += w * v["wait_inst_cycles"]
         wv += w
-    tb = (vi * ISSUE_CYCLES + mi * MFMA_ISSUE_CYCLES) / SIMDS / CLOCK_HZ
+    tb = (vcyc + mi * MFMA_ISSUE_CYCLES) / SIMDS / CLOCK_HZ
     t = ms_per_step * 1e-3
     parked = wa / wc if wc else None
     frac = tb / t if t > 0 else None
     out = {"ms": round(ms_per_step, 4),
            "bound": "valu_issue" if (frac or 0) >= 0.5 or (parked or 0) < 0.4 else "barrier",
            "frac": round(frac, 4) if frac is not None else None,
-           "valu_per_wave": round(vi / wv, 1), "mfma_per_wave": round(mi / wv, 1), "waves_per_step": int(wv),
+           "valu_per_wave": round(vi / wv, 1), "cycles_per_valu": round(vcyc / vi, 3) if vi else None,
+           "mfma_per_wave": round(mi / wv, 1), "waves_per_step": int(wv),
            "mfma_pipe_frac": round(mi * 16 / SIMDS / CLOCK_HZ / t, 4) if mi else 0.0,
            "parked": round(parked, 3) if parked is not None else None,
            "issue_stalled": round(wi / wc, 3) if wc else None,
@@ -165,8 +199,8 @@ def per_kernel_bounds(p, n, nframes, kernel_ms, rice_bytes, pmc, with_residual=F
     hbm         least bytes the kernel must move / 8 TB/s
     fp64_issue  its un-fused fp64 operations (a multiply and an add per product: the reference's
                 rounding sequence) as wave instructions x 4 cycles over 1024 SIMDs at 2.4 GHz
-    valu_issue  its vector instructions per wave (SQ_INSTS_VALU / SQ_WAVES, PMC) x waves per SIMD x
-                4 cycles at 2.4 GHz
+    valu_issue  its vector instructions per wave (SQ_INSTS_VALU / SQ_WAVES, PMC) x waves per SIMD x its
+                cycles per vector instruction (2 .. 4: valu_cycles()) at 2.4 GHz
     frac = bound time / measured time."""
     import flake_amd
     ch = p.channels
@@ -200,8 +234,9 @@ def per_kernel_bounds(p, n, nframes, kernel_ms, rice_bytes, pmc, with_residual=F
             vpw, waves = ent.get("valu_per_wave"), ent.get("waves_per_launch")
             if vpw and waves and ent.get("frames") == nframes and ent.get("workload") == "configs[1]" \
                     and ch == 2 and n == 4096 and p.bits_per_sample == 16:
-                tb = vpw * (waves / SIMDS) * ISSUE_CYCLES / CLOCK_HZ
-                out[k] = {"ms": round(ms, 4), "bound": "valu_issue", "valu_per_wave": vpw,
+                cyc = valu_cycles(ent.get("symbol", "") + ("<16, 256, 0>" if ent.get("symbol") == "k_encode_pow2" else ""))
+                tb = vpw * (waves / SIMDS) * cyc / CLOCK_HZ
+                out[k] = {"ms": round(ms, 4), "bound": "valu_issue", "valu_per_wave": vpw, "cycles_per_valu": cyc,
                           "waves_per_launch": waves, "frac": round(tb / t, 4),
                           "source": f"profiles/pmc_traffic.json, tag {pmc.get('_tag')}",
                           "current": pmc.get("_current")}

@@ -771,12 +771,18 @@ def host_path(nframes=4096, n=4096, vbs=True):
     saved = {k: os.environ.get(k) for k in ("FLAKE_AMD_MD5", "FLAKE_AMD_BATCH")}
     try:
         os.environ["FLAKE_AMD_BATCH"] = str(nframes)
-        for key, md5 in (("ms_md5_off", "0"), ("ms_md5_on", "1")):
-            if md5 == "1" and not vbs:
+        for key, md5, pin in (("ms_md5_off", "0", True), ("ms_md5_off_pageable", "0", False), ("ms_md5_on", "1", True)):
+            if (md5 == "1" or not pin) and not vbs:
                 continue                                 # (the per-rank leg: the stream's bytes only)
             os.environ["FLAKE_AMD_MD5"] = md5
             enc = flake_amd.HostEncoder(level=5, channels=2, bits_per_sample=16, sample_rate=44100,
                                         block_size=n, order_method=flake_amd.OM_MAX)
+            if pin:      # the caller's two buffers page-locked in place (flake_amd_pin_buffers), once, before the loop
+                t0 = time.perf_counter()
+                prc = enc.lib.flake_amd_pin_buffers(C.byref(enc.ctx), flat.ctypes.data, flat.nbytes, out.ctypes.data,
+                                                    min(cap, flat.nbytes // 2 + (1 << 20)))
+                res["pin_buffers_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+                res["pin_buffers_rc"] = int(prc)
             best = None
             for call in range(4 if md5 == "0" else 2):   # the first call pays one-time allocations
                 t0 = time.perf_counter()
@@ -821,8 +827,11 @@ def host_path(nframes=4096, n=4096, vbs=True):
             vb[f"level{level}"] = {"blocks": nblk, "block_size": bs, "ms": round(best * 1e3, 3),
                                    "Msamples_per_s": round(nblk * bs * 2 / best / 1e6, 1)}
         res["vbs_presets_md5_off"] = vb
-        res["note"] = ("pageable host memory in and out; copies over PCIe, kernels and frame packing "
-                       "overlap across two handles; MD5 (sequential over the stream) on a helper thread")
+        res["note"] = ("ms_md5_off / ms_md5_on: the caller's PCM and output buffers page-locked in place once "
+                       "(flake_amd_pin_buffers, pin_buffers_ms); ms_md5_off_pageable: pageable memory in and out as in "
+                       "rounds 1-3; copies over PCIe, kernels and frame packing overlap across two handles; MD5 "
+                       "(sequential over the stream) on a helper thread.  An unmodified single-stream caller of "
+                       "flake_encode_frame() always has the MD5 on (encode.c:1006): it is MD5-bound at ms_md5_on")
     finally:
         for k, v in saved.items():
             if v is None:

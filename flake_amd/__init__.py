@@ -190,6 +190,7 @@ ABI_SYMBOLS = (
     "fhip_get_kernel_times", "fhip_prepare_ahead", "fhip_encode_frames_packed",
     "fhip_frames_packed_begin", "fhip_frames_packed_fetch", "fhip_encode_blocks_vbs_packed",
     "fhip_encode_blocks_vbs_dev", "fhip_order_search_bits",
+    "fhip_host_alloc", "fhip_host_free", "fhip_host_register", "fhip_host_unregister", "fhip_frames_packed_upload", "fhip_frames_packed_fetch_async", "fhip_frames_packed_fetch_wait",
 )
 
 
@@ -434,6 +435,8 @@ def load_host_library() -> C.CDLL:
     lib.flake_amd_encode_frames.argtypes = [cp, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                             C.c_size_t, C.c_void_p]
     lib.flake_amd_encode_frames.restype = C.c_longlong
+    lib.flake_amd_pin_buffers.argtypes = [cp, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    lib.flake_amd_pin_buffers.restype = C.c_int
     lib.flake_amd_encode_close.argtypes = [cp]
     lib.flake_amd_encode_close.restype = None
     lib.flake_amd_get_streaminfo.argtypes = [cp, C.POINTER(HostStreaminfo)]

@@ -44,6 +44,10 @@ struct fhip_ctx {
     size_t d_packed_bytes = 0;
     long long *d_offsets = nullptr;   // [max_frames + 1]
     long long packed_ready = 0;       // bytes waiting in d_packed between _begin and _fetch
+    const int32_t *uploaded_pcm = nullptr;   // fhip_frames_packed_upload: this host batch already lies in d_pcm
+    size_t uploaded_vals = 0;
+    hipEvent_t ev_fetch = nullptr;           // fhip_frames_packed_fetch_async: behind the download of d_packed (on aux[0])
+    bool fetch_pending = false;
     // variable-block-size batches (fhip_encode_blocks_vbs_dev): the piece tables k_vbs_plan leaves
     size_t ws_frames = 0;             // frame capacity of the subframe-indexed workspaces (>= max_frames:
                                       // a VBS handle has 20 slots per block, eight bins of fixed capacity)
@@ -477,6 +481,7 @@ void fhip_destroy(fhip_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->pre) { (void)hipStreamSynchronize(c->pre); (void)hipStreamDestroy(c->pre); }
     if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+    if (c->ev_fetch) { (void)hipEventSynchronize(c->ev_fetch); (void)hipEventDestroy(c->ev_fetch); }
     for (int h = 0; h < 2; h++) {
         if (c->ev_prep[h]) (void)hipEventDestroy(c->ev_prep[h]);
         if (c->ev_enc[h]) (void)hipEventDestroy(c->ev_enc[h]);
@@ -663,6 +668,27 @@ int fhip_encode_subframes(fhip_ctx *c, const fhip_batch *b)
     return fhip_sync(c);
 }
 
+int fhip_frames_packed_upload(fhip_ctx *c, const fhip_batch *b)
+{
+    if (!c || !b || !b->pcm) return fail(c, FHIP_E_INVALID, "null argument");
+    if (b->nframes < 0 || b->nframes > c->max_frames)
+        return fail(c, FHIP_E_INVALID, "nframes exceeds the handle's max_frames");
+    if (b->block_size < 1 || b->block_size > c->p.block_size)
+        return fail(c, FHIP_E_INVALID, "block_size out of range (encode.c:987)");
+    c->uploaded_pcm = nullptr;
+    if (b->nframes == 0) return FHIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t nvals = (size_t)b->nframes * (size_t)c->p.channels * (size_t)b->block_size;
+    const int64_t stride = fhip_frame_stride(&c->p, b->block_size);
+    int rc = ensure_staging(c, (size_t)b->nframes * c->p.channels * (size_t)((stride + 3) & ~(int64_t)3));
+    if (rc != FHIP_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_pcm, b->pcm, nvals * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->uploaded_pcm = b->pcm;
+    c->uploaded_vals = nvals;
+    return FHIP_OK;
+}
+
 int fhip_frames_packed_begin(fhip_ctx *c, const fhip_batch *b, int64_t *total_bytes)
 {
     if (!c || !b || !b->pcm || !total_bytes || !b->frame_bytes)
@@ -702,7 +728,11 @@ int fhip_frames_packed_begin(fhip_ctx *c, const fhip_batch *b, int64_t *total_by
         HIP_TRY(c, hipMemcpyAsync(c->d_fnum, b->frame_numbers, (size_t)b->nframes * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         fo.numbers = c->d_fnum;
     }
-    HIP_TRY(c, hipMemcpyAsync(c->d_pcm, b->pcm, nsub * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    const bool uploaded = c->uploaded_pcm == b->pcm && c->uploaded_vals == nsub * n;
+    c->uploaded_pcm = nullptr;
+    if (c->fetch_pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_fetch, 0));     // d_packed is still being read
+    if (!uploaded)
+        HIP_TRY(c, hipMemcpyAsync(c->d_pcm, b->pcm, nsub * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     rc = run_pipeline(c, c->d_pcm, b->nframes, b->block_size, c->d_info, nullptr, c->d_bits, slot,
                       nullptr, nullptr, fo, false);
     if (rc != FHIP_OK) return rc;
@@ -729,6 +759,69 @@ int fhip_frames_packed_fetch(fhip_ctx *c, uint8_t *out, int64_t out_cap)
         HIP_TRY(c, hipMemcpy(out, c->d_packed, (size_t)c->packed_ready, hipMemcpyDeviceToHost));
     }
     c->packed_ready = 0;
+    return FHIP_OK;
+}
+
+void *fhip_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void fhip_host_free(void *p)
+{
+    if (p && hipHostFree(p) != hipSuccess) (void)hipGetLastError();
+}
+
+int fhip_host_register(void *p, size_t bytes)
+{
+    if (!p || bytes == 0) return FHIP_E_INVALID;
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return FHIP_E_HIP;
+    }
+    return FHIP_OK;
+}
+
+int fhip_host_unregister(void *p)
+{
+    if (!p) return FHIP_E_INVALID;
+    if (hipHostUnregister(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return FHIP_E_HIP;
+    }
+    return FHIP_OK;
+}
+
+int fhip_frames_packed_fetch_async(fhip_ctx *c, uint8_t *out, int64_t out_cap)
+{
+    if (!c || !out) return fail(c, FHIP_E_INVALID, "null argument");
+    if (c->packed_ready > out_cap) return fail(c, FHIP_E_INVALID, "output buffer too small for the batch's frames");
+    if (c->packed_ready > 0) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        if (!c->ev_fetch) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fetch, hipEventDisableTiming));
+        // (_begin has synchronised the handle's stream: d_packed is complete; the copy runs on a stream of its own so
+        // that the handle's next upload does not queue behind it)
+        HIP_TRY(c, hipMemcpyAsync(out, c->d_packed, (size_t)c->packed_ready, hipMemcpyDeviceToHost, c->aux[0]));
+        HIP_TRY(c, hipEventRecord(c->ev_fetch, c->aux[0]));
+        c->fetch_pending = true;
+    }
+    c->packed_ready = 0;
+    return FHIP_OK;
+}
+
+int fhip_frames_packed_fetch_wait(fhip_ctx *c)
+{
+    if (!c) return FHIP_E_INVALID;
+    if (c->fetch_pending) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipEventSynchronize(c->ev_fetch));
+        c->fetch_pending = false;
+    }
     return FHIP_OK;
 }
 

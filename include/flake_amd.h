@@ -95,6 +95,14 @@ FLAKE_AMD_API long long flake_amd_encode_frames(FlakeAmdContext *s, const int *s
                                                 int nblocks, int block_size, int tail_size,
                                                 unsigned char *out, size_t out_size,
                                                 int *frame_sizes);
+/* Page-lock the buffers a caller hands to flake_amd_encode_frames() batch after batch (the loop of
+ * flake.c:622-663 reads every block into the same buffer), in place: copies from and to pageable memory run
+ * at about two thirds of the link's rate.  Either pointer may be NULL (left as it is); bytes = 0 releases a
+ * range.  The ranges must stay mapped until released, replaced or the stream is closed.  Returns 0, or -1
+ * when a range was refused (encoding works as before).  The look-ahead queue of flake_amd_encode_frame()
+ * and its frame buffer are page-locked by the library itself.  FLAKE_AMD_PIN=0 disables both. */
+FLAKE_AMD_API int flake_amd_pin_buffers(FlakeAmdContext *s, const int *samples, size_t sample_bytes,
+                                        unsigned char *out, size_t out_bytes);
 /* flake_encode_close(), encode.c:1010-1026 */
 FLAKE_AMD_API void flake_amd_encode_close(FlakeAmdContext *s);
 /* flake_get_streaminfo() / flake_write_streaminfo(), metadata.c:32-84 */

@@ -190,6 +190,30 @@ FHIP_API int fhip_encode_frames_packed(fhip_ctx *ctx, const fhip_batch *b, uint8
  * chunk's byte count (b->frame_bytes filled); _fetch brings the packed frames to `out`. */
 FHIP_API int fhip_frames_packed_begin(fhip_ctx *ctx, const fhip_batch *b, int64_t *total_bytes);
 FHIP_API int fhip_frames_packed_fetch(fhip_ctx *ctx, uint8_t *out, int64_t out_cap);
+/* Optional first step of _begin, for the same caller: only the upload of b->pcm (returns when the copy is
+ * done).  A following _begin for the same pcm / nframes / block_size skips its own upload.  Several handles
+ * that upload at the same time share the link and finish together; taking turns (each chunk's upload behind
+ * the one before it) lets every other phase -- kernels, the download of the packed frames -- run beside the
+ * next chunk's upload. */
+FHIP_API int fhip_frames_packed_upload(fhip_ctx *ctx, const fhip_batch *b);
+/* _fetch without waiting for the copy (it runs on a stream of the handle's own, beside the handle's next
+ * upload); `out` is complete once fhip_frames_packed_fetch_wait() has returned.  The handle's next _begin
+ * orders itself behind a download still in flight. */
+FHIP_API int fhip_frames_packed_fetch_async(fhip_ctx *ctx, uint8_t *out, int64_t out_cap);
+FHIP_API int fhip_frames_packed_fetch_wait(fhip_ctx *ctx);
+
+/* Page-locked host memory for the host-pointer entries above (libflake mallocs its frame buffer,
+ * encode.c:453-454; a caller's PCM is whatever it read the file into, flake.c:622-630): copies from
+ * and to pageable memory go through the runtime's bounce buffers at ~2/3 of the link's rate.
+ *   fhip_host_alloc / _free        a page-locked buffer (NULL when the runtime refuses)
+ *   fhip_host_register / _unregister   page-lock a range the caller owns, in place; the range must
+ *                                  stay mapped until it is unregistered.  FHIP_E_HIP when refused
+ *                                  (the copies then run as before).
+ * None of them needs a handle; all are optional. */
+FHIP_API void *fhip_host_alloc(size_t bytes);
+FHIP_API void fhip_host_free(void *p);
+FHIP_API int fhip_host_register(void *p, size_t bytes);
+FHIP_API int fhip_host_unregister(void *p);
 
 /* The same for a variable-block-size stream (encode_frame_vbs, vbs.c:85-119, per block):
  * nblocks blocks of block_size samples in host memory -> every block split by split_frame_v1

@@ -325,6 +325,45 @@ def test_long_blocks_through_the_host_layer(oracle, decoder, n):
         assert bytes(enc.streaminfo().md5sum) == pcm_md5(pcm, 16)
 
 
+def test_pinned_staging_is_transparent(monkeypatch):
+    """flake_amd_pin_buffers(): the caller's PCM and output ranges page-locked in place.  The stream is the
+    pageable one byte for byte, batch after batch through the same buffers, after a release, and with the
+    look-ahead queue's own page-locked buffers (FLAKE_AMD_LOOKAHEAD)."""
+    import ctypes as C
+    n, nblocks = 1152, 260
+    pcm = np.ascontiguousarray(flake_amd.synth_pcm(nblocks, n, 2, 16, first_frame=5).reshape(-1, 2), dtype=np.int32)
+    monkeypatch.setenv("FLAKE_AMD_BATCH", "4096")
+    monkeypatch.setenv("FLAKE_AMD_CHUNK", "64")
+    monkeypatch.setenv("FLAKE_AMD_PIN", "0")
+    with flake_amd.HostEncoder(5, block_size=n) as enc:
+        ref, ref_sizes = enc.encode_frames(pcm, n, 0)
+        assert enc.lib.flake_amd_pin_buffers(C.byref(enc.ctx), pcm.ctypes.data, pcm.nbytes, None, 0) == 0   # off: a no-op
+    monkeypatch.delenv("FLAKE_AMD_PIN")
+    cap = 64 + pcm.size * 5
+    out = np.zeros(cap, dtype=np.uint8)
+    sizes = np.zeros(nblocks, dtype=np.int32)
+    for rep in range(3):                              # the same buffers batch after batch, stream after stream
+        with flake_amd.HostEncoder(5, block_size=n) as enc:
+            assert enc.lib.flake_amd_pin_buffers(C.byref(enc.ctx), pcm.ctypes.data, pcm.nbytes, out.ctypes.data, cap) == 0
+            out[:] = 0
+            w = enc.lib.flake_amd_encode_frames(C.byref(enc.ctx), pcm.ctypes.data, nblocks, n, 0, out.ctypes.data, cap,
+                                                sizes.ctypes.data)
+            assert w == ref.size and (sizes == ref_sizes).all()
+            assert out[:w].tobytes() == ref.tobytes()
+            if rep == 1:                               # released: the next batch runs from pageable memory again
+                assert enc.lib.flake_amd_pin_buffers(C.byref(enc.ctx), pcm.ctypes.data, 0, out.ctypes.data, 0) == 0
+            w2 = enc.lib.flake_amd_encode_frames(C.byref(enc.ctx), pcm.ctypes.data, nblocks, n, 0, out.ctypes.data, cap,
+                                                 sizes.ctypes.data)
+            assert w2 >= w                             # (the frame numbers went on counting: longer headers)
+    # the look-ahead queue: the library's own page-locked buffers
+    monkeypatch.setenv("FLAKE_AMD_LOOKAHEAD", "64")
+    got = bytearray()
+    with flake_amd.HostEncoder(5, block_size=n, samples=nblocks * n) as enc:
+        for b in range(nblocks):
+            got += enc.encode_frame(pcm[b * n:(b + 1) * n])
+    assert bytes(got) == ref.tobytes()
+
+
 def test_chunked_two_handle_batches_equal_the_single_pass(monkeypatch, decoder):
     """Large uniform batches run in chunks through two handles on two host threads
     (run_chunked): the stream must be the single-pass stream byte for byte, sizes included,

@@ -554,7 +554,14 @@ int fhip_prepare_ahead(fhip_ctx *c, const fhip_batch *b)
     const fhip_params &p = c->p;
     const size_t cap = (size_t)c->max_frames * p.channels;
     if (!c->pre) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->pre, hipStreamNonBlocking));
+        // FHIP_AHEAD_PRIO=1 (measurements): the feeder's stream at the lowest priority, so that K1's one workgroup per
+        // CU is placed before K0's workgroups take the CU's registers (profiles/r04_overlap_*.txt)
+        int lo = 0, hi = 0;
+        const char *pv = getenv("FHIP_AHEAD_PRIO");
+        if (pv && pv[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->pre, hipStreamNonBlocking, lo));
+        else
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->pre, hipStreamNonBlocking));
         if (const char *v = getenv("FHIP_AHEAD_GATE")) c->ahead_gate = atoi(v);
         if (c->ahead_gate) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_k1, hipEventDisableTiming));
         for (int h = 0; h < 2; h++) {

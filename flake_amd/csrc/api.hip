@@ -28,6 +28,7 @@ struct fhip_ctx {
     int32_t *d_shift = nullptr;       // [nsub][32]
     int32_t *d_opt = nullptr;         // [nsub]
     int32_t *d_fin = nullptr;         // [nsub][FIN_STRIDE]
+    int32_t *d_tilectr = nullptr;     // [nsub / 32 + 1] K1's per-tile arrival counters (lag-split launches), zeroed once
     fhip_subframe_info *d_k0rec = nullptr;   // [nsub] K0's records (obits, wasted, ch_mode, row flag): K1 and
                                              // K3 read them here, K3 copies them into the caller's info[]
     // staging for the host-pointer entry points
@@ -243,8 +244,11 @@ static int run_range(fhip_ctx *c, hipStream_t st, bool prof, const int32_t *pcm,
     }
     if (lpc_path) {
         // K2 rides on K1's tail where K1 is the wave-typed kernel and the order fits registers
-        const bool lpc_tail = !fused && fhip::autocorr_does_lpc(nsub_hint, n, p.max_prediction_order);
-        const fhip::autocorr_lpc_out lo{p.lpc_precision, p.order_method, coefs, shift, opt, fin};
+        // (the arrival counters of a lag-split launch are indexed by the tile within the launch: a range of frames
+        // that does not start at the handle's first subframe -- the split-batch overlap -- keeps its own K2 launch)
+        const bool ctr_ok = sub0 == 0 && !rg;
+        const bool lpc_tail = !fused && fhip::autocorr_does_lpc(nsub_hint, n, p.max_prediction_order, ctr_ok);
+        const fhip::autocorr_lpc_out lo{p.lpc_precision, p.order_method, coefs, shift, opt, fin, ctr_ok ? c->d_tilectr : nullptr};
         {
             MaybeProf pr(c, prof, 1);
             HIP_TRY(c, fhip::launch_autocorr(st, smp, nsub, n, p.max_prediction_order, autoc,
@@ -442,6 +446,8 @@ int fhip_create(fhip_ctx **out, int device, const fhip_params *p, int max_frames
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_shift, nsub * FHIP_MAX_ORDER * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_opt, nsub * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_fin, nsub * fhip::FIN_STRIDE * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_tilectr, (nsub / 32 + 2) * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_tilectr, 0, (nsub / 32 + 2) * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_k0rec, nsub * sizeof(fhip_subframe_info));
     if (e == hipSuccess) e = hipMemset(c->d_k0rec, 0, nsub * sizeof(fhip_subframe_info));
     if (e == hipSuccess) e = hipMemset(c->d_fin, 0, nsub * fhip::FIN_STRIDE * sizeof(int32_t));
@@ -469,7 +475,7 @@ void fhip_destroy(fhip_ctx *c)
     if (c->pre) (void)hipStreamSynchronize(c->pre);
     drain_profile(c);
     for (hipEvent_t ev : c->event_pool) (void)hipEventDestroy(ev);
-    void *bufs[] = {c->d_smp, c->d_autoc, c->d_coefs, c->d_shift, c->d_opt, c->d_fin, c->d_k0rec,
+    void *bufs[] = {c->d_smp, c->d_autoc, c->d_coefs, c->d_shift, c->d_opt, c->d_fin, c->d_k0rec, c->d_tilectr,
                     c->d_pcm, c->d_info, c->d_res, c->d_bits, c->d_frames, c->d_fbytes, c->d_fnum,
                     c->d_packed, c->d_offsets, c->d_srcoff, c->d_frame_src, c->d_totals, c->d_order,
                     c->d_vcnt, c->d_first, c->d_stream_bytes, c->d_blk_bytes, c->d_blk_frames};

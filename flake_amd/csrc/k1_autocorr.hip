@@ -513,7 +513,7 @@ constexpr bool wt_probe_nohalo = false;
 // Schur and the quantiser for the workgroup's 32 subframes (max order <= LPCMO,
 // everything in registers): what a separate launch does in 8 us -- it is latency
 // bound, 128 waves on the whole chip -- costs about half of that here.
-struct wt_lpc_args { int precision, omethod; int32_t *coefs, *shift, *opt_order, *fin; };
+struct wt_lpc_args { int precision, omethod; int32_t *coefs, *shift, *opt_order, *fin; int32_t *tile_ctr; };
 template <int MO>
 __device__ __forceinline__ void lpc_reg_one(const double (&ac)[MO + 1], int s, int max_order, int precision,
                                             int omethod, int32_t *__restrict__ coefs,
@@ -557,7 +557,8 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
     // lsplit = 2 (small batches: fewer workgroups than CUs): two workgroups share a tile of 32
     // subframes, one walks the even lags (grp), the other the odd ones (grp1) -- a wave then carries
     // one or two chains instead of three, and the walk, which is what a small batch waits for, is
-    // that much shorter.  Both stage the same rows.  K2 cannot be the tail then.
+    // that much shorter.  Both stage the same rows.  K2 is then the tail of whichever of the two finishes
+    // second (round 4; a launch of its own before: 8.8 us of a 75 us step at 512 frames).
     if (lsplit == 2) {
         if (blk & 1) grp = grp1;
         blk >>= 1;
@@ -882,11 +883,41 @@ void k_autocorr_wt(const int32_t *__restrict__ smp, double *__restrict__ autoc,
         }
     }
     if constexpr (LPCMO > 0) {
-        __syncthreads();                                   // all lags of the 32 subframes are in acbuf
-        if (wv == 0 && lane < WT_SUB && sub0 + lane < nsub) {
+        bool tail_here = true;
+        if (lsplit == 2) {
+            // The tile's sums are complete when BOTH of its workgroups have stored theirs: an arrival counter per
+            // tile (cdna_hip_programming.md, split-K recipe).  Every storing wave drains its stores, the workgroup
+            // meets, one lane releases at agent scope and draws a ticket; the second arrival (odd ticket: the
+            // counters are never reset, two arrivals per tile and launch) acquires and runs the tail on sums read
+            // back from global memory.  Correct wherever the two workgroups were placed.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int last = 0;
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int ticket = __hip_atomic_fetch_add(&lpc.tile_ctr[blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = ticket & 1;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            // (only wave 0 runs the tail: its own lane 0 made the acquire, the wave's loads below follow it)
+            tail_here = wv == 0 && __builtin_amdgcn_readfirstlane(last) != 0;
+        } else {
+            __syncthreads();                               // all lags of the 32 subframes are in acbuf
+        }
+        if (tail_here && wv == 0 && lane < WT_SUB && sub0 + lane < nsub) {
             double ac[LPCMO + 1];
+            if (lsplit == 2) {
+                const double *row = autoc + (size_t)(sub0 + lane) * FHIP_MAX_LAGS;
 #pragma unroll
-            for (int i = 0; i <= LPCMO; i++) ac[i] = (i <= maxlag) ? acbuf[lane * FHIP_MAX_LAGS + i] : 0.0;
+                for (int i = 0; i <= LPCMO; i++) ac[i] = (i <= maxlag) ? row[i] : 0.0;
+            } else {
+#pragma unroll
+                for (int i = 0; i <= LPCMO; i++) ac[i] = (i <= maxlag) ? acbuf[lane * FHIP_MAX_LAGS + i] : 0.0;
+            }
             lpc_reg_one<LPCMO>(ac, sub0 + lane, maxlag, lpc.precision, lpc.omethod, lpc.coefs, lpc.shift,
                                lpc.opt_order, lpc.fin);
         }
@@ -962,12 +993,18 @@ bool autocorr_is_wave_typed(int nsub, int n, int max_order)
 
 // True when K1 will also run K2 (launch_autocorr with lpc outputs): the wave-typed
 // kernel and a maximum order the register version of K2 covers.
-bool autocorr_does_lpc(int nsub, int n, int max_order)
+bool autocorr_does_lpc(int nsub, int n, int max_order, bool have_tile_counters)
 {
     static const bool off = getenv("FHIP_NO_LPC_TAIL") != nullptr;      // measurements only
+    // K2 as the tail of a LAG-SPLIT launch (the second of a tile's two workgroups to arrive runs it; round 4) is
+    // built and tested but off: measured on MI355X the step gains 1 us at 512 stereo frames (K1 44.9 + K2 8.7 ->
+    // 50.6 us, step 0.0747 -> 0.0737 ms -- the K2 launch mostly ran in the shadow of K3's launch latency already)
+    // and LOSES where the chip is full: 2048 frames 0.1048 -> 0.1079 ms, configs[3] at 512 frames 0.138 -> 0.144.
+    static const bool split_tail = getenv("FHIP_SPLIT_TAIL") != nullptr;
     if (off || max_order > 12) return false;
     const ac_choice ch = pick_autocorr(nsub, n, max_order);
-    return ch.kernel == 2 && ch.split == 1;              // (a lag-split launch leaves K2 to its own kernel)
+    // (a lag-split launch needs the per-tile arrival counters for its tail, else K2 runs as its own kernel)
+    return ch.kernel == 2 && (ch.split == 1 || (have_tile_counters && split_tail));
 }
 
 bool autocorr_fuses_prepare(const fhip_params &p, int nsub, int n)
@@ -1076,7 +1113,7 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
     const int e0 = (ne + 1) / 2, e1 = ne - e0, o0 = (no + 1) / 2, o1 = no - o0;
     if (use_wt) {
         wt_groups gr, gr1{};
-        const int split = (pcm_fused || lpc_out) ? 1 : ch.split;
+        const int split = (pcm_fused || (lpc_out && !lpc_out->tile_ctr)) ? 1 : ch.split;
         int nch;
         if (split == 2) {
             // even lags over the four consumer waves of one workgroup, odd lags over those of its
@@ -1108,7 +1145,7 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
             if (max_order > 12 || pcm_fused) return hipErrorInvalidValue;
             la.precision = lpc_out->precision; la.omethod = lpc_out->omethod;
             la.coefs = lpc_out->coefs; la.shift = lpc_out->shift; la.opt_order = lpc_out->opt_order;
-            la.fin = lpc_out->fin;
+            la.fin = lpc_out->fin; la.tile_ctr = lpc_out->tile_ctr;
             lpcmo = (max_order <= 8) ? 8 : 12;
         }
         const size_t lds_all = lds + (lpcmo ? sizeof(double) * (size_t)WT_SUB * FHIP_MAX_LAGS : 0);
@@ -1133,8 +1170,9 @@ hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,
             }
             return hipGetLastError();
         }
-        if (lpcmo == 12) {                     // max_order 9..12: NCH 3 or 4
+        if (lpcmo == 12) {                     // max_order 9..12: NCH 3 or 4 (2 in a lag-split launch)
             switch (nch) {
+            case 2: LAUNCH_WT3(2, false, 12); break;
             case 3: LAUNCH_WT3(3, false, 12); break;
             case 4: LAUNCH_WT3(4, false, 12); break;
             default: return hipErrorInvalidValue;

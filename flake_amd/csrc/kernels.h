@@ -50,8 +50,11 @@ bool autocorr_fuses_prepare(const fhip_params &p, int nsub, int n);
 // channel mode / wasted bits and write smp_out.
 // With lpc_out (see autocorr_does_lpc) the kernel also does K2's work for its
 // subframes and launch_lpc is not needed.
-struct autocorr_lpc_out { int precision, omethod; int32_t *coefs, *shift, *opt_order, *fin; };
-bool autocorr_does_lpc(int nsub, int n, int max_order);
+// tile_ctr (optional): one arrival counter per tile of 32 subframes, zeroed once (fhip_create) -- with it a
+// lag-split launch (small batches: two workgroups per tile) still runs K2 as its tail, in whichever of a tile's
+// two workgroups arrives second (the counters run on, their parity tells the arrivals apart).
+struct autocorr_lpc_out { int precision, omethod; int32_t *coefs, *shift, *opt_order, *fin; int32_t *tile_ctr = nullptr; };
+bool autocorr_does_lpc(int nsub, int n, int max_order, bool have_tile_counters = false);
 // True when the wave-typed K1 (k_autocorr_wt) serves such a batch.
 bool autocorr_is_wave_typed(int nsub, int n, int max_order);
 hipError_t launch_autocorr(hipStream_t st, const int32_t *smp, int nsub, int n,

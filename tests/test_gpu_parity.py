@@ -395,6 +395,37 @@ def test_fused_prepare_path_subprocess():
     assert r.returncode == 0 and "fused ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_lag_split_tail_subprocess():
+    """FHIP_SPLIT_TAIL=1: in a lag-split K1 launch (small batches, two workgroups per tile of 32 subframes) the
+    second workgroup of a tile to arrive runs K2 as its tail (per-tile arrival counters, agent-scope release /
+    acquire).  Off by default (measured no faster); kept correct: several batches through one handle (the counters
+    run on from launch to launch), orders 8 and 12, a ragged last tile.  The switch is read once per process."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import flake_amd
+        from oraclelib import Oracle
+        from parity import assert_info_equal, assert_bits_equal
+        o = Oracle()
+        for kw, nfr in ((dict(order_method=flake_amd.OM_MAX), 200), (dict(order_method=flake_amd.OM_MAX, max_prediction_order=12), 77),
+                        (dict(), 130)):
+            p = flake_amd.level_params(5, **kw)
+            with flake_amd.Encoder(p, max_frames=nfr) as enc:
+                for rep in range(3):
+                    pcm = flake_amd.synth_pcm(nfr - rep, 4096, 2, 16, first_frame=100 * rep)
+                    got = enc.encode_subframes(pcm, 4096)
+                    exp = o.encode_subframes_batch(p, pcm, 4096, slot_bytes=got["slot_bytes"])
+                    assert_info_equal(got["info"], exp["info"], "split tail")
+                    assert_bits_equal(got["rice_bits"], exp["rice_bits"], exp["info"], "split tail")
+        print("split tail ok")
+    """ % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, FHIP_SPLIT_TAIL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "split tail ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("n", [512, 2048, 4096, 8192])
 def test_narrow_sample_rows(oracle, n):
     """K0 stores a channel as int16 when all its (shifted) samples fit: both channels

@@ -115,6 +115,12 @@ __device__ __forceinline__ uint32_t lshl_add_u32(uint32_t a, uint32_t sh, uint32
     asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(sh), "v"(b));
     return d;
 }
+__device__ __forceinline__ uint32_t add_u32(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_add_u32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ uint32_t xad_u32(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t d;

@@ -404,6 +404,246 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
     }
 }
 
+// rice.c:105-187 for ONE candidate by ONE wave from what mm_search32 left in LDS: the 64 sums of level 6 (s6, one per
+// lane) and, per level 8 / 7 / 6, the bit totals and RICE2 flags of the eight slots (wave, lane half) that evaluated
+// those levels' nodes beside the FIRs.  Levels 5 .. 0 as in wave_candidate_bits: a register pyramid, one trip through the
+// wave's heap, node q on lane q.
+__device__ __forceinline__ uint32_t wave_candidate_bits_s6(const uint32_t *__restrict__ s6, const uint4 *__restrict__ part,
+                                                           unsigned long long *__restrict__ heap, int n, int ord,
+                                                           int pmin, int pmax, int obits, int precision, int lane)
+{
+    uint32_t lb[9];
+#pragma unroll
+    for (int p = 0; p < 9; p++) lb[p] = 0;
+    uint32_t rice2 = 0;
+    {
+        // levels 8, 7, 6: eight partial totals (x: level 8, y: 7, z: 6, w: RICE2 flags by level bit)
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (lane < 8) v = part[lane];
+        uint32_t a = v.x, b = v.y, c = v.z, f = v.w;
+#define RSUM(X_) do { X_ += dpp_u32<0x111>(X_); X_ += dpp_u32<0x112>(X_); X_ += dpp_u32<0x114>(X_); } while (0)
+        RSUM(a); RSUM(b); RSUM(c);
+#undef RSUM
+        f |= dpp_u32<0x111>(f); f |= dpp_u32<0x112>(f); f |= dpp_u32<0x114>(f);
+        lb[8] = (uint32_t)__builtin_amdgcn_readlane((int)a, 7);
+        lb[7] = (uint32_t)__builtin_amdgcn_readlane((int)b, 7);
+        lb[6] = (uint32_t)__builtin_amdgcn_readlane((int)c, 7);
+        rice2 = (uint32_t)__builtin_amdgcn_readlane((int)f, 7) & 0x1C0u;
+    }
+    if (pmin <= 5) {
+        unsigned long long v = s6[lane];
+#define HEAP_STORE(S_) do { if ((lane & ((1 << (S_)) - 1)) == 0) heap[(1 << (6 - (S_))) - 1 + (lane >> (S_))] = v; } while (0)
+        v += row_shl_u64<1>(v); HEAP_STORE(1);
+        v += row_shl_u64<2>(v); HEAP_STORE(2);
+        v += row_shl_u64<4>(v); HEAP_STORE(3);
+        v += row_shl_u64<8>(v); HEAP_STORE(4);
+        v += __shfl_down(v, 16, WAVE); HEAP_STORE(5);
+        v += __shfl_down(v, 32, WAVE); HEAP_STORE(6);
+#undef HEAP_STORE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int p = ilog2_dev((uint32_t)(lane + 1));           // lanes 0..62: node `lane`, level p
+        uint32_t b = 0;
+        bool big = false;
+        const unsigned long long hs = heap[min(lane, 62)];
+        const unsigned long long total = heap[0];
+        if (lane < 63 && p >= pmin && p <= pmax) {
+            const int jn = lane + 1 - (1 << p);
+            const int cnt = (n >> p) - (jn == 0 ? ord : 0);
+            if (total < 0xFFE00000ull) big = rice_k_u32_nb((uint32_t)hs, (uint32_t)cnt, &b) > 14;
+            else big = ((hs >> 32) ? rice_k_fast(hs, cnt, &b) : rice_k_fast_u32((uint32_t)hs, cnt, &b)) > 14;
+        }
+        const uint32_t sc = wave_incl_scan_u32_dpp(b);
+        const unsigned long long bigm = __ballot(big);
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)sc, (2 << q) - 2);
+            const uint32_t lo = q ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (1 << q) - 2) : 0u;
+            lb[q] = hi - lo;
+            const unsigned long long lvl = ((1ull << ((2 << q) - 1)) - 1) & ~((1ull << ((1 << q) - 1)) - 1);
+            if (bigm & lvl) rice2 |= 1u << q;
+        }
+        __builtin_amdgcn_wave_barrier();                        // the heap is reused by the next candidate
+    }
+    uint32_t best = 0, method = 0;
+#pragma unroll
+    for (int p = 0; p < 9; p++) {
+        const uint32_t b = lb[p] + 4u * (1u << p);
+        if (p >= pmin && p <= pmax && (p == pmin || b <= best)) { best = b; method = (rice2 >> p) & 1u; }
+    }
+    uint32_t bits = (uint32_t)(ord * obits + 2) + (uint32_t)(4 + 5 + ord * precision);
+    bits += best;
+    bits += method + 4u;
+    return bits;
+}
+
+// ---------------------------------------------------------------------------
+// Round 4: the same FIRs for ALL 32 candidates in one pass on v_mfma_i32_32x32x32_i8 (256-thread instances)
+// ---------------------------------------------------------------------------
+// A tile is 32 samples x 32 candidates x 32 taps: rows = the samples of equal index o in the 32 leaves (runs of C) of a
+// block, columns = the candidate orders 1 .. 32, K = the taps of ONE limb pair.  The six limb products (c0 x0 | c0 x1 + c1 x0 |
+// c0 x2 + c1 x1 | c1 x2) are six instructions, equal weights chained through the accumulator input, so lo and hi come out as
+// before.  Against the 16x16x64 form (mm_search): the operand windows' funnel shifts serve 1024 elements instead of 256, both
+// halves of the candidates share them, the coefficient operands of all 32 rows are eight registers, and there is one pass, not
+// two.  Lane maps (tools/mfma_i8_32_probe.hip): A[m = l & 31][k = 16 (l >> 5) + j], B[k][n = l & 31], D[m = (r & 3) + 8 (r >> 2) +
+// 4 (l >> 5)][n = l & 31] in register r: a lane ends a block with the folded sums of 16 leaves of ITS candidate -- four aligned
+// groups of four consecutive leaves -- and evaluates the nodes of levels 8, 7 and 6 above them right there (rice.c:105-187: the
+// 448 of a candidate's 511 nodes that wave_candidate_bits spent a wave per candidate on); what goes to LDS is a sum per level-6
+// node and three bit totals per (wave, lane half).  Levels 5 .. 0: wave_candidate_bits_s6, a wave per candidate as before.
+// Every folded value must stay below 2^27 and every leaf below 2^29 (checked; true of any signal whose residuals are not many
+// times full scale): otherwise the subframe takes the general way (returns false).
+template <int C, int T>
+__device__ __forceinline__ bool mm_search32(const unsigned char *__restrict__ planes, const signed char *__restrict__ cl,
+                                            const int32_t *__restrict__ tab, const int32_t *__restrict__ img,
+                                            uint32_t *__restrict__ s6all, unsigned long long *__restrict__ heaps,
+                                            uint32_t *__restrict__ trial, int32_t *__restrict__ flagw, int n, int max_order,
+                                            int obits, int precision, int tid)
+{
+    static_assert(T == 256, "mm_search32: 256 leaves of one run each");
+    using Img = SmpImg<C, T>;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    typedef int v16i __attribute__((ext_vector_type(16)));
+    typedef const v4i __attribute__((address_space(3))) *lds_v4;
+    typedef const v2i __attribute__((address_space(3))) *lds_v2;
+    typedef const int __attribute__((address_space(3))) *lds_i;
+    constexpr int PB = mm_plane_bytes(C * T);
+    constexpr int NW = T / WAVE;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, cc = lane & 31;                  // K half / row half; this lane's candidate: order cc + 1
+    const unsigned lbase = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)planes;
+    const unsigned xbase = (unsigned)(size_t)(const __attribute__((address_space(3))) int32_t *)img;
+    uint4 *part = reinterpret_cast<uint4 *>(s6all + 32 * 64);   // [32 candidates][8 slots]
+
+    // the candidates' rows as B operands: limb 0 and limb 1, this lane's 16 taps of its K half
+    const v4i B0 = *reinterpret_cast<const v4i *>(cl + (0 * 32 + cc) * 32 + 16 * h);
+    const v4i B1 = *reinterpret_cast<const v4i *>(cl + (1 * 32 + cc) * 32 + 16 * h);
+    const int sh = tab[cc], sh16 = 16 - sh, ord = cc + 1;
+    const int pmm = tab[32 + cc];
+    const int pmin = pmm & 0xFF, pmax = pmm >> 8;
+    uint32_t bt8 = 0, bt7 = 0, bt6 = 0, r2 = 0;               // bit totals of this lane's nodes, RICE2 flags (bit = level)
+    uint32_t bad = 0;                                         // a folded value of 2^27 or a leaf of 2^29 and more
+
+    auto block = [&](auto first_c, const int blk) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        uint32_t acc[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0;
+        uint32_t uor = 0;
+        // this lane's operand bytes of tile o: 16 bytes from byte rowoff + o of a plane (a dword-aligned start);
+        // the samples of its rows: element o of the runs of leaves 32 blk + 4 h + (r & 3) + 8 (r >> 2)
+        const unsigned ad0 = lbase + (unsigned)(MM_HIST + C * (32 * blk + cc) - 16 * (h + 1));
+        const unsigned xr0 = xbase + 4u * (unsigned)((32 * blk + 4 * h) * 4 + Img::off(0));
+        const int lim0 = ord - C * 4 * h;                     // FIRST: row m's warm-up samples are o < lim0 - C (m - 4 h)
+        // Tiles in groups of four (o = 4 aa + bb): the misalignment bb is a compile-time constant, the group a real
+        // loop -- fully unrolled, the compiler hoisted per-tile addresses and masks out of it and spilled 140 .. 2400
+        // registers.  A group reads five dwords per plane (its window) and, per element, the sample itself.
+#pragma unroll 1
+        for (int aa = 0; aa < C / 4; aa++) {
+            const unsigned adg = ad0 + 4u * (unsigned)aa;
+            const unsigned xrg = xr0 + (unsigned)aa * (unsigned)(4 * (Img::off(4) - Img::off(0)));
+            int W[3][5];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+                for (int q = 0; q < 5; q++) W[pl][q] = *(lds_i)(size_t)(adg + (unsigned)pl * PB + 4u * q);
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) {
+                __builtin_amdgcn_sched_barrier(0);           // a tile at a time: tiles interleaved hold 64 result registers each
+                v4i Aop[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) {
+                    if (bb == 0) Aop[pl] = v4i{W[pl][0], W[pl][1], W[pl][2], W[pl][3]};
+                    else Aop[pl] = v4i{(int)__builtin_amdgcn_alignbyte(W[pl][1], W[pl][0], bb),
+                                       (int)__builtin_amdgcn_alignbyte(W[pl][2], W[pl][1], bb),
+                                       (int)__builtin_amdgcn_alignbyte(W[pl][3], W[pl][2], bb),
+                                       (int)__builtin_amdgcn_alignbyte(W[pl][4], W[pl][3], bb)};
+                }
+                const v16i Z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                const v16i P0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Aop[0], B0, Z, 0, 0, 0);
+                v16i P1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Aop[0], B1, Z, 0, 0, 0);
+                v16i P2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Aop[1], B1, Z, 0, 0, 0);
+                const v16i P3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Aop[2], B1, Z, 0, 0, 0);
+                P1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Aop[1], B0, P1, 0, 0, 0);
+                P2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(Aop[2], B0, P2, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int mr = (r & 3) + 8 * (r >> 2);                 // the row: leaf 32 blk + 4 h + mr of the subframe
+                    const int32_t xs = *(lds_i)(size_t)(xrg + 4u * (unsigned)(mr * 4 + bb));
+                    const int32_t lo = P0[r] + (P1[r] << 8), hi = P2[r] + (P3[r] << 8);
+                    const uint32_t q = lshl_add_u32((uint32_t)hi, (uint32_t)sh16, (uint32_t)(lo >> sh));
+                    const int32_t res = (int32_t)((uint32_t)xs - q);
+                    // rice.c:122; 2 res as a full-rate add (the compiler's own choice is the half-rate shift)
+                    uint32_t u = add_u32((uint32_t)res, (uint32_t)res) ^ (uint32_t)(res >> 31);
+                    if constexpr (FIRST) {
+                        // rice.c:85-94: partition 0 of every level starts at the order
+                        u = (4 * aa + bb < lim0 - C * mr) ? 0u : u;
+                    }
+                    acc[r] += u;
+                    uor |= u;
+                }
+            }
+        }
+
+        // ---- the nodes of levels 8, 7, 6 above this lane's 16 leaves ----
+        uint32_t lor = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) lor |= acc[r];
+        bad |= (uor >> 27) | (lor >> 29);
+        const uint32_t n8 = (uint32_t)(n >> 8), n7 = (uint32_t)(n >> 7), n6 = (uint32_t)(n >> 6);
+        const bool on8 = pmin <= 8 && pmax >= 8, on7 = pmin <= 7 && pmax >= 7, on6 = pmin <= 6 && pmax >= 6;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint32_t a0 = acc[4 * g], a1 = acc[4 * g + 1], a2 = acc[4 * g + 2], a3 = acc[4 * g + 3];
+            const uint32_t s70 = a0 + a1, s71 = a2 + a3, s60 = s70 + s71;
+            // node j of a level owns the subframe's first samples when it holds leaf 0: block 0, group 0, lane half 0
+            const bool head = FIRST && g == 0 && h == 0;
+            uint32_t b;
+            int k;
+            // (the subframe's first node of a level has n >> p - order samples, possibly none: the form with every corner,
+            // on the lanes that count it only)
+            auto node = [&](uint32_t sum, uint32_t cnt, bool first_node, bool on) {
+                if (FIRST && first_node) { b = 0; k = 0; if (on) k = rice_k_fast_u32(sum, (int)cnt - ord, &b); }
+                else k = rice_k_u32_nb(sum, cnt, &b);
+            };
+            if (__any(on8)) {
+                node(a0, n8, head, on8); bt8 += on8 ? b : 0u; r2 |= (on8 && k > 14) ? 0x100u : 0u;
+                node(a1, n8, false, on8); bt8 += on8 ? b : 0u; r2 |= (on8 && k > 14) ? 0x100u : 0u;
+                node(a2, n8, false, on8); bt8 += on8 ? b : 0u; r2 |= (on8 && k > 14) ? 0x100u : 0u;
+                node(a3, n8, false, on8); bt8 += on8 ? b : 0u; r2 |= (on8 && k > 14) ? 0x100u : 0u;
+            }
+            if (__any(on7)) {
+                node(s70, n7, head, on7); bt7 += on7 ? b : 0u; r2 |= (on7 && k > 14) ? 0x80u : 0u;
+                node(s71, n7, false, on7); bt7 += on7 ? b : 0u; r2 |= (on7 && k > 14) ? 0x80u : 0u;
+            }
+            if (__any(on6)) {
+                node(s60, n6, head, on6); bt6 += on6 ? b : 0u; r2 |= (on6 && k > 14) ? 0x40u : 0u;
+            }
+            s6all[cc * 64 + 8 * blk + 2 * g + h] = s60;
+        }
+    };
+#pragma unroll 1
+    for (int bq = 0; bq < 8 / NW; bq++) {
+        const int blk = wv * (8 / NW) + bq;                   // block of 32 leaves (wave-uniform)
+        if (blk == 0) block(std::true_type{}, 0);
+        else block(std::false_type{}, blk);
+    }
+    part[cc * 8 + 2 * wv + h] = make_uint4(bt8, bt7, bt6, r2);
+    if (__any(bad != 0u) && lane == 0) atomicOr(reinterpret_cast<uint32_t *>(flagw), 1u);
+    __syncthreads();
+    if (*flagw != 0) return false;                            // workgroup-uniform: the general way does this subframe
+    // ---- levels 5 .. 0 and the level choice per candidate, a wave each ----
+    for (int m = wv; m < max_order; m += NW) {
+        const int pm = tab[32 + m];
+        const uint32_t b = wave_candidate_bits_s6(s6all + m * 64, part + m * 8, heaps + wv * 128, n, m + 1, pm & 0xFF,
+                                                  pm >> 8, obits, precision, lane);
+        if (lane == 0) trial[m] = b;
+    }
+    __syncthreads();
+    return true;
+}
+
 // Geometries: runs of C samples (whole groups of four) in T threads, n = C * T.  The finest
 // partition sums there are -- the LEAVES -- are the 256 partitions of level 8 (T <= 256: one or
 // two per thread) or the T thread sums; every piece of a variable-block-size stream (k eighths of
@@ -583,7 +823,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             cshifts[32 + tid] = clamp_porder(P.min_partition_order, n, tid + 1) | (clamp_porder(P.max_partition_order, n, tid + 1) << 8);
         }
     }
-    if (tid < 2) l.misc[24 + tid] = 0;                 // rounds: "a thread sum left 32 bits", per round parity
+    if (tid < 3) l.misc[24 + tid] = 0;                 // rounds: "a thread sum left 32 bits", per round parity; 26: mm_search32's
 
     STAMP(0);
     const int omethod = P.order_method;
@@ -651,10 +891,23 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
             // only the orders above to the matrix pipe measured SLOWER -- SEARCH 1-32 at 16 bits 0.99 against
             // 0.89 ms, level 12 1.43 against 1.30 -- and a run-time choice between the two cost the 24-bit
             // path 6 %: the compiler must then keep the rounds' state alive across the matrix passes)
-            mm_search<C, T>(lds_raw + off[12], mm_cl, mm_tab, l.smp, reinterpret_cast<uint32_t *>(l.sums),
-                            reinterpret_cast<unsigned long long *>(lds_raw + off[14]), l.trial, n, max_order,
-                            e.obits, e.precision, tid);
-            mm_done = true;
+#ifndef FHIP_MM32
+#define FHIP_MM32 1
+#endif
+            // (runs of four -- the 1024-sample pieces of a variable-block-size stream -- keep the 16x16x64 form: a block
+            // is a single group of four tiles there and a wave has nothing to put beside the six dependent matrix
+            // instructions of a tile: 184 against 161 us for the level-12 batch's 16384 such pieces)
+            if constexpr (T == 256 && C >= 8 && FHIP_MM32) {
+                // all 32 candidates in one pass (32x32x32 tiles); false: residuals many times full scale, the general way
+                mm_done = mm_search32<C, T>(lds_raw + off[12], mm_cl, mm_tab, l.smp, reinterpret_cast<uint32_t *>(l.sums),
+                                            reinterpret_cast<unsigned long long *>(lds_raw + off[14]), l.trial,
+                                            &l.misc[26], n, max_order, e.obits, e.precision, tid);
+            } else {
+                mm_search<C, T>(lds_raw + off[12], mm_cl, mm_tab, l.smp, reinterpret_cast<uint32_t *>(l.sums),
+                                reinterpret_cast<unsigned long long *>(lds_raw + off[14]), l.trial, n, max_order,
+                                e.obits, e.precision, tid);
+                mm_done = true;
+            }
         }
     }
 

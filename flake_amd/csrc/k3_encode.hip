@@ -1123,6 +1123,14 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
 // order).  LDS use: l.sums[k * 64 + node], wave totals l.sums[320 + k * 16 + wave],
 // level bits l.kpar[k * 9 + p], RICE2 flags l.kpar[48 + k], parameters of every
 // node l.kpar[64 + k * 64 + node] (the winner's move to l.kpar[node] at the end).
+// Round 4: ONE WAVE PER ORDER behind the thread sums -- the form the order-search kernel's wave_candidate_bits has.  The
+// stamps of workgroup 0 (tools/stamps.py level2 / fixed) put rounds 2-3's version at 9.8-10.8 k cycles of the 18.7 k (n = 1152)
+// / 25.6 k (mono n = 4096) a subframe took: five 64-bit pyramids stored level by level, one thread per (order, level,
+// partition) node with an integer division to find its order, 64-bit parameter searches, LDS atomics per node, a serial
+// selection over 5 x 6 level words.  Here the waves reduce their thread sums to the 32 sums of level 5 (one to five DPP
+// steps, in 32 bits where a wave's total fits), one barrier, and wave k - min_order does rice.c:105-187 for order k alone:
+// levels 4 .. 0 by a register pyramid and one trip through its heap, node q on lane q, level totals by a wave scan, the level
+// choice on scalars; a second barrier and every thread compares the five results.
 template <int C, int T>
 __device__ __forceinline__ int fixed_search5(const FastCtx<C, T> &e, int min_order, int max_order,
                                              uint32_t *bits_out, int *porder_out, int *method_out)
@@ -1130,6 +1138,9 @@ __device__ __forceinline__ int fixed_search5(const FastCtx<C, T> &e, int min_ord
     using Img = SmpImg<C, T>;
     constexpr int LT = clog2(T);
     constexpr int NW = T / WAVE;
+    static_assert(T >= 64, "fixed_search5: whole waves");
+    const bool narrow = e.obits + 4 + clog2_up(C) + 6 <= 32;      // a wave's total fits 32 bits
+    const bool sum32 = e.obits + 4 + clog2_up(C) <= 32;           // a thread's sum does (a folded value is below 2^(obits+4))
     const FastLds &l = e.l;
     const int n = e.n, tid = e.tid, lane = e.lane;
     const int32_t *mine = l.smp + tid * Img::CS;
@@ -1149,15 +1160,10 @@ __device__ __forceinline__ int fixed_search5(const FastCtx<C, T> &e, int min_ord
 #pragma unroll
         for (int o = 0; o < C; o++) xs[o] = (uint32_t)mine[Img::off(o)];
     }
-    // differences of orders 1..3 at the sample in front of the run
     uint32_t p1 = h[0] - h[1];
     uint32_t p2 = h[0] - 2u * h[1] + h[2];
     uint32_t p3 = h[0] - 3u * h[1] + 3u * h[2] - h[3];
     uint32_t p0 = h[0];
-
-    // folded sums per order; a folded value is below 2^(obits+4)
-    const bool sum32 = e.obits + 4 + clog2_up(C) <= 32;
-    unsigned long long v[5];
     uint32_t a32[5] = {0, 0, 0, 0, 0};
     unsigned long long a64[5] = {0, 0, 0, 0, 0};
     const bool head = e.i0 < 4;                      // this run holds warm-up samples of some order
@@ -1184,120 +1190,93 @@ __device__ __forceinline__ int fixed_search5(const FastCtx<C, T> &e, int min_ord
             for (int k = 0; k < 5; k++) a64[k] += z[k];
         }
     }
+    // ---- the 32 sums of level 5: T / 32 threads each ----
+    unsigned long long *s5 = l.sums;                                        // [5][32]
+    unsigned long long *heaps = l.sums + 160;                               // [5][64] behind them
+    constexpr int ST = LT - 5;                                              // log2(threads per level-5 node): 1 .. 5
+    const bool writer = (lane & ((1 << ST) - 1)) == 0;
+    if (narrow) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) v[k] = sum32 ? (unsigned long long)a32[k] : a64[k];
-
-    // partition-order window over all orders: order 0 has the loosest clamp, the
-    // highest order the tightest (rice.c:148-155)
-    const int pmin_lo = clamp_porder(e.pmin_req, n, max_order);
-    const int pmax_hi = clamp_porder(e.pmax_req, n, min_order);
-
-    if (tid < 64) l.kpar[tid] = 0;                   // level bits and RICE2 flags
-#define PYR5_STORE(S_)                                                                      \
-    do {                                                                                    \
-        const int lev_ = LT - (S_);                                                         \
-        if (lev_ <= pmax_hi && lev_ >= pmin_lo && (lane & ((1 << (S_)) - 1)) == 0) {        \
-            _Pragma("unroll") for (int k = 0; k < 5; k++)                                   \
-                l.sums[k * 64 + (1 << lev_) - 1 + (tid >> (S_))] = v[k];                    \
-        }                                                                                   \
-    } while (0)
-    // a wave's total is below 2^(obits + 4 + log2(64 C)): in 32 bits one DPP add per step
-    const bool wave32 = e.obits + 4 + clog2_up(C) + 6 <= 32;
-    if (wave32) {
-        uint32_t w[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) w[k] = (uint32_t)v[k];
-#define PYR5_STEP32(S_, CTRL_)                                                              \
-    do {                                                                                    \
-        PYR5_STORE(S_);                                                                     \
-        _Pragma("unroll") for (int k = 0; k < 5; k++) { w[k] += dpp_u32<CTRL_>(w[k]); v[k] = w[k]; } \
-    } while (0)
-        PYR5_STEP32(0, 0x101);
-        PYR5_STEP32(1, 0x102);
-        PYR5_STEP32(2, 0x104);
-        PYR5_STEP32(3, 0x108);
-#undef PYR5_STEP32
-        PYR5_STORE(4);
-#pragma unroll
-        for (int k = 0; k < 5; k++) { w[k] += (uint32_t)__shfl_down((int)w[k], 16, WAVE); v[k] = w[k]; }
-        PYR5_STORE(5);
-#pragma unroll
-        for (int k = 0; k < 5; k++) { w[k] += (uint32_t)__shfl_down((int)w[k], 32, WAVE); v[k] = w[k]; }
-        PYR5_STORE(6);
+        for (int k = 0; k < 5; k++) {
+            uint32_t v = a32[k];
+            if (ST >= 1) v += dpp_u32<0x101>(v);
+            if (ST >= 2) v += dpp_u32<0x102>(v);
+            if (ST >= 3) v += dpp_u32<0x104>(v);
+            if (ST >= 4) v += dpp_u32<0x108>(v);
+            if (ST >= 5) v += (uint32_t)__shfl_down((int)v, 16, WAVE);
+            if (writer) s5[k * 32 + (tid >> ST)] = v;
+        }
     } else {
-        PYR5_STORE(0);
 #pragma unroll
-        for (int k = 0; k < 5; k++) v[k] += row_shl_u64<1>(v[k]);
-        PYR5_STORE(1);
-#pragma unroll
-        for (int k = 0; k < 5; k++) v[k] += row_shl_u64<2>(v[k]);
-        PYR5_STORE(2);
-#pragma unroll
-        for (int k = 0; k < 5; k++) v[k] += row_shl_u64<4>(v[k]);
-        PYR5_STORE(3);
-#pragma unroll
-        for (int k = 0; k < 5; k++) v[k] += row_shl_u64<8>(v[k]);
-        PYR5_STORE(4);
-#pragma unroll
-        for (int k = 0; k < 5; k++) v[k] += __shfl_down(v[k], 16, WAVE);
-        PYR5_STORE(5);
-#pragma unroll
-        for (int k = 0; k < 5; k++) v[k] += __shfl_down(v[k], 32, WAVE);
-        PYR5_STORE(6);
-    }
-#undef PYR5_STORE
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) l.sums[320 + k * 16 + e.wv] = v[k];
-    }
-    __syncthreads();
-
-    {
-        // one thread per (order, level, partition) node
-        const int first = (1 << pmin_lo) - 1, last = (2 << pmax_hi) - 2;
-        const int nn = last - first + 1;
-        for (int it = tid; it < 5 * nn; it += T) {
-            const int k = it / nn;
-            const int q = first + (it - k * nn);
-            const int p = ilog2_dev((uint32_t)(q + 1));
-            const int jn = q + 1 - (1 << p);
-            const int cnt = (n >> p) - (jn == 0 ? k : 0);
-            unsigned long long sum;
-            if (p <= LT - 7) {
-                const int span = NW >> p;              // waves per node
-                sum = 0;
-                for (int w = 0; w < span; w++) sum += l.sums[320 + k * 16 + jn * span + w];
-            } else {
-                sum = l.sums[k * 64 + q];
-            }
-            uint32_t b;
-            const int kk = rice_k_fast(sum, cnt, &b);
-            l.kpar[64 + k * 64 + q] = kk;
-            atomicAdd(reinterpret_cast<uint32_t *>(&l.kpar[k * 9 + p]), b);
-            if (kk > 14) atomicOr(reinterpret_cast<uint32_t *>(&l.kpar[48 + k]), 1u << p);
+        for (int k = 0; k < 5; k++) {
+            unsigned long long v = sum32 ? (unsigned long long)a32[k] : a64[k];
+            if (ST >= 1) v += row_shl_u64<1>(v);
+            if (ST >= 2) v += row_shl_u64<2>(v);
+            if (ST >= 3) v += row_shl_u64<4>(v);
+            if (ST >= 4) v += row_shl_u64<8>(v);
+            if (ST >= 5) v += __shfl_down(v, 16, WAVE);
+            if (writer) s5[k * 32 + (tid >> ST)] = v;
         }
     }
     __syncthreads();
-
-    // rice.c:127-138 and :157-171 per order, optimize.c:171-180 across them;
-    // evaluated by every thread from workgroup-uniform LDS words
-    int best = min_order, best_p = 0, best_m = 0;
-    uint32_t best_bits = 0;
-    for (int k = min_order; k <= max_order; k++) {
+    // ---- rice.c:105-187 per order, a wave each ----
+    for (int k = min_order + e.wv; k <= max_order; k += NW) {
         const int pmin = clamp_porder(e.pmin_req, n, k);
         const int pmax = clamp_porder(e.pmax_req, n, k);
-        const uint32_t lmask = (uint32_t)__builtin_amdgcn_readfirstlane(l.kpar[48 + k]);
-        uint32_t lb = 0, method = 0;
-        int bp = pmin;
-        for (int p = pmin; p <= pmax; p++) {
-            const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane(l.kpar[k * 9 + p]) + 4u * (1u << p);
-            if (p == pmin || b <= lb) { lb = b; bp = p; method = (lmask >> p) & 1u; }
+        unsigned long long *heap = heaps + (k - min_order) * 64;
+        unsigned long long v = (lane < 32) ? s5[k * 32 + lane] : 0ull;
+#define HEAP_STORE(S_) do { if (lane < 32 && (lane & ((1 << (S_)) - 1)) == 0) heap[(1 << (5 - (S_))) - 1 + (lane >> (S_))] = v; } while (0)
+        HEAP_STORE(0);
+        v += row_shl_u64<1>(v); HEAP_STORE(1);
+        v += row_shl_u64<2>(v); HEAP_STORE(2);
+        v += row_shl_u64<4>(v); HEAP_STORE(3);
+        v += row_shl_u64<8>(v); HEAP_STORE(4);
+        v += __shfl_down(v, 16, WAVE); HEAP_STORE(5);
+#undef HEAP_STORE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int p = ilog2_dev((uint32_t)(lane + 1));           // lanes 0..62: node `lane`, level p
+        uint32_t b = 0;
+        int kk = 0;
+        const unsigned long long hs = heap[min(lane, 62)];
+        const unsigned long long total = heap[0];
+        if (lane < 63 && p >= pmin && p <= pmax) {
+            const int jn = lane + 1 - (1 << p);
+            const int cnt = (n >> p) - (jn == 0 ? k : 0);
+            if (total < 0xFFE00000ull && cnt > 0) kk = rice_k_u32_nb((uint32_t)hs, (uint32_t)cnt, &b);
+            else kk = (hs >> 32) ? rice_k_fast(hs, cnt, &b) : rice_k_fast_u32((uint32_t)hs, cnt, &b);
         }
-        const uint32_t bits = (uint32_t)(k * e.obits + 2) + lb + method + 4u;
-        if (k == min_order || bits < best_bits) { best_bits = bits; best = k; best_p = bp; best_m = (int)method; }
+        if (lane < 64) l.kpar[64 + k * 64 + lane] = kk;           // every node's parameter (the winner's move below)
+        const uint32_t sc = wave_incl_scan_u32_dpp(b);
+        const unsigned long long bigm = __ballot(kk > 14);
+        uint32_t best = 0, method = 0;
+        int bp = pmin;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)sc, (2 << q) - 2);
+            const uint32_t lo = q ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (1 << q) - 2) : 0u;
+            const unsigned long long lvl = ((1ull << ((2 << q) - 1)) - 1) & ~((1ull << ((1 << q) - 1)) - 1);
+            const uint32_t bb = hi - lo + 4u * (1u << q);
+            if (q >= pmin && q <= pmax && (q == pmin || bb <= best)) { best = bb; bp = q; method = (bigm & lvl) ? 1u : 0u; }
+        }
+        if (lane == 0) {
+            l.kpar[4 * k + 0] = (int32_t)((uint32_t)(k * e.obits + 2) + best + method + 4u);      // rice.c:157-171
+            l.kpar[4 * k + 1] = bp;
+            l.kpar[4 * k + 2] = (int32_t)method;
+        }
     }
+    __syncthreads();
+    // optimize.c:171-180: first strict minimum from min_order upward
+    int best = min_order;
+    uint32_t best_bits = (uint32_t)__builtin_amdgcn_readfirstlane(l.kpar[4 * min_order]);
+    for (int k = min_order + 1; k <= max_order; k++) {
+        const uint32_t bits = (uint32_t)__builtin_amdgcn_readfirstlane(l.kpar[4 * k]);
+        if (bits < best_bits) { best_bits = bits; best = k; }
+    }
+    const int best_p = __builtin_amdgcn_readfirstlane(l.kpar[4 * best + 1]);
+    const int best_m = __builtin_amdgcn_readfirstlane(l.kpar[4 * best + 2]);
     // the winner's parameters to where the emit and the info record read them
-    __syncthreads();                                 // level words (l.kpar[0..52]) fully read
+    __syncthreads();                                 // result words (l.kpar[0..19]) fully read
     if (tid < 64) l.kpar[tid] = l.kpar[64 + best * 64 + tid];
     __syncthreads();
     *bits_out = best_bits;

@@ -30,10 +30,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "search":
 nch = 2
 if len(sys.argv) > 1 and sys.argv[1] == "fixed":          # configs[0] on the GPU: mono, fixed orders 0..4
     p = fa.level_params(2, block_size=4096, channels=1); nch = 1
-pcm = fa.synth_pcm(2048, 4096, nch, p.bits_per_sample)
+n = 4096
+if len(sys.argv) > 1 and sys.argv[1] == "level2":         # stereo, n 1152, fixed orders 0..4
+    p = fa.level_params(2); n = 1152
+pcm = fa.synth_pcm(2048, n, nch, p.bits_per_sample)
 enc = fa.Encoder(p, max_frames=2048)
 for _ in range(3):
-    out = enc.encode_subframes(pcm, 4096, want_residual=False)
+    out = enc.encode_subframes(pcm, n, want_residual=False)
 st = (C.c_longlong * 64)()
 rc = fa.load_library().fhip_debug_read_stamps(st)
 v = np.array(st[:13], dtype=np.int64)

@@ -497,7 +497,7 @@ __device__ __forceinline__ bool mm_search32(const unsigned char *__restrict__ pl
                                             const int32_t *__restrict__ tab, const int32_t *__restrict__ img,
                                             uint32_t *__restrict__ s6all, unsigned long long *__restrict__ heaps,
                                             uint32_t *__restrict__ trial, int32_t *__restrict__ flagw, int n, int max_order,
-                                            int obits, int precision, int tid)
+                                            int obits, int precision, int tid, bool force_bad)
 {
     static_assert(T == 256, "mm_search32: 256 leaves of one run each");
     using Img = SmpImg<C, T>;
@@ -523,7 +523,7 @@ __device__ __forceinline__ bool mm_search32(const unsigned char *__restrict__ pl
     const int pmm = tab[32 + cc];
     const int pmin = pmm & 0xFF, pmax = pmm >> 8;
     uint32_t bt8 = 0, bt7 = 0, bt6 = 0, r2 = 0;               // bit totals of this lane's nodes, RICE2 flags (bit = level)
-    uint32_t bad = 0;                                         // a folded value of 2^27 or a leaf of 2^29 and more
+    uint32_t bad = force_bad ? 1u : 0u;                       // a folded value of 2^27 or a leaf of 2^29 and more
 
     auto block = [&](auto first_c, const int blk) {
         constexpr bool FIRST = decltype(first_c)::value;
@@ -901,7 +901,7 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
                 // all 32 candidates in one pass (32x32x32 tiles); false: residuals many times full scale, the general way
                 mm_done = mm_search32<C, T>(lds_raw + off[12], mm_cl, mm_tab, l.smp, reinterpret_cast<uint32_t *>(l.sums),
                                             reinterpret_cast<unsigned long long *>(lds_raw + off[14]), l.trial,
-                                            &l.misc[26], n, max_order, e.obits, e.precision, tid);
+                                            &l.misc[26], n, max_order, e.obits, e.precision, tid, lg0.merged < 0);
             } else {
                 mm_search<C, T>(lds_raw + off[12], mm_cl, mm_tab, l.smp, reinterpret_cast<uint32_t *>(l.sums),
                                 reinterpret_cast<unsigned long long *>(lds_raw + off[14]), l.trial, n, max_order,
@@ -1321,7 +1321,11 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
     if (!order_search_supported(p, n) || !search_geometry(n, &fc, &ft)) return hipErrorInvalidValue;
     constexpr int G = 4;
     size_t off[16];
-    const LogPlan0 lg0 = (p.order_method == 6) ? log_plan_round0(p.min_prediction_order, p.max_prediction_order, G) : LogPlan0{0u, 0, 0};
+    LogPlan0 lg0 = (p.order_method == 6) ? log_plan_round0(p.min_prediction_order, p.max_prediction_order, G) : LogPlan0{0u, 0, 0};
+    // tests only: FHIP_MM32_FORCE_FALLBACK=1 makes mm_search32 report "residuals too large" for every subframe, so that
+    // the general way runs behind a finished matrix pass (the path a signal has to be pathological to reach)
+    static const bool force_fb = getenv("FHIP_MM32_FORCE_FALLBACK") != nullptr;
+    if (force_fb && p.order_method == 5) lg0.merged = -1;
     // SEARCH on 4096-sample blocks: the FIRs on the int8 matrix pipe (samples beyond 24 bits, constant
     // subframes and the other methods take the vector way inside the same kernel)
     static const bool no_mm = getenv("FHIP_NO_MM") != nullptr;              // measurements only

@@ -395,6 +395,37 @@ def test_fused_prepare_path_subprocess():
     assert r.returncode == 0 and "fused ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_matrix_search_fallback_subprocess():
+    """mm_search32 gives a subframe to the general way when its folded residuals or leaf sums leave the 32-bit fast
+    forms (values many times full scale) -- AFTER a finished matrix pass has used the workgroup's LDS.  Real signals
+    never get there; FHIP_MM32_FORCE_FALLBACK=1 sends every subframe that way: the whole bits[] table must still be
+    the oracle's, at every instance the matrix search serves (runs of 8 ... 28 and 16)."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import flake_amd
+        from oraclelib import Oracle
+        from parity import assert_info_equal, assert_bits_equal
+        o = Oracle()
+        for n in (2048, 3072, 4096, 5120, 6144, 7168):
+            for bps in (16, 24):
+                p = flake_amd.level_params(5, bits_per_sample=bps, block_size=n, order_method=flake_amd.OM_SEARCH,
+                                           max_prediction_order=32, max_partition_order=8)
+                pcm = flake_amd.synth_pcm(9, n, 2, bps, first_frame=n)
+                with flake_amd.Encoder(p, max_frames=9) as enc:
+                    got = enc.encode_subframes(pcm, n)
+                exp = o.encode_subframes_batch(p, pcm, n, slot_bytes=got["slot_bytes"])
+                assert_info_equal(got["info"], exp["info"], "mm fallback")
+                assert_bits_equal(got["rice_bits"], exp["rice_bits"], exp["info"], "mm fallback")
+        print("mm fallback ok")
+    """ % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, FHIP_MM32_FORCE_FALLBACK="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "mm fallback ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_lag_split_tail_subprocess():
     """FHIP_SPLIT_TAIL=1: in a lag-split K1 launch (small batches, two workgroups per tile of 32 subframes) the
     second workgroup of a tile to arrive runs K2 as its tail (per-tile arrival counters, agent-scope release /

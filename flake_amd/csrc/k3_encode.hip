@@ -1219,7 +1219,71 @@ __device__ __forceinline__ int fixed_search5(const FastCtx<C, T> &e, int min_ord
         }
     }
     __syncthreads();
-    // ---- rice.c:105-187 per order, a wave each ----
+    // ---- rice.c:105-187 per order ----
+    // Partition orders 0 .. 3 (levels 0-2's own setting): an order's 15 nodes fit 16 lanes, so FOUR orders share a wave
+    // (a DPP row each) and the fifth takes the next wave, all at once -- a wave per order ran two (256 threads) or three
+    // (128 threads) orders deep in wave 0.  Everything below is the wave-per-order code with lane -> (row, local lane) and
+    // compile-time widths; the level choice is made per row by its first lanes, not on scalars.
+    const int pmax_all = clamp_porder(e.pmax_req, n, min_order);             // order min_order has the loosest clamp
+    if (pmax_all <= 3) {
+        const int row = lane >> 4, ll = lane & 15;
+        for (int slot0 = e.wv * 4; min_order + slot0 <= max_order; slot0 += NW * 4) {
+            const int k = min_order + slot0 + row;
+            const bool valid = k <= max_order;
+            const int kc = min(k, max_order);
+            unsigned long long *heap = heaps + (kc - min_order) * 64;
+            // the 8 sums of level 3: four level-5 sums each
+            unsigned long long v = 0;
+            if (valid && ll < 8) v = s5[kc * 32 + 4 * ll] + s5[kc * 32 + 4 * ll + 1] + s5[kc * 32 + 4 * ll + 2] + s5[kc * 32 + 4 * ll + 3];
+            const bool leaf = valid && ll < 8;
+            if (leaf) heap[7 + ll] = v;
+            v += row_shl_u64<1>(v); if (leaf && (ll & 1) == 0) heap[3 + (ll >> 1)] = v;
+            v += row_shl_u64<2>(v); if (leaf && (ll & 3) == 0) heap[1 + (ll >> 2)] = v;
+            v += row_shl_u64<4>(v); if (leaf && ll == 0) heap[0] = v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // pmin / pmax of this row's order: rice.c:148-155 without the division (orders 0 .. 4)
+            const int L = ilog2_dev((uint32_t)n);
+            const int lq = (kc == 0) ? 31 : (kc == 1) ? L : (kc == 2) ? L - 1 : (kc == 3) ? ((n >= (3 << (L - 1))) ? L - 1 : L - 2) : L - 2;
+            const int lim = min(ilog2_dev((uint32_t)(n ^ (n - 1))), lq);
+            const int pmin = min(e.pmin_req, lim), pmax = min(e.pmax_req, lim);
+            const int p = ilog2_dev((uint32_t)(ll + 1));             // local lanes 0 .. 14: node ll, level p
+            uint32_t b = 0;
+            int kk = 0;
+            const unsigned long long hs = heap[min(ll, 14)];
+            const unsigned long long total = heap[0];
+            if (valid && ll < 15 && p >= pmin && p <= pmax) {
+                const int jn = ll + 1 - (1 << p);
+                const int cnt = (n >> p) - (jn == 0 ? kc : 0);
+                if (total < 0xFFE00000ull && cnt > 0) kk = rice_k_u32_nb((uint32_t)hs, (uint32_t)cnt, &b);
+                else kk = (hs >> 32) ? rice_k_fast(hs, cnt, &b) : rice_k_fast_u32((uint32_t)hs, cnt, &b);
+            }
+            if (valid) l.kpar[64 + kc * 64 + ll] = kk;                // every node's parameter (the winner's move below)
+            // level totals inside the row: an inclusive row scan, then level q = sc[2^(q+1) - 2] - sc[2^q - 2]
+            uint32_t sc = b;
+            sc += dpp_u32<0x111>(sc); sc += dpp_u32<0x112>(sc); sc += dpp_u32<0x114>(sc); sc += dpp_u32<0x118>(sc);
+            uint32_t big = kk > 14 ? 1u : 0u;                         // ... and "some parameter above 14" per level, the same way
+            uint32_t bs = big;
+            bs += dpp_u32<0x111>(bs); bs += dpp_u32<0x112>(bs); bs += dpp_u32<0x114>(bs); bs += dpp_u32<0x118>(bs);
+            const int base = lane & ~15;
+            uint32_t best = 0, method = 0;
+            int bp = pmin;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t hi = (uint32_t)__shfl((int)sc, base + (2 << q) - 2, WAVE);
+                const uint32_t lo = q ? (uint32_t)__shfl((int)sc, base + (1 << q) - 2, WAVE) : 0u;
+                const uint32_t bh = (uint32_t)__shfl((int)bs, base + (2 << q) - 2, WAVE);
+                const uint32_t bl = q ? (uint32_t)__shfl((int)bs, base + (1 << q) - 2, WAVE) : 0u;
+                const uint32_t bb = hi - lo + 4u * (1u << q);
+                if (q >= pmin && q <= pmax && (q == pmin || bb <= best)) { best = bb; bp = q; method = (bh != bl) ? 1u : 0u; }
+            }
+            if (valid && ll == 0) {
+                l.kpar[4 * kc + 0] = (int32_t)((uint32_t)(kc * e.obits + 2) + best + method + 4u);      // rice.c:157-171
+                l.kpar[4 * kc + 1] = bp;
+                l.kpar[4 * kc + 2] = (int32_t)method;
+            }
+        }
+    } else
     for (int k = min_order + e.wv; k <= max_order; k += NW) {
         const int pmin = clamp_porder(e.pmin_req, n, k);
         const int pmax = clamp_porder(e.pmax_req, n, k);

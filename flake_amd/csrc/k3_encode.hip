@@ -1002,8 +1002,137 @@ __device__ __forceinline__ void fold_residuals(const FastCtx<C, T> &e, const int
     }
 }
 
+// rice.c:105-187 by ONE wave from the workgroup's thread sums as 32-bit leaves in LDS -- the order-search kernel's
+// wave_candidate_bits with the outputs the emit needs: every node's parameter at its heap index in kpar[], the level
+// chosen and its method.  A lane takes NL / 64 consecutive leaves and owns the nodes above them down to level 6 (four at
+// level 8, two at 7, one at 6); levels 5 .. 0 are 63 nodes built through a heap in LDS and evaluated one per lane; level
+// totals by a wave reduction / a wave scan; no barrier, no atomics (round 4: the workgroup-wide form below it took 4.7 k of a
+// subframe's 14.6 k cycles -- a 64-bit pyramid stored level by level, a thread per node with an LDS atomic each, a
+// serial choice over nine level words in every wave).
+template <int NL>
+__device__ __forceinline__ void wave_rice_leaves(const uint32_t *__restrict__ leaf, unsigned long long *__restrict__ heap,
+                                                 int32_t *__restrict__ kpar, int n, int ord, int pmin, int pmax, int lane,
+                                                 uint32_t *best_out, int *bp_out, uint32_t *method_out)
+{
+    constexpr int LPL = NL / 64;                // leaves per lane: 4 (256 leaves), 8
+    constexpr int L8 = LPL / 4;                 // leaves per level-8 node
+    static_assert(LPL >= 4 && LPL <= 16, "wave_rice_leaves: 256 .. 1024 leaves");
+    uint32_t lf[LPL];
+#pragma unroll
+    for (int q = 0; q < LPL; q += 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(leaf + lane * LPL + q);
+        lf[q] = v.x; lf[q + 1] = v.y; lf[q + 2] = v.z; lf[q + 3] = v.w;
+    }
+    unsigned long long s8[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        s8[i] = 0;
+#pragma unroll
+        for (int q = 0; q < L8; q++) s8[i] += lf[i * L8 + q];
+    }
+    const unsigned long long s7[2] = {s8[0] + s8[1], s8[2] + s8[3]};
+    const unsigned long long s6 = s7[0] + s7[1];
+    // the usual case -- every sum below 0xFFE00000, no empty first partition -- in straight-line 32-bit code
+    const bool corners = __any(s6 >= 0xFFE00000ull) || ((n >> pmax) - ord) <= 0;
+    uint32_t lb[9];
+#pragma unroll
+    for (int p = 0; p < 9; p++) lb[p] = 0;
+    uint32_t rice2 = 0;                         // bit p: some parameter of level p is above 14
+    auto levels = [&](auto fast_c) {
+        constexpr bool FAST = decltype(fast_c)::value;
+        auto node = [&](unsigned long long sum, int p, int jn, uint32_t *b) -> int {
+            const int cnt = (n >> p) - (jn == 0 ? ord : 0);
+            int k;
+            if constexpr (FAST) k = rice_k_u32_nb((uint32_t)sum, (uint32_t)cnt, b);
+            else k = (sum >> 32) ? rice_k_fast(sum, cnt, b) : rice_k_fast_u32((uint32_t)sum, cnt, b);
+            kpar[(1 << p) - 1 + jn] = k;
+            return k;
+        };
+        {
+            uint32_t b8 = 0, b7 = 0, b6 = 0;
+            bool k8 = false, k7 = false, k6 = false;
+            if (pmax >= 8 && pmin <= 8) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) { uint32_t b; k8 |= node(s8[i], 8, 4 * lane + i, &b) > 14; b8 += b; }
+            }
+            if (pmax >= 7 && pmin <= 7) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) { uint32_t b; k7 |= node(s7[i], 7, 2 * lane + i, &b) > 14; b7 += b; }
+            }
+            if (pmax >= 6 && pmin <= 6) { uint32_t b; k6 = node(s6, 6, lane, &b) > 14; b6 = b; }
+            if (pmax >= 6) {
+                uint32_t t8 = b8, t7 = b7, t6 = b6;
+#define WSUM(X_) do { X_ += dpp_u32<0x111>(X_); X_ += dpp_u32<0x112>(X_); X_ += dpp_u32<0x114>(X_);       \
+                      X_ += dpp_u32<0x118>(X_); X_ += dpp_u32<0x142, 0xA>(X_); X_ += dpp_u32<0x143, 0xC>(X_); } while (0)
+                WSUM(t8); WSUM(t7); WSUM(t6);
+#undef WSUM
+                lb[8] = (uint32_t)__builtin_amdgcn_readlane((int)t8, 63);
+                lb[7] = (uint32_t)__builtin_amdgcn_readlane((int)t7, 63);
+                lb[6] = (uint32_t)__builtin_amdgcn_readlane((int)t6, 63);
+                if (__any(k8)) rice2 |= 1u << 8;
+                if (__any(k7)) rice2 |= 1u << 7;
+                if (__any(k6)) rice2 |= 1u << 6;
+            }
+        }
+        if (pmin <= 5) {
+            unsigned long long v = s6;
+#define HEAP_STORE(S_) do { if ((lane & ((1 << (S_)) - 1)) == 0) heap[(1 << (6 - (S_))) - 1 + (lane >> (S_))] = v; } while (0)
+            v += row_shl_u64<1>(v); HEAP_STORE(1);
+            v += row_shl_u64<2>(v); HEAP_STORE(2);
+            v += row_shl_u64<4>(v); HEAP_STORE(3);
+            v += row_shl_u64<8>(v); HEAP_STORE(4);
+            v += __shfl_down(v, 16, WAVE); HEAP_STORE(5);
+            v += __shfl_down(v, 32, WAVE); HEAP_STORE(6);
+#undef HEAP_STORE
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int p = ilog2_dev((uint32_t)(lane + 1));           // lanes 0..62: node `lane`, level p
+            uint32_t b = 0;
+            bool big = false;
+            const unsigned long long hs = heap[min(lane, 62)];
+            const unsigned long long total = heap[0];       // the block's total bounds every node of the heap
+            if (lane < 63 && p >= pmin && p <= pmax) {
+                const int jn = lane + 1 - (1 << p);
+                const int cnt = (n >> p) - (jn == 0 ? ord : 0);
+                int k;
+                if (FAST && total < 0xFFE00000ull) k = rice_k_u32_nb((uint32_t)hs, (uint32_t)cnt, &b);
+                else k = (hs >> 32) ? rice_k_fast(hs, cnt, &b) : rice_k_fast_u32((uint32_t)hs, cnt, &b);
+                kpar[lane] = k;
+                big = k > 14;
+            }
+            const uint32_t sc = wave_incl_scan_u32_dpp(b);
+            const unsigned long long bigm = __ballot(big);
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)sc, (2 << q) - 2);
+                const uint32_t lo = q ? (uint32_t)__builtin_amdgcn_readlane((int)sc, (1 << q) - 2) : 0u;
+                lb[q] = hi - lo;
+                const unsigned long long lvl = ((1ull << ((2 << q) - 1)) - 1) & ~((1ull << ((1 << q) - 1)) - 1);
+                if (bigm & lvl) rice2 |= 1u << q;
+            }
+        }
+    };
+    if (!corners) levels(std::true_type{});
+    else levels(std::false_type{});
+    // rice.c:127-138
+    uint32_t best = 0, method = 0;
+    int bp = pmin;
+#pragma unroll
+    for (int p = 0; p < 9; p++) {
+        const uint32_t b = lb[p] + 4u * (1u << p);
+        if (p >= pmin && p <= pmax && (p == pmin || b <= best)) { best = b; bp = p; method = (rice2 >> p) & 1u; }
+    }
+    *best_out = best;
+    *bp_out = bp;
+    *method_out = method;
+}
+
 // rice.c:105-187 on the residuals in r[]; all threads call it.
-template <int C, int T>
+// ONE_WAVE: the search by one wave from the thread sums (wave_rice_leaves) -- the instances whose searches are large
+// (MODE 3: orders 9 .. 16 and every order-search winner, partition orders up to 8; MODE 2) take it: configs[2]'s K3
+// 112 -> 82 us, configs[3]'s 322 -> 297.  The lean instance (MODE 0, partition orders <= 5 at the headline: 63 nodes) measured
+// the same either way (58.5 us) and keeps the workgroup-wide form, which fits its 96 registers without a spill.
+template <int C, int T, bool ONE_WAVE = false>
 __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, const int32_t (&r)[C],
                                                      uint32_t (&u)[C], int order, bool lpc,
                                                      int *porder_out, int *method_out, uint32_t *umax_out)
@@ -1036,6 +1165,39 @@ __device__ __forceinline__ uint32_t rice_search_fast(const FastCtx<C, T> &e, con
         for (int o = 0; o < C; o++) v += u[o];
     }
 
+    if constexpr (ONE_WAVE && T >= 256 && T <= 512) {
+        // One wave does the whole search from the thread sums (wave_rice_leaves); the others meet it at the second
+        // barrier.  Thread sums beyond 32 bits (residuals of 32-bit noise) keep the workgroup-wide form below.
+        uint32_t *leaf = reinterpret_cast<uint32_t *>(l.sums);          // [T] (2 KB at most), the heap behind them
+        leaf[tid] = (uint32_t)v;
+        const int wide = __any((v >> 32) != 0ull) ? 1 : 0;
+        if (lane == 0) l.wtot[e.wv] = (unsigned long long)wide;
+        __syncthreads();
+        int any_wide = 0;
+#pragma unroll
+        for (int w = 0; w < T / WAVE; w++) any_wide |= (int)l.wtot[w];
+        if (__builtin_amdgcn_readfirstlane(any_wide) == 0) {
+            if (e.wv == 0) {
+                uint32_t best;
+                int bp;
+                uint32_t method;
+                wave_rice_leaves<T>(leaf, l.sums + 256, l.kpar, n, order, pmin, pmax, lane, &best, &bp, &method);
+                if (lane == 0) { l.lvl_bits[0] = best; l.lvl_bits[1] = (uint32_t)bp; l.lvl_bits[2] = method; }
+            }
+            __syncthreads();
+            const uint32_t best = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.lvl_bits[0]);
+            const int bp = __builtin_amdgcn_readfirstlane((int)l.lvl_bits[1]);
+            const uint32_t method = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.lvl_bits[2]);
+            uint32_t bits = (uint32_t)(order * e.obits + 2);            // rice.c:157-171
+            if (lpc) bits += (uint32_t)(4 + 5 + order * e.precision);
+            bits += best;
+            bits += method + 4u;
+            *porder_out = bp;
+            *method_out = (int)method;
+            return bits;
+        }
+        __syncthreads();             // (leaf[] and the wave flags are read; the pyramid below stores over them)
+    }
     // (callers guarantee a barrier between the previous search's reads of
     // lvl_bits/lvl_meth and this reset)
     if (tid < 12) { l.lvl_bits[tid] = 0; l.lvl_meth[tid] = 0; }
@@ -1709,7 +1871,7 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
                     if (!wide_done) fir_lpc<C, T, (MODE == 3) ? 4 : 8>(e, r, ord, cshift);
                 }
                 STAMP(3);
-                b = rice_search_fast<C, T>(e, r, u, ord, true, &porder, &method, &umax_run);
+                b = rice_search_fast<C, T, (MODE == 2 || MODE == 3)>(e, r, u, ord, true, &porder, &method, &umax_run);
                 STAMP(8);
             }
             if (final_pass) { est_bits = b; break; }

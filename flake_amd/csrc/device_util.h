@@ -156,19 +156,7 @@ __device__ __forceinline__ int rice_best_k(uint64_t sum, int n, uint32_t *bits_o
     return kb;
 }
 
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-    return v;   // valid in lane 0
-}
-
-__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v |= (uint32_t)__shfl_down((int)v, off, WAVE);
-    return v;   // valid in lane 0
-}
+// (wave_sum_u64 / wave_or_u32, below the DPP helpers: reductions without the LDS crossbar)
 
 // inclusive scan of a u64 across the wave
 __device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v, int lane)
@@ -209,6 +197,32 @@ __device__ __forceinline__ unsigned long long row_shl_u64(unsigned long long v)
     const uint32_t lo = dpp_u32<0x100 + D>((uint32_t)v);
     const uint32_t hi = dpp_u32<0x100 + D>((uint32_t)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
+}
+
+// Wave reductions, valid in lane 0, by DPP inside the 16-lane rows and three lane reads across them.  (Rounds 1-3 used
+// shuffles -- ds_bpermute, six dependent trips through the CU's one LDS crossbar per value: K0's four 64-bit sums and
+// four ORs were 72 of them per wave, 4600 per CU and launch, and K0 ran at 41 us where a kernel that only moves its bytes
+// takes 29, tools/hbm_probe.hip.)
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    v += row_shl_u64<1>(v);
+    v += row_shl_u64<2>(v);
+    v += row_shl_u64<4>(v);
+    v += row_shl_u64<8>(v);
+    const int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+#define ROWSUM_(R_) (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(hi, R_) << 32) | (uint32_t)__builtin_amdgcn_readlane(lo, R_))
+    return v + ROWSUM_(16) + ROWSUM_(32) + ROWSUM_(48);      // lane 0: rows 0 + 1 + 2 + 3
+#undef ROWSUM_
+}
+
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+{
+    v |= dpp_u32<0x101>(v);
+    v |= dpp_u32<0x102>(v);
+    v |= dpp_u32<0x104>(v);
+    v |= dpp_u32<0x108>(v);
+    return v | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) | (uint32_t)__builtin_amdgcn_readlane((int)v, 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 48);      // lane 0
 }
 
 // x86-64 cvttsd2si semantics for (int)double: out-of-range and NaN give

@@ -1019,7 +1019,7 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
                 const int k = 7 - j;
                 m0.cnt_ix[j] = k;
                 m0.wg0[j] = wg;
-                wg += fhip::prepare_bins_workgroups(vb.n[k], vb.cap[k]);
+                wg += fhip::prepare_bins_workgroups(vb.n[k], vb.cap[k], vb.n[7]);
                 m0.n[j] = vb.n[k];
                 m0.unit0[j] = vb.slot0[k];
                 m0.cap[j] = vb.cap[k];

@@ -532,7 +532,12 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
 // K0 for every bin of a ragged (variable-block-size) stereo batch in ONE launch (kernels.h: MultiBin;
 // unit0 = the bin's first frame slot, cnt = live frames per bin on the device): eight launches of
 // ~10 us each were 55-80 us of a batch whose other stages already run once over all bins.
-__global__ __launch_bounds__(NT, 2)          // (the variant of eight quads per thread holds 96 samples in registers)
+// QLIM: the longest bin's quads in units of NT.  A kernel's registers are those of its widest path: with the
+// variants of five and eight quads per thread compiled in, every bin ran at 256 VGPRs (two waves per SIMD) and a
+// level-12 batch of 8192 blocks took 355 us for bytes that take 80; blocks of up to 4096 samples (QLIM 4)
+// need four quads per thread at most.
+template <int QLIM>
+__global__ __launch_bounds__(NT, QLIM <= 4 ? 4 : 2)   // (the variant of eight quads per thread holds 96 samples in registers)
 void k_prepare_stereo_bins(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
                            fhip_subframe_info *__restrict__ info, int bps, int estimate,
                            const long long *__restrict__ frame_src, MultiBin mb)
@@ -549,7 +554,19 @@ void k_prepare_stereo_bins(const int32_t *__restrict__ pcm, int32_t *__restrict_
     const int nar = mb.narrow[k];
     const int quads = n >> 2;
 #define BODY_(M_, W_) prepare_stereo_body<M_, W_, true>(pcm, smp_k, info_k, n, bps, estimate, nar, nframes, src_k, blk)
-    FHIP_STEREO_GEOM(quads, BODY_);
+    if constexpr (QLIM <= 4) {
+        // FHIP_STEREO_GEOM's rule up to 4 NT quads
+        if (quads <= 64) BODY_(1, 1);
+        else if (quads <= 128) BODY_(1, 2);
+        else if (quads <= 192) BODY_(3, 1);
+        else if (quads <= NT) BODY_(1, 4);
+        else if (quads <= 320) BODY_(2, 4);         // (five quads per thread would set this kernel's registers)
+        else if (quads <= 2 * NT) BODY_(2, 4);
+        else if (quads <= 3 * NT) BODY_(3, 4);
+        else BODY_(4, 4);
+    } else {
+        FHIP_STEREO_GEOM(quads, BODY_);
+    }
 #undef BODY_
 }
 
@@ -628,12 +645,13 @@ bool prepare_bins_supported(const fhip_params &p, const int *n, int nbins)
     return true;
 }
 
-int prepare_bins_workgroups(int n, int cap)
+int prepare_bins_workgroups(int n, int cap, int nmax)
 {
     int wpf = 4;
 #define WPF_(M_, W_) wpf = W_
     FHIP_STEREO_GEOM(n >> 2, WPF_);
 #undef WPF_
+    if ((nmax >> 2) <= 4 * NT && (n >> 2) > NT && (n >> 2) <= 320) wpf = 4;       // k_prepare_stereo_bins<4>'s rule
     const int fpw = 4 / wpf;                       // frames per workgroup
     return (cap + fpw - 1) / fpw;
 }
@@ -644,8 +662,14 @@ hipError_t launch_prepare_bins(hipStream_t st, const fhip_params &p, const int32
     if (!prepare_bins_supported(p, mb.n, mb.nbins) || !frame_src) return hipErrorInvalidValue;
     const int blocks = mb.wg0[mb.nbins];
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_prepare_stereo_bins, dim3(blocks), dim3(NT), 0, st, pcm, smp, info, p.bits_per_sample,
-                       p.stereo_method == 1 ? 1 : 0, frame_src, mb);
+    int nmax = 0;
+    for (int k = 0; k < mb.nbins; k++) nmax = mb.n[k] > nmax ? mb.n[k] : nmax;
+    if ((nmax >> 2) <= 4 * NT)
+        hipLaunchKernelGGL(k_prepare_stereo_bins<4>, dim3(blocks), dim3(NT), 0, st, pcm, smp, info, p.bits_per_sample,
+                           p.stereo_method == 1 ? 1 : 0, frame_src, mb);
+    else
+        hipLaunchKernelGGL(k_prepare_stereo_bins<8>, dim3(blocks), dim3(NT), 0, st, pcm, smp, info, p.bits_per_sample,
+                           p.stereo_method == 1 ? 1 : 0, frame_src, mb);
     return hipGetLastError();
 }
 

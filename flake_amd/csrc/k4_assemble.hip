@@ -626,115 +626,161 @@ void k_vbs_plan(const int32_t *__restrict__ nfr, const int32_t *__restrict__ siz
                 int32_t *__restrict__ cnt, int32_t *__restrict__ order, long long *__restrict__ frame_src,
                 long long *__restrict__ src_off, uint32_t *__restrict__ numbers, int32_t *__restrict__ first)
 {
+    // Round 4: a thread owns one block of every 1024 (coalesced reads of the splitter's verdicts, the running totals
+    // carried from chunk to chunk) -- a thread that owned nblocks / 1024 consecutive blocks walked them by dependent
+    // loads twice over: 123 us for 8192 blocks.
     __shared__ int32_t s_wtot[9][PLAN_NT / 64 + 1];
     const int tid = threadIdx.x;
-    const int per = (nblocks + PLAN_NT - 1) / PLAN_NT;
-    const int b0 = min(tid * per, nblocks), b1 = min(b0 + per, nblocks);
-    const int eighth = block_size / 8;
-    int c[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) c[k] = 0;
-    for (int b = b0; b < b1; b++) {
-        const int f = nfr[b];
-        if (f <= 1) { c[7]++; c[8]++; continue; }
-        for (int q = 0; q < f; q++) {
-            const int k = sizes[(size_t)b * 8 + q] / eighth - 1;
-#pragma unroll
-            for (int z = 0; z < 8; z++) c[z] += (z == k);
-            c[8]++;
-        }
-    }
-    // nine exclusive scans over the 1024 threads: inside a wave by DPP, the sixteen wave totals by the
-    // first lanes of wave 0 -- two barriers (round 3; a Hillis-Steele scan through LDS took twenty)
     const int lane = tid & 63, wv = tid >> 6;
-    int incl[9];
+    const int eighth = block_size / 8;
+    int base[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-        incl[k] = (int)wave_incl_scan_u32_dpp((uint32_t)c[k]);
-        if (lane == 63) s_wtot[k][wv] = incl[k];
-    }
-    __syncthreads();
-    if (wv == 0) {
+    for (int k = 0; k < 9; k++) base[k] = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += PLAN_NT) {
+        const int b = b0 + tid;
+        const bool on = b < nblocks;
+        int f = 0;
+        int len[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) len[q] = 0;
+        if (on) {
+            f = nfr[b];
+            const int4 s0 = *reinterpret_cast<const int4 *>(sizes + (size_t)b * 8);
+            const int4 s1 = *reinterpret_cast<const int4 *>(sizes + (size_t)b * 8 + 4);
+            len[0] = s0.x; len[1] = s0.y; len[2] = s0.z; len[3] = s0.w;
+            len[4] = s1.x; len[5] = s1.y; len[6] = s1.z; len[7] = s1.w;
+            if (f <= 1) { f = 1; len[0] = block_size; }          // the splitter left the block whole
+        }
+        int bin[8], c[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) c[k] = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            bin[q] = (q < f) ? len[q] / eighth - 1 : -1;
+#pragma unroll
+            for (int z = 0; z < 8; z++) c[z] += (z == bin[q]);
+        }
+        c[8] = f;
+        // nine exclusive scans over the 1024 threads: inside a wave by DPP, the sixteen wave totals by the
+        // first lanes of wave 0
+        int incl[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            const int t = (lane < PLAN_NT / 64) ? s_wtot[k][lane] : 0;
-            const int sc = (int)wave_incl_scan_u32_dpp((uint32_t)t);
-            if (lane < PLAN_NT / 64) s_wtot[k][lane] = sc - t;     // exclusive prefix of the wave
-            if (lane == PLAN_NT / 64 - 1) s_wtot[k][PLAN_NT / 64] = sc;   // the grand total
+            incl[k] = (int)wave_incl_scan_u32_dpp((uint32_t)c[k]);
+            if (lane == 63) s_wtot[k][wv] = incl[k];
         }
-    }
-    __syncthreads();
-    int run[9], total[9];
+        __syncthreads();
+        if (wv == 0) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) { run[k] = s_wtot[k][wv] + incl[k] - c[k]; total[k] = s_wtot[k][PLAN_NT / 64]; }
-    if (tid == PLAN_NT - 1) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) { cnt[k] = total[k]; cnt[8 + k] = total[k] * nch; }
-        cnt[16] = total[8];
-        first[nblocks] = total[8];
-    }
-    for (int b = b0; b < b1; b++) {
-        int f = nfr[b];
-        first[b] = run[8];
-        const bool whole = f <= 1;
-        if (whole) f = 1;
-        long long pos = (long long)b * block_size;
-        for (int q = 0; q < f; q++) {
-            const int len = whole ? block_size : sizes[(size_t)b * 8 + q];
-            const int k = len / eighth - 1;
-            int j = 0;
-#pragma unroll
-            for (int z = 0; z < 8; z++) if (z == k) { j = run[z]; run[z]++; }
-            const int slot = bins.slot0[k] + j;
-            order[run[8]++] = slot;
-            frame_src[slot] = pos * nch;
-            src_off[slot] = bins.fr_off[k] + (long long)j * bins.stride[k];
-            numbers[slot] = first_number + (uint32_t)pos;
-            pos += len;
+            for (int k = 0; k < 9; k++) {
+                const int t = (lane < PLAN_NT / 64) ? s_wtot[k][lane] : 0;
+                const int sc = (int)wave_incl_scan_u32_dpp((uint32_t)t);
+                if (lane < PLAN_NT / 64) s_wtot[k][lane] = sc - t;     // exclusive prefix of the wave
+                if (lane == PLAN_NT / 64 - 1) s_wtot[k][PLAN_NT / 64] = sc;   // the chunk's total
+            }
         }
+        __syncthreads();
+        int run[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            run[k] = base[k] + s_wtot[k][wv] + incl[k] - c[k];
+            base[k] += s_wtot[k][PLAN_NT / 64];
+        }
+        if (on) {
+            first[b] = run[8];
+            long long pos = (long long)b * block_size;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (q < f) {
+                    const int k = bin[q];
+                    int j = 0;
+#pragma unroll
+                    for (int z = 0; z < 8; z++) if (z == k) { j = run[z]; run[z]++; }
+                    const int slot = bins.slot0[k] + j;
+                    order[run[8]++] = slot;
+                    frame_src[slot] = pos * nch;
+                    src_off[slot] = bins.fr_off[k] + (long long)j * bins.stride[k];
+                    numbers[slot] = first_number + (uint32_t)pos;
+                    pos += len[q];
+                }
+            }
+        }
+        __syncthreads();                     // s_wtot is written again by the next chunk
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { cnt[k] = base[k]; cnt[8 + k] = base[k] * nch; }
+        cnt[16] = base[8];
+        first[nblocks] = base[8];
     }
 }
 
+// Round 4: chunks of 4096 frames, four consecutive frames per thread (one 16-byte read of order[], four gathers in
+// flight), wave scans and one barrier per chunk -- a thread that walked nframes / 1024 consecutive frames by dependent
+// loads, twice, and a Hillis-Steele scan of twenty barriers took 70-92 us for the frames of 8192 blocks.
 __global__ __launch_bounds__(SCAN_NT)
 void k_frame_offsets_perm(const int32_t *__restrict__ fbytes, const int32_t *__restrict__ order,
                           const int32_t *__restrict__ dev_frames, long long *__restrict__ offsets,
                           long long cap, long long *__restrict__ totals)
 {
-    __shared__ long long s_part[SCAN_NT];
+    __shared__ long long s_w[2][SCAN_NT / 64];       // the wave totals of a chunk, by the chunk's parity
     __shared__ int s_max, s_bad;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nframes = dev_count(dev_frames, 0);
-    const int per = (nframes + SCAN_NT - 1) / SCAN_NT;
-    const int f0 = min(tid * per, nframes), f1 = min(f0 + per, nframes);
-    long long sum = 0;
-    int mx = 0, bad = 0;
+    const bool vec = (reinterpret_cast<uintptr_t>(order) & 15) == 0;
+    long long base = 0;
+    int mx = 0, bad = 0, par = 0;
     if (tid == 0) { s_max = 0; s_bad = 0; }
-    for (int f = f0; f < f1; f++) {
-        const int raw = fbytes[order[f]];
-        const int b = max(raw, 0);
-        bad |= (raw <= 0);                         // a frame K4 did not produce: the stream would be short of it
-        sum += b; mx = max(mx, b);
+    for (int c0 = 0; c0 < nframes; c0 += 4 * SCAN_NT, par ^= 1) {
+        const int f = c0 + 4 * tid;
+        int slot[4], b[4];
+        if (vec && f + 4 <= nframes) {
+            const int4 o = *reinterpret_cast<const int4 *>(order + f);
+            slot[0] = o.x; slot[1] = o.y; slot[2] = o.z; slot[3] = o.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) slot[q] = (f + q < nframes) ? order[f + q] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) b[q] = (slot[q] >= 0) ? fbytes[slot[q]] : 1;
+        long long sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            bad |= (b[q] <= 0);                      // a frame K4 did not produce: the stream would be short of it
+            b[q] = (slot[q] >= 0) ? max(b[q], 0) : 0;
+            mx = max(mx, b[q]);
+            sum += b[q];
+        }
+        const long long incl = (long long)wave_incl_scan_u64((unsigned long long)sum, lane);
+        if (lane == 63) s_w[par][wv] = incl;
+        __syncthreads();
+        long long pre = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < SCAN_NT / 64; w++) {
+            const long long t = s_w[par][w];
+            tot += t;
+            pre += (w < wv) ? t : 0;
+        }
+        long long run = base + pre + incl - sum;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (f + q < nframes) offsets[f + q] = run;
+            run += b[q];
+        }
+        base += tot;
     }
-    s_part[tid] = sum;
-    __syncthreads();
+    __syncthreads();                                 // s_max / s_bad are zero (a batch without frames runs no chunk)
     if (mx > 0) atomicMax(&s_max, mx);
     if (bad) atomicOr(&s_bad, 1);
-    for (int off = 1; off < SCAN_NT; off <<= 1) {
-        const long long v = (tid >= off) ? s_part[tid - off] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    long long run = s_part[tid] - sum;
-    for (int f = f0; f < f1; f++) { offsets[f] = run; run += max(fbytes[order[f]], 0); }
-    if (tid == SCAN_NT - 1) {
-        offsets[nframes] = s_part[tid];
+    __syncthreads();
+    if (tid == 0) {
+        offsets[nframes] = base;
         // totals: frames, bytes, largest frame, flags: 1 = the stream does not fit `cap`, 2 = some frame of the
         // stream was not encoded (frame_bytes <= 0: its bytes are missing from the packed stream)
         totals[0] = nframes;
-        totals[1] = s_part[tid];
-        totals[2] = s_max;                     // encode.c:967 (ordered by the scan's barriers)
-        totals[3] = ((s_part[tid] > cap) ? 1 : 0) | (s_bad ? 2 : 0);
+        totals[1] = base;
+        totals[2] = s_max;                     // encode.c:967
+        totals[3] = ((base > cap) ? 1 : 0) | (s_bad ? 2 : 0);
     }
 }
 

@@ -151,7 +151,7 @@ struct MultiBin {
 // K0 over all bins of a stereo batch (unit0 = first frame slot of the bin, cnt = live frames, wg0 from
 // prepare_bins_workgroups): frame_src[slot] = the piece's offset in pcm
 bool prepare_bins_supported(const fhip_params &p, const int *n, int nbins);
-int prepare_bins_workgroups(int n, int cap);
+int prepare_bins_workgroups(int n, int cap, int nmax);     // nmax: the batch's longest bin
 hipError_t launch_prepare_bins(hipStream_t st, const fhip_params &p, const int32_t *pcm, const MultiBin &mb,
                                int32_t *smp, fhip_subframe_info *info, const long long *frame_src);
 hipError_t launch_autocorr_bins(hipStream_t st, const MultiBin &mb, const int32_t *smp, int max_order,

@@ -976,7 +976,11 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
     // 4.2, four 2.2 / 2.1 / 4.3), longest pieces first, each to the stream with least capacity queued.
     static const bool vbs_serial = getenv("FHIP_VBS_SERIAL") != nullptr;          // measurements only
     constexpr int NA = fhip_ctx::NAUX;
-    static const int vbs_streams = getenv("FHIP_VBS_STREAMS") ? std::max(2, std::min(NA, atoi(getenv("FHIP_VBS_STREAMS")))) : 3;
+    // lanes: the handle's own stream and vbs_lanes - 1 internal ones.  (Round 4: the kernel trace of a level-10 batch showed
+    // three internal streams on TWO hardware queues -- sixteen part-filled launches one after another, 350 of 585 us -- and
+    // the handle's own queue idle meanwhile.)
+    static const int vbs_lanes = getenv("FHIP_VBS_STREAMS") ? std::max(2, std::min(NA + 1, atoi(getenv("FHIP_VBS_STREAMS")))) : 3;
+    const int vbs_streams = vbs_lanes - 1;
     bool fan = !vbs_serial && !c->profiling;
     for (int h = 0; h < vbs_streams; h++) fan = fan && c->aux[h];
     FanJoin fj(c, vbs_streams);
@@ -987,14 +991,16 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
         MaybeProf(fhip_ctx *cc, bool on, int i) : p(on ? new Prof(cc, i) : nullptr) {}
         ~MaybeProf() { delete p; }
     };
-    // the stream a bin's launches go to: the one with least capacity queued
-    long long queued[NA] = {0};
+    // the lane a bin's launches go to: the one with the least estimated work queued.  A bin's search + K3 is a launch's
+    // latency plus its live pieces' work, and the short pieces' bins hold more pieces (measured per 1024 blocks, eighths
+    // 1 .. 8: 130, 69, 64, 41, 62, 45, 72, 39 us).
+    long long queued[NA + 1] = {0};
     auto pick_stream = [&](int k) -> hipStream_t {
         if (!fan) return c->stream;
         int h = 0;
-        for (int q = 1; q < vbs_streams; q++) if (queued[q] < queued[h]) h = q;
-        queued[h] += (long long)vb.cap[k] * vb.n[k];
-        return c->aux[h];
+        for (int q = 1; q < vbs_lanes; q++) if (queued[q] < queued[h]) h = q;
+        queued[h] += 45 + 10 * (long long)(vb.cap[k] / std::max(nblocks, 1));
+        return h == 0 ? c->stream : c->aux[h - 1];
     };
 
     // K1, K2 and K4 do not depend on the piece length: ONE launch each over all bins (kernels.h:
@@ -1094,8 +1100,8 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
         }
         // ---- order search + K3 per bin ----
         if (fan) HIP_TRY(c, fj.fork());
-        for (int q = 0; q < NA; q++) queued[q] = 0;
-        for (int k = 7; k >= 0; k--) {
+        for (int q = 0; q <= NA; q++) queued[q] = 0;
+        for (int k = 0; k < 8; k++) {                               // (the bins with the most pieces first)
             const int n = vb.n[k];
             const size_t sub0 = (size_t)vb.slot0[k] * nch;
             const int nsub_cap = vb.cap[k] * (int)nch;

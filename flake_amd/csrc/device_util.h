@@ -225,6 +225,16 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
            (uint32_t)__builtin_amdgcn_readlane((int)v, 48);      // lane 0
 }
 
+__device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v)
+{
+    v ^= dpp_u32<0x101>(v);
+    v ^= dpp_u32<0x102>(v);
+    v ^= dpp_u32<0x104>(v);
+    v ^= dpp_u32<0x108>(v);
+    return v ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 16) ^ (uint32_t)__builtin_amdgcn_readlane((int)v, 32) ^
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 48);      // lane 0
+}
+
 // x86-64 cvttsd2si semantics for (int)double: out-of-range and NaN give
 // INT_MIN (the reference's `q = error + 0.5`, lpc.c:211).
 __device__ __forceinline__ int c_double_to_int(double x)

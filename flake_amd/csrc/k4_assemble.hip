@@ -1,6 +1,9 @@
 // k4_assemble.hip -- K4: whole FLAC frames on the device (encode.c:718-764, :800-917,
 // :949-964) and the VBS splitter (vbs.c:36-83).
 #include "device_util.h"
+#ifdef FHIP_STAMPS
+FHIP_DEFINE_STAMP_READER(fhip_debug_read_stamps_k4)      // tools/stamps_k4.py: phases of k_assemble's workgroup 0
+#endif
 
 namespace fhip {
 namespace {
@@ -27,38 +30,23 @@ namespace {
 constexpr int ASM_MAX_SEG = 2 * FHIP_MAX_CH + 2;
 constexpr int ASM_PREFIX_BYTES = 224;     // 8+33 header bits, 32 warm-ups of <= 32 bits, 9 + 32*15 coef bits
 
-struct AsmSeg { int kind; int ch; long long nbits; long long dst; };   // kind: 0 LDS bytes, 1 rice slot, 2 verbatim samples
+struct AsmSeg { int kind; int ch; int nbits; int dst; };   // kind: 0 LDS dwords, 1 rice slot, 2 verbatim samples (a frame is < 2^31 bits)
 
-struct MiniSink {                          // MSB-first writer into LDS bytes (serial, one thread)
-    // Fields gather in a 64-bit register and leave a byte at a time by plain byte stores (round 2 set
-    // every bit by a read-modify-write of its LDS byte: ~400 dependent LDS round trips per subframe
-    // prefix, the latency a frame's workgroup waited for).  No recursion: the compiler keeps it inline.
-    uint8_t *buf; int nbits;
-    unsigned long long acc = 0; int nacc = 0;
-    __device__ __forceinline__ void emit(int nb, uint32_t v)      // 1 <= nb <= 32
-    {
-        const uint32_t m = (nb == 32) ? 0xFFFFFFFFu : ((1u << nb) - 1u);
-        acc = (acc << nb) | (unsigned long long)(v & m);
-        nacc += nb;
-#pragma unroll
-        for (int z = 0; z < 5; z++) {
-            if (nacc >= 8) {
-                nacc -= 8;
-                buf[nbits >> 3] = (uint8_t)(acc >> nacc);
-                nbits += 8;
-            }
-        }
-        // the pending bits, left-aligned, as the (partial) last byte: readers see a complete byte image
-        buf[nbits >> 3] = (uint8_t)((acc << (8 - nacc)) & 0xFFu);
-    }
-    __device__ __forceinline__ void put(int nb, uint32_t v)
-    {
-        if (nb <= 0) return;
-        if (nb > 32) { emit(nb - 32, 0u); nb = 32; }               // fields wider than 32 bits are zero-extended
-        emit(nb, v);
-    }
-    __device__ __forceinline__ int bits() const { return nbits + nacc; }
-};
+constexpr int ASM_PREFIX_WORDS = ASM_PREFIX_BYTES / 4;
+
+// A bit string in LDS is kept as stream-order dwords (dword j = stream bits 32 j .. 32 j + 31, the first bit on top): a
+// field of nb bits (1 .. 33; v's bits past 32 are zero: fields wider than 32 bits are zero-extended) is ORed in at any
+// bit position by whichever lane holds it.  (Rounds 2-3 wrote a subframe's prefix by ONE thread, field after field, each
+// warm-up sample and coefficient a global load the next waited for: ~10 us of a frame's ~35.)
+__device__ __forceinline__ void or_field(uint32_t *w, int pos, int nb, uint32_t v)
+{
+    if (nb <= 0) return;
+    const int j = pos >> 5, off = pos & 31;
+    const unsigned long long x = (unsigned long long)v << (64 - off - nb);        // off + nb <= 64
+    const uint32_t hi = (uint32_t)(x >> 32), lo = (uint32_t)x;
+    if (hi) atomicOr(&w[j], hi);
+    if (lo) atomicOr(&w[j + 1], lo);
+}
 
 __device__ __forceinline__ uint16_t crc16_mulmod(uint16_t a, uint16_t b)
 {
@@ -102,6 +90,61 @@ __device__ __forceinline__ uint16_t crc16_pow8(int i)
     return r;
 }
 
+// a * B mod P for a constant B: linear in a, the XOR of (x^i B mod P) over a's set bits -- three instructions a bit
+struct Crc16Lin { uint16_t c[16]; };
+constexpr Crc16Lin crc16_lin_table(uint16_t b)
+{
+    Crc16Lin t{};
+    for (int i = 0; i < 16; i++) t.c[i] = crc16_mulmod_c(b, (uint16_t)(1u << i));
+    return t;
+}
+template <uint16_t B>
+__device__ __forceinline__ uint32_t crc16_mul_const(uint32_t a)
+{
+    constexpr Crc16Lin t = crc16_lin_table(B);
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r ^= (uint32_t)((int32_t)(a << (31 - i)) >> 31) & (uint32_t)t.c[i];
+    return r;
+}
+// crc * x^(8 e) mod P for e's bits JLO .. J: the CRC of a string followed by e more bytes, less those bytes' own CRC
+template <int J, int JLO>
+__device__ __forceinline__ uint32_t crc16_shift_bytes(uint32_t crc, int e)
+{
+    if constexpr (J >= JLO) {
+        constexpr Crc16Pow t = crc16_pow_table();
+        const uint32_t m = crc16_mul_const<t.v[J]>(crc);
+        crc = ((e >> J) & 1) ? m : crc;
+        return crc16_shift_bytes<J - 1, JLO>(crc, e);
+    } else {
+        return crc;
+    }
+}
+// x^e mod P; x^32767 = 1 (P = (x + 1)(x^15 + x + 1), the second factor primitive), so x^(32767 - 8 k) undoes k bytes
+constexpr uint16_t crc16_xpow_c(uint32_t e)
+{
+    uint16_t r = 1, b = 2;
+    while (e) {
+        if (e & 1u) r = crc16_mulmod_c(r, b);
+        b = crc16_mulmod_c(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+static_assert(crc16_mulmod_c(crc16_xpow_c(8), crc16_xpow_c(32767 - 8)) == 1, "x^-8 mod the CRC-16 polynomial");
+// the CRC of a string from the CRC of the string followed by e < 16 zero bytes
+__device__ __forceinline__ uint32_t crc16_unshift_bytes(uint32_t crc, int e)
+{
+    const uint32_t m0 = crc16_mul_const<crc16_xpow_c(32767 - 8)>(crc);
+    crc = (e & 1) ? m0 : crc;
+    const uint32_t m1 = crc16_mul_const<crc16_xpow_c(32767 - 16)>(crc);
+    crc = (e & 2) ? m1 : crc;
+    const uint32_t m2 = crc16_mul_const<crc16_xpow_c(32767 - 32)>(crc);
+    crc = (e & 4) ? m2 : crc;
+    const uint32_t m3 = crc16_mul_const<crc16_xpow_c(32767 - 64)>(crc);
+    return (e & 8) ? m3 : crc;
+}
+
 __device__ __forceinline__ int32_t asm_sample(const int32_t *pcm_frame, int nch, int ch, int t,
                                              int ch_mode, int wasted)
 {
@@ -119,7 +162,17 @@ __device__ __forceinline__ int32_t asm_sample(const int32_t *pcm_frame, int nch,
     return v >> wasted;
 }
 
-__global__ __launch_bounds__(NT)
+// Round 4: ONE WAVE per frame.  The stamps of a four-wave workgroup (tools/stamps_k4.py) showed a frame's 27 k cycles
+// to be waits -- the record's loads, a thread's serial sums, the header's table chain, a memory round trip for every 256
+// quads, the barriers between -- with eight frames in flight per CU; a wave per frame keeps 32 in flight, needs no
+// barrier (the LDS is the wave's own), takes the per-channel sums by lanes and keeps four quads' loads in the air.
+// (Also tried: a grid of what the chip holds at once walking the frames in stream order -- no workgroup for the slots of
+// a ragged batch that stay empty, tables built once: 367 us for the frames of 8192 blocks where a workgroup per slot
+// took 324; the same form lost 11-15 % in the order search.  The hardware's dispatch of a fresh workgroup balances
+// better than a fixed walk, and a workgroup that finds its slot empty costs little.)
+constexpr int AT = WAVE;                  // threads per frame
+constexpr int ASM_QB = 4;                 // quads a lane keeps in flight
+__global__ __launch_bounds__(AT)
 void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
                 const fhip_subframe_info *__restrict__ info, const uint8_t *__restrict__ rice,
                 long long slot_bytes, uint8_t *__restrict__ frames, long long frame_stride,
@@ -129,7 +182,7 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
                 const long long *__restrict__ frame_src, const int32_t *__restrict__ dev_frames, MultiBin mb)
 {
     if (dev_frames && (int)blockIdx.x >= dev_count(dev_frames, 0)) return;      // (a ragged batch's grid is its bin's capacity)
-    int f = blockIdx.x;
+    const int f = blockIdx.x;
     if (mb.nbins) {
         // every bin of a ragged batch in one launch (kernels.h: MultiBin; one workgroup per frame
         // slot: wg0 = unit0): info / frame_bytes / numbers / frame_src are the handle's whole
@@ -144,271 +197,348 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
         rice += mb.bits_off[k] - (long long)mb.unit0[k] * P.channels * slot_bytes;     // indexed by the global slot below
         frames += mb.fr_off[k] - (long long)mb.unit0[k] * frame_stride;
     }
-    __shared__ uint8_t s_hdr[32];
-    __shared__ uint8_t s_prefix[FHIP_MAX_CH][ASM_PREFIX_BYTES];
-    __shared__ AsmSeg s_seg[ASM_MAX_SEG];
-    __shared__ int s_nseg, s_verbatim, s_hdr_bits;
-    __shared__ long long s_total_bits;
+    __shared__ uint32_t s_bits[FHIP_MAX_CH + 1][ASM_PREFIX_WORDS];   // row 0: the frame header; row c + 1: subframe c's prefix
+    __shared__ AsmSeg s_seg[ASM_MAX_SEG];        // the header, then a prefix and a body per channel (a body may be empty)
     __shared__ uint16_t s_crc_tab[256];
     __shared__ uint16_t s_crc_zk[3][256];        // CRC of byte x followed by 1, 2, 3 zero bytes (word steps below)
-    __shared__ int s_info[FHIP_MAX_CH][8];       // type, type_code, order, shift, obits, wasted, rice_nbits, ch_mode
+    __shared__ int s_info[FHIP_MAX_CH][4];       // obits, wasted, ch_mode (what verbatim samples are rebuilt from)
+    __shared__ uint8_t s_crc8[256];              // crc.c:46-57 (x^8 + x^2 + x + 1)
+    static_assert(AT == 64, "the CRC's step from quad to quad is x^(8 * 16 * AT) = crc16_pow_table().v[10]");
 
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     const int nch = P.channels;
     const fhip_subframe_info *fi = info + (size_t)f * nch;
     const int32_t *pcm_frame = pcm + (frame_src ? (size_t)frame_src[f] : (size_t)f * n * nch);
     uint8_t *out = frames + (size_t)f * frame_stride;
     uint32_t *out32 = reinterpret_cast<uint32_t *>(out);
+    STAMP(0);
 
-    // CRC-16 table (crc.c:24-44), one entry per thread
-    {
-        uint16_t c = (uint16_t)(tid << 8);
+    // ---- everything the frame needs from memory but its sections, in flight at once: lane c holds channel c's record,
+    // lanes 0 .. 31 / 32 .. 63 every channel's warm-up samples / coefficients ----
+    int type = 0, type_code = 0, order = 0, shift = 0, obits = 0, wasted = 0, rn = 0, ch_mode = 0;
+    if (lane < nch) {
+        const fhip_subframe_info *i = &fi[lane];
+        type = i->type; type_code = i->type_code; order = i->order; shift = i->shift; obits = i->obits;
+        wasted = i->wasted; rn = i->rice_nbits; ch_mode = i->ch_mode;
+    }
+    int32_t fld[FHIP_MAX_CH];
 #pragma unroll
-        for (int b = 0; b < 8; b++) c = (uint16_t)((c & 0x8000) ? ((c << 1) ^ 0x8005) : (c << 1));
-        s_crc_tab[tid] = c;
+    for (int c = 0; c < FHIP_MAX_CH; c++) fld[c] = (c < nch) ? ((lane < 32) ? fi[c].warmup[lane] : fi[c].coefs[lane - 32]) : 0;
+    const uint32_t number = numbers ? numbers[f] : number_base + (uint32_t)f * number_step;
+    // CRC-16 and CRC-8 tables (crc.c:24-57), four entries per lane
+#pragma unroll
+    for (int q = 0; q < 256 / AT; q++) {
+        const int x = lane + AT * q;
+        uint32_t c = (uint32_t)x << 8, c8 = (uint32_t)x;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            c = ((c & 0x8000u) ? ((c << 1) ^ 0x8005u) : (c << 1)) & 0xFFFFu;
+            c8 = ((c8 & 0x80u) ? ((c8 << 1) ^ 0x07u) : (c8 << 1)) & 0xFFu;
+        }
+        s_crc_tab[x] = (uint16_t)c;
+        s_crc8[x] = (uint8_t)c8;
     }
-    if (tid < nch) {
-        const fhip_subframe_info *i = &fi[tid];
-        s_info[tid][0] = i->type; s_info[tid][1] = i->type_code; s_info[tid][2] = i->order;
-        s_info[tid][3] = i->shift; s_info[tid][4] = i->obits; s_info[tid][5] = i->wasted;
-        s_info[tid][6] = i->rice_nbits; s_info[tid][7] = i->ch_mode;
-    }
-    __syncthreads();
-    {
-        uint16_t v = s_crc_tab[tid];
+    for (int i = lane; i < (FHIP_MAX_CH + 1) * ASM_PREFIX_WORDS; i += AT) (&s_bits[0][0])[i] = 0u;
+    __syncthreads();                       // (one wave: the LDS writes above are visible to its other lanes)
+#pragma unroll
+    for (int q = 0; q < 256 / AT; q++) {
+        const int x = lane + AT * q;
+        uint16_t v = s_crc_tab[x];
 #pragma unroll
         for (int z = 0; z < 3; z++) {
             v = (uint16_t)((v << 8) ^ s_crc_tab[v >> 8]);
-            s_crc_zk[z][tid] = v;                 // read first behind later barriers
+            s_crc_zk[z][x] = v;
         }
     }
+    STAMP(1);
 
-    // ---- does the frame take the verbatim fallback? (encode.c:949) -----------
-    // The frame's length follows from lengths alone; the header's bytes (below, thread 64) and the
-    // subframe prefixes (threads 0 .. channels-1) are then written side by side, in different waves.
     int bs0 = -1, bs1 = -1;
     {
         const int bs_tab[15] = {0, 192, 576, 1152, 2304, 4608, 0, 0, 256, 512, 1024, 2048, 4096, 8192, 16384};
         for (int q = 0; q < 15; q++) if (n == bs_tab[q]) { bs0 = q; break; }
         if (bs0 < 0) { bs0 = (n <= 256) ? 6 : 7; bs1 = n - 1; }
     }
-    const uint32_t number = numbers ? numbers[f] : number_base + (uint32_t)f * number_step;
-    if (tid == 0) {
-        // header length: 32 fixed bits, the UTF-8 style number (encode.c:696-716), the optional block
-        // size / sample rate fields, CRC-8
-        const int nbytes = (number < 0x80) ? 1 : (ilog2_dev(number) + 4) / 5;
-        const int hdr_bits = 32 + 8 * nbytes + (bs1 >= 0 ? (bs1 < 256 ? 8 : 16) : 0) +
-                             (sr_code1 > 0 ? (sr_code1 < 256 ? 8 : 16) : 0) + 8;
-        s_hdr_bits = hdr_bits;
-        long long bits = hdr_bits;
-        int verb = 0;
-        for (int c = 0; c < nch; c++) {
-            const int type = s_info[c][0], order = s_info[c][2], obits = s_info[c][4];
-            const int wasted = s_info[c][5], rn = s_info[c][6];
-            bits += 8 + (wasted ? wasted : 0);
-            if (type == FHIP_SUB_CONSTANT) bits += obits;
-            else if (type == FHIP_SUB_VERBATIM) bits += (long long)n * obits;
-            else {
-                if (rn < 0) verb = 1;
-                bits += (long long)order * obits + rn;
-                if (type == FHIP_SUB_LPC) bits += 9 + order * P.lpc_precision;
-            }
-        }
-        const long long bytes = ((bits + 7) >> 3) + 2;
-        if (bytes > verbatim_size) verb = 1;
-        s_verbatim = verb;
-    }
-    __syncthreads();
-    const int verbatim = s_verbatim;
+    // header length: 32 fixed bits, the UTF-8 style number (encode.c:696-716), the optional block
+    // size / sample rate fields, CRC-8
+    const int nb = (number < 0x80) ? 1 : (ilog2_dev(number) + 4) / 5;
+    const int bsb = (bs1 >= 0) ? (bs1 < 256 ? 1 : 2) : 0, srb = (sr_code1 > 0) ? (sr_code1 < 256 ? 1 : 2) : 0;
+    const int hbytes = 4 + nb + bsb + srb;
+    const int hdr_bits = 8 * hbytes + 8;
 
-    if (tid == WAVE) {
-        // frame header (encode.c:718-764) + CRC-8
-        MiniSink hs{s_hdr, 0};
-        const int ch_mode = s_info[0][7];
-        hs.put(15, 0x7FFC);
-        hs.put(1, (uint32_t)P.allow_vbs);
-        hs.put(4, (uint32_t)bs0);
-        hs.put(4, (uint32_t)sr_code0);
-        hs.put(4, (uint32_t)(ch_mode == FHIP_CH_NOT_STEREO ? nch - 1 : ch_mode));
-        hs.put(3, (uint32_t)bps_code);
-        hs.put(1, 0);
-        if (number < 0x80) {
-            hs.put(8, number);
-        } else {
-            const int bytes = (ilog2_dev(number) + 4) / 5;          // encode.c:696-716
-            int sh = (bytes - 1) * 6;
-            hs.put(8, ((256u - (256u >> bytes)) | (number >> sh)) & 0xFFu);
-            while (sh >= 6) { sh -= 6; hs.put(8, 0x80u | ((number >> sh) & 0x3Fu)); }
+    // ---- does the frame take the verbatim fallback? (encode.c:949)  The frame's length, and with it the segment
+    // list, follows from lengths alone: lane c has channel c's ----
+    const int prec = P.lpc_precision;
+    int plen = 0, blen = 0, bkind = 1, bad = 0;
+    if (lane < nch) {
+        plen = 8 + wasted;                                           // encode.c:871-905
+        if (type == FHIP_SUB_CONSTANT) plen += obits;
+        else if (type == FHIP_SUB_VERBATIM) { blen = n * obits; bkind = 2; }
+        else {
+            bad = rn < 0;
+            plen += order * obits + ((type == FHIP_SUB_LPC) ? 9 + order * prec : 0);
+            blen = max(rn, 0);
         }
-        if (bs1 >= 0) hs.put(bs1 < 256 ? 8 : 16, (uint32_t)bs1);
-        if (sr_code1 > 0) hs.put(sr_code1 < 256 ? 8 : 16, (uint32_t)sr_code1);
-        uint8_t c8 = 0;
-        for (int q = 0; q < (hs.bits() >> 3); q++) {
-            c8 ^= s_hdr[q];
-            for (int b = 0; b < 8; b++) c8 = (uint8_t)((c8 & 0x80) ? ((c8 << 1) ^ 0x07) : (c8 << 1));
-        }
-        hs.put(8, c8);
     }
-    // ---- per-subframe prefixes (encode.c:871-905, 800-869), one thread each --
-    if (tid < nch) {
-        const fhip_subframe_info *i = &fi[tid];
-        const int type = verbatim ? FHIP_SUB_VERBATIM : s_info[tid][0];
-        const int order = s_info[tid][2], obits = s_info[tid][4], wasted = s_info[tid][5];
-        MiniSink ps{s_prefix[tid], 0};
-        ps.put(1, 0);
-        ps.put(6, (uint32_t)(verbatim ? FHIP_SUB_VERBATIM : s_info[tid][1]));
-        if (wasted) { ps.put(1, 1); ps.put(wasted - 1, 0); ps.put(1, 1); }
-        else ps.put(1, 0);
-        const uint32_t omask = (obits >= 32) ? 0xFFFFFFFFu : ((1u << obits) - 1u);
-        if (type == FHIP_SUB_CONSTANT) {
-            ps.put(obits, (uint32_t)i->warmup[0] & omask);
-        } else if (type == FHIP_SUB_FIXED || type == FHIP_SUB_LPC) {
-            for (int t = 0; t < order; t++) ps.put(obits, (uint32_t)i->warmup[t] & omask);
-            if (type == FHIP_SUB_LPC) {
-                ps.put(4, (uint32_t)(P.lpc_precision - 1));
-                ps.put(5, (uint32_t)s_info[tid][3] & 31u);
-                const uint32_t cmask = (1u << P.lpc_precision) - 1u;
-                for (int t = 0; t < order; t++) ps.put(P.lpc_precision, (uint32_t)i->coefs[t] & cmask);
-            }
-        }
-        s_info[tid][0] = type;
-        s_info[tid][3] = ps.bits();             // reuse: prefix length
+    uint32_t incl = wave_incl_scan_u32_dpp((uint32_t)(plen + blen));
+    const int verbatim = (__ballot(bad) != 0ull) ||
+                         ((((long long)hdr_bits + (long long)__shfl((int)incl, WAVE - 1, WAVE) + 7) >> 3) + 2 > verbatim_size);
+    if (verbatim) {
+        if (lane < nch) { type = FHIP_SUB_VERBATIM; type_code = FHIP_SUB_VERBATIM; plen = 8 + wasted; blen = n * obits; bkind = 2; }
+        incl = wave_incl_scan_u32_dpp((uint32_t)(plen + blen));
     }
-    __syncthreads();
-    if (tid == 0) {
-        int ns = 0;
-        long long pos = 0;
-        s_seg[ns++] = AsmSeg{0, -1, s_hdr_bits, pos}; pos += s_hdr_bits;
-        for (int c = 0; c < nch; c++) {
-            s_seg[ns++] = AsmSeg{0, c, s_info[c][3], pos}; pos += s_info[c][3];
-            const int type = s_info[c][0];
-            if (type == FHIP_SUB_VERBATIM) {
-                const long long nb = (long long)n * s_info[c][4];
-                s_seg[ns++] = AsmSeg{2, c, nb, pos}; pos += nb;
-            } else if (type == FHIP_SUB_FIXED || type == FHIP_SUB_LPC) {
-                s_seg[ns++] = AsmSeg{1, c, s_info[c][6], pos}; pos += s_info[c][6];
-            }
-        }
-        s_nseg = ns;
-        s_total_bits = pos;
+    const int total_bits = hdr_bits + __shfl((int)incl, WAVE - 1, WAVE);
+    if (lane < nch) {
+        const int pos = hdr_bits + (int)incl - plen - blen;
+        s_seg[1 + 2 * lane] = AsmSeg{0, lane, plen, pos};
+        s_seg[2 + 2 * lane] = AsmSeg{bkind, lane, blen, pos + plen};
+        s_info[lane][0] = obits; s_info[lane][1] = wasted; s_info[lane][2] = ch_mode;
     }
-    __syncthreads();
+    if (lane == 0) s_seg[0] = AsmSeg{0, -1, hdr_bits, 0};
+    const int nseg = 1 + 2 * nch;
+    {
+        // frame header (encode.c:718-764) + CRC-8: a lane per field (the 32 fixed bits, each byte of the UTF-8 style
+        // number, the block-size and sample-rate fields), each with the CRC-8 of its bytes moved to the header's end (the
+        // CRC is linear: zero bytes in front leave it alone, zero bytes behind are table steps)
+        const int ch_mode0 = __shfl(ch_mode, 0, WAVE);
+        uint32_t val = 0;
+        int bp = 0, fl = 0;                                     // the field's first byte and its bytes
+        if (lane == 0) {
+            val = (0x7FFCu << 17) | (((uint32_t)P.allow_vbs & 1u) << 16) | (((uint32_t)bs0 & 15u) << 12) |
+                  (((uint32_t)sr_code0 & 15u) << 8) |
+                  (((uint32_t)(ch_mode0 == FHIP_CH_NOT_STEREO ? nch - 1 : ch_mode0) & 15u) << 4) | (((uint32_t)bps_code & 7u) << 1);
+            fl = 4;
+        } else if (lane <= nb) {
+            const int j = lane - 1, sh = (nb - 1 - j) * 6;
+            val = (nb == 1) ? number : (j == 0) ? (((256u - (256u >> nb)) | (number >> sh)) & 0xFFu)
+                                                : (0x80u | ((number >> sh) & 0x3Fu));
+            bp = 4 + j; fl = 1;
+        } else if (lane == 8 && bsb) {
+            val = (uint32_t)bs1; bp = 4 + nb; fl = bsb;
+        } else if (lane == 9 && srb) {
+            val = (uint32_t)sr_code1; bp = 4 + nb + bsb; fl = srb;
+        }
+        if (fl) or_field(s_bits[0], 8 * bp, 8 * fl, val);
+        uint32_t c8 = 0;
+#pragma unroll
+        for (int z = 3; z >= 0; z--) c8 = s_crc8[c8 ^ ((val >> (8 * z)) & 0xFFu)];
+        for (int z = hbytes - bp - fl; z > 0; z--) c8 = s_crc8[c8];
+        c8 = wave_xor_u32(fl ? c8 : 0u);
+        if (lane == 0) or_field(s_bits[0], 8 * hbytes, 8, c8);
+    }
+    STAMP(2);
 
-    const long long total_bits = s_total_bits;
-    const int body_bytes = (int)((total_bits + 7) >> 3);          // before the CRC-16
+    // ---- per-subframe prefixes (encode.c:871-905, 800-869): a lane per field ----
+#pragma unroll
+    for (int c = 0; c < FHIP_MAX_CH; c++) {
+        if (c < nch) {
+            const int type_c = __shfl(type, c, WAVE), order_c = __shfl(order, c, WAVE), obits_c = __shfl(obits, c, WAVE);
+            const int wasted_c = __shfl(wasted, c, WAVE), code_c = __shfl(type_code, c, WAVE), shift_c = __shfl(shift, c, WAVE);
+            uint32_t *pw = s_bits[c + 1];
+            const int pos0 = 8 + wasted_c;
+            const uint32_t omask = (obits_c >= 32) ? 0xFFFFFFFFu : ((1u << obits_c) - 1u);
+            if (lane == 0) {
+                // a zero bit, six bits of type, the wasted-bits flag; then wasted - 1 zeros and a one
+                or_field(pw, 0, 8, (((uint32_t)code_c & 63u) << 1) | (wasted_c ? 1u : 0u));
+                if (wasted_c) or_field(pw, 8 + wasted_c - 1, 1, 1u);
+            }
+            if (type_c == FHIP_SUB_CONSTANT) {
+                if (lane == 0) or_field(pw, pos0, obits_c, (uint32_t)fld[c] & omask);
+            } else if (type_c == FHIP_SUB_FIXED || type_c == FHIP_SUB_LPC) {
+                if (lane < order_c) or_field(pw, pos0 + lane * obits_c, obits_c, (uint32_t)fld[c] & omask);
+                if (type_c == FHIP_SUB_LPC) {
+                    const int pq = pos0 + order_c * obits_c;
+                    if (lane == 0) or_field(pw, pq, 9, (((uint32_t)(prec - 1) & 15u) << 5) | ((uint32_t)shift_c & 31u));
+                    if (lane >= 32 && lane - 32 < order_c)
+                        or_field(pw, pq + 9 + (lane - 32) * prec, prec, (uint32_t)fld[c] & ((1u << prec) - 1u));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    STAMP(3);
+
+    const int body_bytes = (total_bits + 7) >> 3;                 // before the CRC-16
     const int nwords = (body_bytes + 3) >> 2;
-    const int nseg = s_nseg;
+    const int nquads = (nwords + 3) >> 2;
 
-    // ---- every output dword from the segments that overlap it ----------------
-    for (int w = tid; w < nwords; w += NT) {
-        const long long w0 = (long long)w * 32, w1 = w0 + 32;
+    // one output dword from the segments that overlap it (the general case: headers, section borders, verbatim samples)
+    auto gen_word = [&](int w) -> uint32_t {
+        const int w0 = w * 32, w1 = w0 + 32;
         uint32_t word = 0;
         // the segments lie back to back in ascending order: skip those that end at or before this
-        // word (one 8-byte LDS read each), stop at the first that starts behind it -- most words lie
-        // inside one long residual section
+        // word (one LDS read each), stop at the first that starts behind it
         int q0 = 0;
         while (q0 < nseg - 1 && s_seg[q0 + 1].dst <= w0) q0++;
         for (int q = q0; q < nseg; q++) {
             const AsmSeg sg = s_seg[q];
             if (sg.dst >= w1) break;
-            const long long a = max(sg.dst, w0), b = min(sg.dst + sg.nbits, w1);
+            const int a = max(sg.dst, w0), b = min(sg.dst + sg.nbits, w1);
             if (a >= b) continue;
-            const int cnt = (int)(b - a);
-            const long long sp = a - sg.dst;                      // bit offset inside the segment
+            const int cnt = b - a;
+            const int sp = a - sg.dst;                            // bit offset inside the segment
             uint32_t bitsv;                                       // cnt bits, right aligned
             if (sg.kind == 2) {
-                const int c = sg.ch, obits = s_info[c][4], wasted = s_info[c][5], cm = s_info[c][7];
-                const uint32_t omask = (obits >= 32) ? 0xFFFFFFFFu : ((1u << obits) - 1u);
-                int i = (int)(sp / obits), offb = (int)(sp % obits), got = 0;
+                const int c = sg.ch, ob = s_info[c][0], ws = s_info[c][1], cm = s_info[c][2];
+                const uint32_t omask = (ob >= 32) ? 0xFFFFFFFFu : ((1u << ob) - 1u);
+                int i = sp / ob, offb = sp % ob, got = 0;
                 unsigned long long acc = 0;
                 while (got < cnt) {
-                    const uint32_t v = (uint32_t)asm_sample(pcm_frame, nch, c, i, cm, wasted) & omask;
-                    const int take = min(obits - offb, cnt - got);
-                    const uint32_t piece = (take >= 32) ? v : ((v >> (obits - offb - take)) & ((1u << take) - 1u));
+                    const uint32_t v = (uint32_t)asm_sample(pcm_frame, nch, c, i, cm, ws) & omask;
+                    const int take = min(ob - offb, cnt - got);
+                    const uint32_t piece = (take >= 32) ? v : ((v >> (ob - offb - take)) & ((1u << take) - 1u));
                     acc = (acc << take) | piece;
                     got += take; offb = 0; i++;
                 }
                 bitsv = (uint32_t)acc;
             } else {
                 // 64 source bits that start at the dword holding bit sp
-                const long long sw = sp >> 5;
+                const int sw = sp >> 5;
                 uint32_t hi, lo;
                 if (sg.kind == 0) {
-                    const uint8_t *src = (sg.ch < 0) ? s_hdr : s_prefix[sg.ch];
-                    const int lim = (sg.ch < 0) ? 32 : ASM_PREFIX_BYTES;
-                    uint32_t bv[8];
-#pragma unroll
-                    for (int z = 0; z < 8; z++) {
-                        const long long bi = sw * 4 + z;
-                        bv[z] = (bi < lim) ? src[bi] : 0u;
-                    }
-                    hi = (bv[0] << 24) | (bv[1] << 16) | (bv[2] << 8) | bv[3];
-                    lo = (bv[4] << 24) | (bv[5] << 16) | (bv[6] << 8) | bv[7];
+                    const uint32_t *src = s_bits[sg.ch + 1];
+                    hi = src[sw];
+                    lo = (sw + 1 < ASM_PREFIX_WORDS) ? src[sw + 1] : 0u;
                 } else {
                     const uint32_t *src = reinterpret_cast<const uint32_t *>(
                         rice + ((size_t)f * nch + sg.ch) * (size_t)slot_bytes);
                     hi = __builtin_bswap32(src[sw]);
-                    lo = ((sw + 1) * 4 < slot_bytes) ? __builtin_bswap32(src[sw + 1]) : 0u;
+                    lo = ((long long)(sw + 1) * 4 < slot_bytes) ? __builtin_bswap32(src[sw + 1]) : 0u;
                 }
                 const unsigned long long x = ((unsigned long long)hi << 32) | lo;
-                const int sh = (int)(sp & 31);
-                bitsv = (uint32_t)((x << sh) >> (64 - cnt));
+                bitsv = (uint32_t)((x << (sp & 31)) >> (64 - cnt));
             }
-            word |= bitsv << (32 - (int)(a - w0) - cnt);
+            word |= bitsv << (32 - (a - w0) - cnt);
         }
-        out32[w] = __builtin_bswap32(word);
-    }
-    __syncthreads();                       // the frame body is in memory (same CU)
+        return word;
+    };
 
-    // ---- CRC-16 (crc.c:59-94): ONE wave, 64 chunks, merged by shuffles -----------
-    // (round 3.  Round 2 gave every thread a chunk and merged 256 partial CRCs through LDS: a
-    // square-and-multiply for x^(8L) and eight barrier-separated steps with two 16-step GF(2)
-    // products each -- ~2600 of the kernel's ~6000 instructions per wave, on all four waves, for
-    // a frame of a few KB.)  Lane i >= 1 takes the L bytes that end (63 - i) L bytes before the
-    // body's end, L the smallest power of two with 64 L >= body; lane 0 takes what is in front
-    // (lanes whose range lies before the body are empty: crc 0).  crc(A || B) = crc(A) x^(8 |B|) +
-    // crc(B) only asks for the RIGHT part's length, so every merge constant is x^(8 L 2^j) mod P, a
-    // compile-time table entry.
-    if (tid >= WAVE) return;
-    {
-        int k = 2;
-        while ((64 << k) < body_bytes) k++;
-        const int L = 1 << k;
-        const int e = body_bytes - (63 - tid) * L;             // end of this lane's chunk
-        const int s0 = max(e - L, 0);
-        uint16_t c = 0;
-        uint32_t wv = 0;
-        // (the bytes were stored by other lanes of this workgroup: read past L1)
-        int bi = s0;
-        for (; bi < e && (bi & 3) != 0; bi++) {                  // up to the first whole word
-            if (bi == s0) wv = __hip_atomic_load(&out32[bi >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t byte = (wv >> (8 * (bi & 3))) & 0xFFu;
-            c = (uint16_t)((c << 8) ^ s_crc_tab[((c >> 8) ^ byte) & 0xFFu]);
-        }
-        // four bytes a step: the state only meets the first two, the four table reads are independent
-        // (a byte a step is a dependent LDS read per byte: 512 in a row for a 20 KB frame)
-        for (; bi + 4 <= e; bi += 4) {
-            wv = __hip_atomic_load(&out32[bi >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t x0 = ((c >> 8) ^ wv) & 0xFFu, x1 = (c ^ (wv >> 8)) & 0xFFu;
-            c = (uint16_t)(s_crc_zk[2][x0] ^ s_crc_zk[1][x1] ^ s_crc_zk[0][(wv >> 16) & 0xFFu] ^ s_crc_tab[wv >> 24]);
-        }
-        for (; bi < e; bi++) {
-            if ((bi & 3) == 0) wv = __hip_atomic_load(&out32[bi >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t byte = (wv >> (8 * (bi & 3))) & 0xFFu;
-            c = (uint16_t)((c << 8) ^ s_crc_tab[((c >> 8) ^ byte) & 0xFFu]);
+    // ---- the frame, four consecutive dwords a lane and step; its CRC-16 on the way ----------------
+    // Most quads lie inside one residual section: five source dwords, four funnel shifts, one 16-byte store; the loads
+    // of ASM_QB quads are issued before the first is used.
+    // CRC-16 (crc.c:59-94): CRC(A || B) = CRC(A) x^(8 |B|) + CRC(B) over GF(2).  A lane runs the table step over its
+    // quad's four dwords, carries the CRC of its own quads -- 16 AT bytes apart: one constant product a quad -- moves it
+    // to the end of the frame's last quad (lane t's last quad is the t-th from the end), and the 64 values are XORed;
+    // the zero bytes that fill the last quad are taken off again by x^-8 (x^32767 = 1).  (Round 3 read the finished
+    // frame back from memory with one wave of four, a load the next step waited for at each dword, and produced the
+    // frame a dword at a time with 64-bit positions.)
+    const bool st16 = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    const uint32_t *rice0 = reinterpret_cast<const uint32_t *>(rice + (size_t)f * nch * (size_t)slot_bytes);
+    const int slot_dw = (int)(slot_bytes >> 2);
+    uint32_t crc = 0;
+    const int last = nquads - 1 - lane;                           // lane t's quads are last - AT i, in ascending order
+    int q0 = 0;                                                   // (the segment of a quad's first bit: quads ascend)
+    for (int base = last & (AT - 1); base <= last; base += AT * ASM_QB) {
+        uint32_t raw[ASM_QB][5];
+        int dq[ASM_QB], segq[ASM_QB];
+        bool fastq[ASM_QB];
+#pragma unroll
+        for (int j = 0; j < ASM_QB; j++) {
+            const int qd = base + AT * j;
+            const int b0 = qd * 128;
+            while (q0 < nseg - 1 && s_seg[q0 + 1].dst <= b0) q0++;
+            const AsmSeg sg = s_seg[q0];
+            const bool sec = qd <= last && sg.kind == 1;
+            // 128 bits of the section from its bit b0 - dst on (a quad that starts elsewhere, or none at all, loads the
+            // frame's first dwords: no branch around the loads; dwords past the slot are never inside the section)
+            const int d = sec ? b0 - sg.dst : 0;
+            const uint32_t *src = rice0 + (sec ? (size_t)sg.ch * (size_t)slot_dw : (size_t)0);
+            dq[j] = d;
+            segq[j] = q0;
+            fastq[j] = sec && b0 + 128 <= sg.dst + sg.nbits;
+#pragma unroll
+            for (int k = 0; k < 5; k++) raw[j][k] = src[min((d >> 5) + k, slot_dw - 1)];
         }
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            // lanes = 0 mod 2^(j+1) absorb the node 2^j lanes to their right (2^j chunks of L bytes)
-            const uint16_t right = (uint16_t)__shfl_down((int)c, 1 << j, WAVE);
-            c = (uint16_t)(crc16_mulmod(c, crc16_pow8(k + j)) ^ right);
-        }
-        if (tid == 0) {
-            out[body_bytes] = (uint8_t)(c >> 8);
-            out[body_bytes + 1] = (uint8_t)c;
-            frame_bytes[f] = body_bytes + 2;
+        for (int j = 0; j < ASM_QB; j++) {
+            const int qd = base + AT * j;
+            if (qd <= last) {
+                uint32_t wd[4];
+                if (fastq[j]) {
+                    const int sh = dq[j] & 31;
+                    uint32_t sv[5];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) sv[k] = __builtin_bswap32(raw[j][k]);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t fs = __builtin_amdgcn_alignbit(sv[k], sv[k + 1], (32 - sh) & 31);
+                        wd[k] = sh ? fs : sv[k];
+                    }
+                } else {
+                    // a quad with a border in it: every segment that overlaps it gives its 128-bit window (the first one's
+                    // is loaded already), cut to the bits that are its own
+                    const int b0 = qd * 128;
+                    wd[0] = wd[1] = wd[2] = wd[3] = 0u;
+                    bool samples = false;
+                    for (int i = segq[j]; i < nseg; i++) {
+                        const AsmSeg sg = s_seg[i];
+                        if (sg.dst >= b0 + 128) break;
+                        const int lo = max(sg.dst, b0) - b0, hi = min(sg.dst + sg.nbits, b0 + 128) - b0;
+                        if (lo >= hi) continue;
+                        if (sg.kind == 2) { samples = true; break; }
+                        const int d = b0 - sg.dst;                 // (negative: the segment starts inside the quad)
+                        const int sw = d >> 5, sh = d & 31;
+                        uint32_t sv[5];
+                        if (sg.kind == 0) {
+                            const uint32_t *src = s_bits[sg.ch + 1];
+#pragma unroll
+                            for (int k = 0; k < 5; k++) sv[k] = (sw + k >= 0 && sw + k < ASM_PREFIX_WORDS) ? src[sw + k] : 0u;
+                        } else if (i == segq[j]) {
+#pragma unroll
+                            for (int k = 0; k < 5; k++) sv[k] = __builtin_bswap32(raw[j][k]);
+                        } else {
+                            const uint32_t *src = rice0 + (size_t)sg.ch * (size_t)slot_dw;
+#pragma unroll
+                            for (int k = 0; k < 5; k++) sv[k] = (sw + k >= 0) ? __builtin_bswap32(src[min(sw + k, slot_dw - 1)]) : 0u;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t fs = __builtin_amdgcn_alignbit(sv[k], sv[k + 1], (32 - sh) & 31);
+                            const int l = lo - 32 * k, h = hi - 32 * k;     // the segment's bits of this dword: [l, h), bit 0 on top
+                            const uint32_t m = ((l <= 0) ? 0xFFFFFFFFu : (l >= 32) ? 0u : (0xFFFFFFFFu >> l)) &
+                                               ((h >= 32) ? 0xFFFFFFFFu : (h <= 0) ? 0u : ~(0xFFFFFFFFu >> h));
+                            wd[k] |= (sh ? fs : sv[k]) & m;
+                        }
+                    }
+                    if (samples) {
+                        // verbatim samples (a frame that took the fallback, or a subframe K3 left verbatim): dword by dword
+#pragma unroll 1
+                        for (int k = 0; k < 4; k++) {
+                            const int w = 4 * qd + k;
+                            const uint32_t v = (w < nwords) ? gen_word(w) : 0u;
+                            wd[0] = (k == 0) ? v : wd[0]; wd[1] = (k == 1) ? v : wd[1];
+                            wd[2] = (k == 2) ? v : wd[2]; wd[3] = (k == 3) ? v : wd[3];
+                        }
+                    }
+                }
+                if (st16 && 4 * qd + 4 <= nwords) {
+                    *reinterpret_cast<uint4 *>(out32 + 4 * qd) = make_uint4(__builtin_bswap32(wd[0]), __builtin_bswap32(wd[1]),
+                                                                            __builtin_bswap32(wd[2]), __builtin_bswap32(wd[3]));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (4 * qd + k < nwords) out32[4 * qd + k] = __builtin_bswap32(wd[k]);
+                }
+                uint32_t c = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t x0 = ((c >> 8) ^ (wd[k] >> 24)) & 0xFFu, x1 = (c ^ (wd[k] >> 16)) & 0xFFu;
+                    c = (uint32_t)(s_crc_zk[2][x0] ^ s_crc_zk[1][x1] ^ s_crc_zk[0][(wd[k] >> 8) & 0xFFu] ^ s_crc_tab[wd[k] & 0xFFu]);
+                }
+                crc = crc16_mul_const<crc16_pow_table().v[10]>(crc) ^ c;
+            }
         }
     }
+    STAMP(4);
+    // behind the `lane` quads that follow this lane's last one
+    crc = crc16_shift_bytes<9, 4>(crc, 16 * lane);
+    crc = wave_xor_u32(crc);
+    __threadfence_block();                 // the dword the two CRC bytes lie in may be one this wave stored above
+    if (lane == 0) {
+        const uint32_t c = crc16_unshift_bytes(crc, 16 * nquads - body_bytes);
+        out[body_bytes] = (uint8_t)(c >> 8);
+        out[body_bytes + 1] = (uint8_t)c;
+        frame_bytes[f] = body_bytes + 2;
+    }
+    STAMP(6);
 }
 
 
@@ -513,7 +643,7 @@ hipError_t launch_assemble(hipStream_t st, const fhip_params &p, const int32_t *
     const int bps = p.bits_per_sample;
     const int vsize = (p.channels == 2) ? 16 + ((n * (bps + bps + 1) + 7) >> 3)
                                         : 16 + ((n * p.channels * bps + 7) >> 3);
-    hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(NT), 0, st, p, n, pcm, info, rice,
+    hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(AT), 0, st, p, n, pcm, info, rice,
                        (long long)slot_bytes, frames, (long long)frame_stride, frame_bytes,
                        number_base, number_step, numbers, sr0, sr1, bpsc, vsize, frame_src, dev_frames, MultiBin{});
     return hipGetLastError();
@@ -538,7 +668,7 @@ hipError_t launch_assemble_bins(hipStream_t st, const fhip_params &p, const Mult
         else if (sr < 65535) { sr0 = 13; sr1 = sr; }
     }
     for (int i = 1; i < 8; i++) if (p.bits_per_sample == bd_table[i]) { bpsc = i; break; }
-    hipLaunchKernelGGL(k_assemble, dim3(slots), dim3(NT), 0, st, p, 0, pcm, info, rice, 0ll, frames, 0ll,
+    hipLaunchKernelGGL(k_assemble, dim3(slots), dim3(AT), 0, st, p, 0, pcm, info, rice, 0ll, frames, 0ll,
                        frame_bytes, 0u, 0u, numbers, sr0, sr1, bpsc, 0, frame_src, (const int32_t *)nullptr, mb);
     return hipGetLastError();
 }
@@ -791,12 +921,13 @@ void k_pack_frames_perm(const uint8_t *__restrict__ frames, const long long *__r
                         const int32_t *__restrict__ dev_frames, long long cap,
                         int32_t *__restrict__ stream_bytes, long long *__restrict__ totals)
 {
-    const int f = blockIdx.x, tid = threadIdx.x;
-    if (f >= dev_count(dev_frames, 0)) return;
+    const int tid = threadIdx.x;
+    const int total = dev_count(dev_frames, 0);
+    for (int f = blockIdx.x; f < total; f += gridDim.x) {         // (a grid of the most frames there can be: mostly empty workgroups)
     const int slot = order[f];
     const int len = max(fbytes[slot], 0);
     if (tid == 0 && stream_bytes) stream_bytes[f] = fbytes[slot];   // the frame sizes in stream order
-    if (offsets[f] + len > cap) return;                             // the caller's buffer ends here (totals[3])
+    if (offsets[f] + len > cap) continue;                           // the caller's buffer ends here (totals[3])
     const uint8_t *src = frames + src_off[slot];                   // 4-byte aligned
     uint8_t *dst = packed + offsets[f];
     const int head = min((int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3), len);
@@ -812,6 +943,7 @@ void k_pack_frames_perm(const uint8_t *__restrict__ frames, const long long *__r
     }
     const int done = head + 4 * ndw;
     if (tid < len - done) dst[done + tid] = src[done + tid];
+    }
 }
 
 // bytes and frames of every block (what flake_encode_frame returns for it, vbs.c:104-116)

@@ -1,6 +1,6 @@
 """Diagnostic (not part of the product): phase stamps of k_order_search, workgroup 0 (wave 0), per round.
 Build: python -c "from flake_amd.build import build_hip; build_hip(True, ['-DFHIP_STAMPS'], 'libflakehip_dbg.so')"; run on the GPU box.
-python tools/stamps_k3s.py [level]"""
+python tools/stamps_k3s.py [level] [block size]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,8 +8,11 @@ import flake_amd as fa
 os.environ["FHIP_LIB"] = os.path.join(fa.LIB_DIR, "libflakehip_dbg.so")
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 p = fa.level_params(level, variable_block_size=0) if level >= 9 else fa.level_params(level)
-pcm = fa.synth_pcm(2048, p.block_size, 2, 16)
-enc = fa.Encoder(p, max_frames=2048)
+if len(sys.argv) > 2:
+    p = fa.level_params(level, variable_block_size=0, block_size=int(sys.argv[2]))
+nfr = 2048 * max(1, 4096 // p.block_size)
+pcm = fa.synth_pcm(nfr, p.block_size, 2, 16)
+enc = fa.Encoder(p, max_frames=nfr)
 for _ in range(3):
     enc.encode_subframes(pcm, p.block_size, want_residual=False)
 st = (C.c_longlong * 64)()

@@ -502,6 +502,133 @@ void prepare_stereo_body(const int32_t *__restrict__ pcm, int32_t *__restrict__ 
     }
 }
 
+// The same for blocks of more than 4096 samples inside a ragged batch, in two passes over the block (the second finds it
+// in L2): five to eight quads per thread held through the decision are 120-181 registers -- two waves per SIMD for every
+// bin of the launch (k_prepare_stereo_bins) and 355 us for the blocks of a level-12 batch whose bytes take 80.  Pass 1
+// takes the sums of the estimate and, for all four candidates of the two output channels (left, right, mid, side), the OR
+// of the samples and of their magnitude bits -- none of them depends on the decision --; pass 2 applies the decision.
+__device__ __forceinline__
+void prepare_stereo_body_2p(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
+                            fhip_subframe_info *__restrict__ info, int n, int bps, int estimate,
+                            int allow_narrow, int nframes, const long long *__restrict__ frame_src, int blk)
+{
+    __shared__ unsigned long long s_sum2[4][4];
+    __shared__ uint32_t s_or2[4][8];
+    if (blk >= nframes) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int f = blk;
+    const int4 *src = reinterpret_cast<const int4 *>(pcm + (frame_src ? (size_t)frame_src[f] : (size_t)f * n * 2));
+    const int nquads = n >> 2;
+    const bool est = estimate && n > 32;
+
+    unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    uint32_t o[4] = {0, 0, 0, 0}, mg[4] = {0, 0, 0, 0};          // left, right, mid, side
+#pragma unroll 2
+    for (int g = tid; g < nquads; g += NT) {
+        const int4 a = src[2 * g], b = src[2 * g + 1];           // (l0 r0 l1 r1) (l2 r2 l3 r3)
+        const int4 pv = src[max(2 * g - 1, 0)];                  // (l-2 r-2 l-1 r-1)
+        const uint32_t l[4] = {(uint32_t)a.x, (uint32_t)a.z, (uint32_t)b.x, (uint32_t)b.z};
+        const uint32_t r[4] = {(uint32_t)a.y, (uint32_t)a.w, (uint32_t)b.y, (uint32_t)b.w};
+        uint32_t l2 = (uint32_t)pv.x, r2 = (uint32_t)pv.y, l1 = (uint32_t)pv.z, r1 = (uint32_t)pv.w;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            // encode.c:598-643 calc_decorr_scores (no history for the block's first two samples, encode.c:607)
+            const int32_t lt = (int32_t)(l[q] - 2u * l1 + l2);
+            const int32_t rt = (int32_t)(r[q] - 2u * r1 + r2);
+            const int32_t mm = (int32_t)((uint32_t)lt + (uint32_t)rt) >> 1;
+            const int32_t ss = (int32_t)((uint32_t)lt - (uint32_t)rt);
+            const bool on = est && (4 * g + q >= 2);
+            a0 += on ? (unsigned long long)(long long)wrap_abs(lt) : 0ull;
+            a1 += on ? (unsigned long long)(long long)wrap_abs(rt) : 0ull;
+            a2 += on ? (unsigned long long)(long long)wrap_abs(mm) : 0ull;
+            a3 += on ? (unsigned long long)(long long)wrap_abs(ss) : 0ull;
+            l2 = l1; r2 = r1; l1 = l[q]; r1 = r[q];
+            // encode.c:668-693: what either output channel can be
+            const int32_t c4[4] = {(int32_t)l[q], (int32_t)r[q], (int32_t)(l[q] + r[q]) >> 1, (int32_t)(l[q] - r[q])};
+#pragma unroll
+            for (int z = 0; z < 4; z++) { o[z] |= (uint32_t)c4[z]; mg[z] |= (uint32_t)(c4[z] ^ (c4[z] >> 31)); }
+        }
+    }
+    if (est) {
+        a0 = wave_sum_u64(a0); a1 = wave_sum_u64(a1); a2 = wave_sum_u64(a2); a3 = wave_sum_u64(a3);
+        if (lane == 0) { s_sum2[wv][0] = a0; s_sum2[wv][1] = a1; s_sum2[wv][2] = a2; s_sum2[wv][3] = a3; }
+    }
+#pragma unroll
+    for (int z = 0; z < 4; z++) {
+        const uint32_t x = wave_or_u32(o[z]), y = wave_or_u32(mg[z]);
+        if (lane == 0) { s_or2[wv][z] = x; s_or2[wv][4 + z] = y; }
+    }
+    __syncthreads();
+    int mode = FHIP_CH_LEFT_RIGHT;
+    if (est) {
+        // every wave prices the four sums itself (prepare_stereo_body)
+        const unsigned long long sm = s_sum2[0][lane & 3] + s_sum2[1][lane & 3] + s_sum2[2][lane & 3] + s_sum2[3][lane & 3];
+        uint32_t dummy;
+        const int k = rice_k_fast(2 * sm, n, &dummy);
+        const unsigned long long cnt = rice_count64(2 * sm, n, k);      // no 32-bit truncation (encode.c:620)
+        const int lo = (int)(uint32_t)cnt, hi = (int)(uint32_t)(cnt >> 32);
+#define LANE64(q_) (((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(hi, q_) << 32) | (uint32_t)__builtin_amdgcn_readlane(lo, q_))
+        const unsigned long long c0 = LANE64(0), c1 = LANE64(1), c2 = LANE64(2), c3 = LANE64(3);
+#undef LANE64
+        const unsigned long long sc[4] = {c0 + c1, c0 + c3, c1 + c3, c2 + c3};
+        int best = 0;
+#pragma unroll
+        for (int q = 1; q < 4; q++) if (sc[q] < sc[best]) best = q;
+        mode = (best == 0) ? FHIP_CH_LEFT_RIGHT : (best == 1) ? FHIP_CH_LEFT_SIDE
+             : (best == 2) ? FHIP_CH_RIGHT_SIDE : FHIP_CH_MID_SIDE;
+    }
+    // which candidates the two channels are: (left, right), (left, side), (side, right), (mid, side)
+    const int cand[2] = {(mode == FHIP_CH_MID_SIDE) ? 2 : (mode == FHIP_CH_RIGHT_SIDE) ? 3 : 0,
+                         (mode == FHIP_CH_LEFT_RIGHT || mode == FHIP_CH_RIGHT_SIDE) ? 1 : 3};
+    int wasted[2], obits[2], magbits[2];
+    bool narrow[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        // encode.c:558-593
+        uint32_t ov = 0, mv = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+#pragma unroll
+            for (int z = 0; z < 4; z++) if (z == cand[c]) { ov |= s_or2[w][z]; mv |= s_or2[w][4 + z]; }
+        }
+        int w = ov ? min(__ffs((int)ov) - 1, bps - 1) : bps - 1;
+        if (w == bps - 1) w = 0;
+        wasted[c] = w;
+        obits[c] = bps - w;
+        const uint32_t m = mv >> w;
+        narrow[c] = allow_narrow && (m < 32768u);
+        magbits[c] = 32 - __clz((int)m);
+    }
+    if (mode == FHIP_CH_MID_SIDE || mode == FHIP_CH_LEFT_SIDE) obits[1]++;
+    if (mode == FHIP_CH_RIGHT_SIDE) obits[0]++;
+
+    int4 *dl = reinterpret_cast<int4 *>(smp + (size_t)f * 2 * n);
+    int4 *dr = reinterpret_cast<int4 *>(smp + (size_t)f * 2 * n + n);
+#pragma unroll 2
+    for (int g = tid; g < nquads; g += NT) {
+        const int4 a = src[2 * g], b = src[2 * g + 1];
+        int32_t L[4] = {a.x, a.z, b.x, b.z}, R[4] = {a.y, a.w, b.y, b.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int32_t l = L[q], r = R[q];
+            const int32_t mid = (int32_t)((uint32_t)l + (uint32_t)r) >> 1, sd = (int32_t)((uint32_t)l - (uint32_t)r);
+            L[q] = ((mode == FHIP_CH_MID_SIDE) ? mid : (mode == FHIP_CH_RIGHT_SIDE) ? sd : l) >> wasted[0];
+            R[q] = ((mode == FHIP_CH_LEFT_RIGHT || mode == FHIP_CH_RIGHT_SIDE) ? r : sd) >> wasted[1];
+        }
+        if (narrow[0]) reinterpret_cast<int2 *>(dl)[g] = make_int2((L[0] & 0xFFFF) | (L[1] << 16), (L[2] & 0xFFFF) | (L[3] << 16));
+        else dl[g] = make_int4(L[0], L[1], L[2], L[3]);
+        if (narrow[1]) reinterpret_cast<int2 *>(dr)[g] = make_int2((R[0] & 0xFFFF) | (R[1] << 16), (R[2] & 0xFFFF) | (R[3] << 16));
+        else dr[g] = make_int4(R[0], R[1], R[2], R[3]);
+    }
+    if (tid < 2) {
+        fhip_subframe_info *oi = &info[(size_t)f * 2 + tid];
+        oi->obits = obits[tid];
+        oi->wasted = wasted[tid];
+        oi->ch_mode = mode;
+        oi->reserved = (narrow[tid] ? 1 + magbits[tid] : 0) | ((1 + magbits[tid]) << 8);      // (prepare_stereo_body)
+    }
+}
+
 template <int M, int WPF, bool APPLY>
 __global__ __launch_bounds__(NT)
 void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
@@ -537,7 +664,7 @@ void k_prepare_stereo(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp
 // level-12 batch of 8192 blocks took 355 us for bytes that take 80; blocks of up to 4096 samples (QLIM 4)
 // need four quads per thread at most.
 template <int QLIM>
-__global__ __launch_bounds__(NT, QLIM <= 4 ? 4 : 2)   // (the variant of eight quads per thread holds 96 samples in registers)
+__global__ __launch_bounds__(NT, 4)
 void k_prepare_stereo_bins(const int32_t *__restrict__ pcm, int32_t *__restrict__ smp,
                            fhip_subframe_info *__restrict__ info, int bps, int estimate,
                            const long long *__restrict__ frame_src, MultiBin mb)
@@ -565,7 +692,16 @@ void k_prepare_stereo_bins(const int32_t *__restrict__ pcm, int32_t *__restrict_
         else if (quads <= 3 * NT) BODY_(3, 4);
         else BODY_(4, 4);
     } else {
-        FHIP_STEREO_GEOM(quads, BODY_);
+        // up to 4 NT quads as above; beyond, the block in two passes
+        if (quads <= 64) BODY_(1, 1);
+        else if (quads <= 128) BODY_(1, 2);
+        else if (quads <= 192) BODY_(3, 1);
+        else if (quads <= NT) BODY_(1, 4);
+        else if (quads <= 320) BODY_(5, 1);
+        else if (quads <= 2 * NT) BODY_(2, 4);
+        else if (quads <= 3 * NT) BODY_(3, 4);
+        else if (quads <= 4 * NT) BODY_(4, 4);
+        else prepare_stereo_body_2p(pcm, smp_k, info_k, n, bps, estimate, nar, nframes, src_k, blk);
     }
 #undef BODY_
 }

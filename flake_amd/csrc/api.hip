@@ -993,13 +993,15 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
     };
     // the lane a bin's launches go to: the one with the least estimated work queued.  A bin's search + K3 is a launch's
     // latency plus its live pieces' work, and the short pieces' bins hold more pieces (measured per 1024 blocks, eighths
-    // 1 .. 8: 130, 69, 64, 41, 62, 45, 72, 39 us).
+    // 1 .. 8: level 10 130, 69, 64, 41, 62, 45, 72, 39 us; level 12 275, 265, 245, 168, 137, 136, 115, 113): the weights
+    // are the mean of the two profiles, in twentieths of the lightest bin's.
+    static const int bin_weight[8] = {48, 35, 33, 21, 23, 20, 23, 17};
     long long queued[NA + 1] = {0};
     auto pick_stream = [&](int k) -> hipStream_t {
         if (!fan) return c->stream;
         int h = 0;
         for (int q = 1; q < vbs_lanes; q++) if (queued[q] < queued[h]) h = q;
-        queued[h] += 45 + 10 * (long long)(vb.cap[k] / std::max(nblocks, 1));
+        queued[h] += bin_weight[k];
         return h == 0 ? c->stream : c->aux[h - 1];
     };
 
@@ -1101,7 +1103,9 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
         // ---- order search + K3 per bin ----
         if (fan) HIP_TRY(c, fj.fork());
         for (int q = 0; q <= NA; q++) queued[q] = 0;
-        for (int k = 0; k < 8; k++) {                               // (the bins with the most pieces first)
+        static const int by_weight[8] = {0, 1, 2, 4, 6, 3, 5, 7};     // (the heaviest bins first)
+        for (int kk = 0; kk < 8; kk++) {
+            const int k = by_weight[kk];
             const int n = vb.n[k];
             const size_t sub0 = (size_t)vb.slot0[k] * nch;
             const int nsub_cap = vb.cap[k] * (int)nch;

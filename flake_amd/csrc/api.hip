@@ -1103,6 +1103,7 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
         // ---- order search + K3 per bin ----
         if (fan) HIP_TRY(c, fj.fork());
         for (int q = 0; q <= NA; q++) queued[q] = 0;
+        hipStream_t lane_of[8];
         static const int by_weight[8] = {0, 1, 2, 4, 6, 3, 5, 7};     // (the heaviest bins first)
         for (int kk = 0; kk < 8; kk++) {
             const int k = by_weight[kk];
@@ -1110,6 +1111,7 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
             const size_t sub0 = (size_t)vb.slot0[k] * nch;
             const int nsub_cap = vb.cap[k] * (int)nch;
             hipStream_t st = pick_stream(k);
+            lane_of[k] = st;
             int32_t *coefs = c->d_coefs + sub0 * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
             int32_t *shift = c->d_shift + sub0 * FHIP_MAX_ORDER;
             int32_t *opt = c->d_opt + sub0, *fin = c->d_fin + sub0 * fhip::FIN_STRIDE;
@@ -1124,14 +1126,37 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
                                            c->d_info + sub0, nullptr, c->d_bits + vb.bits_off[k], vb.slot[k], -1, 0,
                                            narrow[k], c->d_k0rec + sub0, searched, cnt_sub + k));
         }
-        HIP_TRY(c, fj.join());
-        // ---- K4 over all bins ----
+        // ---- K4: one launch per lane over the lane's bins, behind their K3s (round 4: one launch over all bins behind
+        // the join left it, and the 18 us a cross-queue wait takes, on the critical path while lanes idled) ----
         m2.cnt = cnt_frames;
         {
-            MaybeProf pr(c, prof, 4);
-            HIP_TRY(c, fhip::launch_assemble_bins(c->stream, p, m2, pcm, c->d_info, c->d_bits, c->d_frames, c->d_fbytes,
-                                                  c->d_fnum, c->d_frame_src));
+            hipStream_t done[8];
+            int ndone = 0;
+            for (int k = 0; k < 8; k++) {
+                bool seen = false;
+                for (int q = 0; q < ndone; q++) seen = seen || done[q] == lane_of[k];
+                if (seen) continue;
+                done[ndone++] = lane_of[k];
+                fhip::MultiBin ml = m2;
+                int nb = 0, wgs = 0;
+                for (int q = 0; q < 8; q++) {
+                    if (lane_of[q] != lane_of[k]) continue;
+                    ml.cnt_ix[nb] = q;
+                    ml.wg0[nb] = wgs;
+                    wgs += vb.cap[q];
+                    ml.n[nb] = m2.n[q]; ml.cap[nb] = m2.cap[q]; ml.unit0[nb] = m2.unit0[q];
+                    ml.stride[nb] = m2.stride[q]; ml.fr_off[nb] = m2.fr_off[q];
+                    ml.slot[nb] = m2.slot[q]; ml.bits_off[nb] = m2.bits_off[q]; ml.vsize[nb] = m2.vsize[q];
+                    nb++;
+                }
+                ml.nbins = nb;
+                ml.wg0[nb] = wgs;
+                MaybeProf pr(c, prof, 4);
+                HIP_TRY(c, fhip::launch_assemble_bins(lane_of[k], p, ml, pcm, c->d_info, c->d_bits, c->d_frames, c->d_fbytes,
+                                                      c->d_fnum, c->d_frame_src));
+            }
         }
+        HIP_TRY(c, fj.join());
     } else {
         if (fan) HIP_TRY(c, fj.fork());
         for (int k = 7; k >= 0; k--) {

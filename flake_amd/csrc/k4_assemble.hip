@@ -182,14 +182,15 @@ void k_assemble(fhip_params P, int n, const int32_t *__restrict__ pcm,
                 const long long *__restrict__ frame_src, const int32_t *__restrict__ dev_frames, MultiBin mb)
 {
     if (dev_frames && (int)blockIdx.x >= dev_count(dev_frames, 0)) return;      // (a ragged batch's grid is its bin's capacity)
-    const int f = blockIdx.x;
+    int f = blockIdx.x;
     if (mb.nbins) {
-        // every bin of a ragged batch in one launch (kernels.h: MultiBin; one workgroup per frame
-        // slot: wg0 = unit0): info / frame_bytes / numbers / frame_src are the handle's whole
-        // slot-indexed arrays, the sections and the frames lie bin by bin
+        // several bins of a ragged batch in one launch (kernels.h: MultiBin; one workgroup per frame slot of the
+        // bins listed): info / frame_bytes / numbers / frame_src are the handle's whole slot-indexed arrays, the
+        // sections and the frames lie bin by bin
         const int k = find_bin(mb, f);
-        const int local = f - mb.unit0[k];
+        const int local = f - mb.wg0[k];
         if (local >= __builtin_amdgcn_readfirstlane(mb.cnt[mb.cnt_ix[k]])) return;
+        f = mb.unit0[k] + local;
         n = mb.n[k];
         verbatim_size = mb.vsize[k];
         slot_bytes = mb.slot[k];
@@ -654,7 +655,7 @@ hipError_t launch_assemble_bins(hipStream_t st, const fhip_params &p, const Mult
                                 int32_t *frame_bytes, const uint32_t *numbers, const long long *frame_src)
 {
     if (mb.nbins < 1 || !numbers || !frame_src) return hipErrorInvalidValue;
-    const int slots = mb.unit0[mb.nbins - 1] + mb.cap[mb.nbins - 1];
+    const int slots = mb.wg0[mb.nbins];
     if (slots == 0) return hipSuccess;
     static const int sr_table[16] = {0, 0, 0, 0, 8000, 16000, 22050, 24000, 32000, 44100, 48000,
                                      96000, 0, 0, 0, 0};

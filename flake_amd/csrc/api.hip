@@ -993,9 +993,11 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
     };
     // the lane a bin's launches go to: the one with the least estimated work queued.  A bin's search + K3 is a launch's
     // latency plus its live pieces' work, and the short pieces' bins hold more pieces (measured per 1024 blocks, eighths
-    // 1 .. 8: level 10 130, 69, 64, 41, 62, 45, 72, 39 us; level 12 275, 265, 245, 168, 137, 136, 115, 113): the weights
-    // are the mean of the two profiles, in twentieths of the lightest bin's.
-    static const int bin_weight[8] = {48, 35, 33, 21, 23, 20, 23, 17};
+    // 1 .. 8, with three lanes busy: level 10 -- the vector searches -- 175, 195, 192, 56, 54, 39, 72, 40 us; level 12 -- the
+    // matrix searches -- 275, 265, 245, 168, 137, 136, 115, 113): the weights are those, in units of 5 us.
+    static const int bin_weight_vec[8] = {35, 39, 38, 11, 11, 8, 14, 8}, bin_weight_mat[8] = {55, 53, 49, 34, 27, 27, 23, 23};
+    const bool mat_search = p.order_method == 5 && p.bits_per_sample <= 24 && (p.bits_per_sample > 16 || p.max_prediction_order > 16);
+    const int *bin_weight = mat_search ? bin_weight_mat : bin_weight_vec;
     long long queued[NA + 1] = {0};
     auto pick_stream = [&](int k) -> hipStream_t {
         if (!fan) return c->stream;
@@ -1100,18 +1102,78 @@ int vbs_dev_core(fhip_ctx *c, const int32_t *pcm, int nblocks, int block_size, u
             HIP_TRY(c, fhip::launch_lpc_bins(c->stream, mk, c->d_autoc, p.max_prediction_order, p.lpc_precision,
                                              p.order_method, c->d_coefs, c->d_shift, c->d_opt, c->d_fin));
         }
-        // ---- order search + K3 per bin ----
+        // ---- order search + K3: a launch each per bin; the thinly filled bins of a small batch -- four eighths and longer:
+        // a few hundred pieces each, whose launches are latency one after another -- grouped by the kernel they can share
+        // (k_order_search_bins / k_encode_bins).  Units (a bin, or a group) go to the lanes by estimated work, heaviest first.
         if (fan) HIP_TRY(c, fj.fork());
         for (int q = 0; q <= NA; q++) queued[q] = 0;
         hipStream_t lane_of[8];
-        static const int by_weight[8] = {0, 1, 2, 4, 6, 3, 5, 7};     // (the heaviest bins first)
-        for (int kk = 0; kk < 8; kk++) {
-            const int k = by_weight[kk];
+        static const int merge_max = getenv("FHIP_VBS_MERGE_MAX") ? atoi(getenv("FHIP_VBS_MERGE_MAX")) : 2048;   // blocks
+        int unit_of[8], nunits = 0, unit_w[8] = {0};
+        {
+            int gkey[8];
+            for (int k = 0; k < 8; k++) {
+                const bool sr = fhip::order_search_supported(p, vb.n[k]);
+                const int sg = sr ? fhip::order_search_group(p, vb.n[k]) : -1;
+                // (the 256-thread geometries of runs up to 16 only: the two 128-thread bins of runs of 20 and 28 took 84 us in one
+                // launch, 40 and 60 on different lanes)
+                gkey[k] = (nblocks <= merge_max && k >= 3 && sg == 256 && fhip::encode_group(p, vb.n[k], true) == 256) ? sg : -1;
+                unit_of[k] = -1;
+                for (int q = 3; q < k && gkey[k] >= 0; q++) if (gkey[q] == gkey[k]) { unit_of[k] = unit_of[q]; break; }
+                if (unit_of[k] < 0) unit_of[k] = nunits++;
+                // (a group costs its first member's latency once: 95 us of three launches were 55 in one)
+                unit_w[unit_of[k]] += (unit_w[unit_of[k]] > 0) ? 2 : bin_weight[k];
+            }
+        }
+        bool unit_done[8] = {false};
+        for (int turn = 0; turn < nunits; turn++) {
+            int u = -1;
+            for (int q = 0; q < nunits; q++) if (!unit_done[q] && (u < 0 || unit_w[q] > unit_w[u])) u = q;
+            unit_done[u] = true;
+            // the lane with the least estimated work queued
+            hipStream_t st = c->stream;
+            if (fan) {
+                int h = 0;
+                for (int q = 1; q < vbs_lanes; q++) if (queued[q] < queued[h]) h = q;
+                queued[h] += unit_w[u];
+                st = h == 0 ? c->stream : c->aux[h - 1];
+            }
+            int members = 0, first = -1;
+            for (int k = 0; k < 8; k++) if (unit_of[k] == u) { lane_of[k] = st; members++; if (first < 0) first = k; }
+            if (members > 1) {
+                fhip::MultiBin mg{};
+                mg.cnt = cnt_sub;
+                int nb = 0, wgs = 0;
+                for (int k = 0; k < 8; k++) {
+                    if (unit_of[k] != u) continue;
+                    mg.cnt_ix[nb] = k;
+                    mg.wg0[nb] = wgs;
+                    wgs += vb.cap[k] * (int)nch;
+                    mg.n[nb] = vb.n[k];
+                    mg.unit0[nb] = vb.slot0[k] * (int)nch;
+                    mg.cap[nb] = vb.cap[k] * (int)nch;
+                    mg.narrow[nb] = narrow[k] ? 1 : 0;
+                    mg.smp_off[nb] = vb.smp_off[k];
+                    mg.slot[nb] = vb.slot[k];
+                    mg.bits_off[nb] = vb.bits_off[k];
+                    nb++;
+                }
+                mg.nbins = nb;
+                mg.wg0[nb] = wgs;
+                {
+                    MaybeProf pr(c, prof, 5);
+                    HIP_TRY(c, fhip::launch_order_search_bins(st, p, mg, c->d_smp, c->d_coefs, c->d_shift, c->d_opt, c->d_fin,
+                                                              c->d_k0rec));
+                }
+                MaybeProf pr(c, prof, 3);
+                HIP_TRY(c, fhip::launch_encode_bins(st, p, mg, c->d_smp, c->d_coefs, c->d_shift, c->d_opt, c->d_fin, c->d_info,
+                                                    c->d_k0rec, c->d_bits));
+                continue;
+            }
+            const int k = first;
             const int n = vb.n[k];
             const size_t sub0 = (size_t)vb.slot0[k] * nch;
             const int nsub_cap = vb.cap[k] * (int)nch;
-            hipStream_t st = pick_stream(k);
-            lane_of[k] = st;
             int32_t *coefs = c->d_coefs + sub0 * FHIP_MAX_ORDER * FHIP_MAX_ORDER;
             int32_t *shift = c->d_shift + sub0 * FHIP_MAX_ORDER;
             int32_t *opt = c->d_opt + sub0, *fin = c->d_fin + sub0 * fhip::FIN_STRIDE;

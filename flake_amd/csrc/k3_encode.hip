@@ -1545,16 +1545,18 @@ template <int C, int T, int MODE>
 // of a 512- / 1024-thread workgroup stops at four waves per SIMD anyway.
 // Geometry for n = 4096, measured: (C,T) = (16,256) 94 us, (8,512) 137, (4,1024)
 // 256, (32,128) 115 (206 VGPRs): cross-wave phases grow with T, serial ones with C.
-__global__ __launch_bounds__(T, (MODE == 2 || C >= 18 || (C >= 14 && T > 256)) ? 4 : 5)
-void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ smp_all,
-                   const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
-                   const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,
-                   fhip_subframe_info *__restrict__ info, const fhip_subframe_info *__restrict__ prep,
-                   int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
-                   int narrow_ok, const int32_t *__restrict__ dev_sub)
+// Subframe s (an index into the subframe-indexed workspaces; its samples at smp_all + s n, its section at bits_out +
+// s slot_bytes): the body of k_encode_pow2 (one geometry: a batch, or one bin of a ragged batch) and of k_encode_bins
+// (several thinly filled bins of a ragged batch in one launch).
+__device__ __forceinline__
+void encode_pow2_body(const fhip_params &P, const int n, const int32_t *__restrict__ smp_all,
+                      const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
+                      const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,
+                      fhip_subframe_info *__restrict__ info, const fhip_subframe_info *__restrict__ prep,
+                      int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, const long long slot_bytes,
+                      const int narrow_ok, const int s)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    if (dev_sub && (int)blockIdx.x >= dev_count(dev_sub, 0)) return;      // (a ragged batch's grid is its bin's capacity)
     size_t off[12];
     fast_lds_layout(n, SmpImg<C, T>::SIZE, off, fast_wide_window(MODE, P.bits_per_sample));
     FastCtx<C, T> e;
@@ -1594,7 +1596,6 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
     // One workgroup per subframe (a persistent variant that prefetched the next
     // subframe into registers measured slower: the hardware's own dispatch of a
     // fresh workgroup per subframe balances better and costs no VGPRs).
-    const int s = blockIdx.x;
     int32_t xn[C];
     int32_t first_n, obits_n, fcoef_n = 0, fshift_n = 0, forder_n = 0, fcabs_n = 0, magbits_n = -1;
     {
@@ -2137,6 +2138,49 @@ void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ s
   }
 }
 
+template <int C, int T, int MODE>
+__global__ __launch_bounds__(T, (MODE == 2 || C >= 18 || (C >= 14 && T > 256)) ? 4 : 5)
+void k_encode_pow2(fhip_params P, int n, int nsub, const int32_t *__restrict__ smp_all,
+                   const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
+                   const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,
+                   fhip_subframe_info *__restrict__ info, const fhip_subframe_info *__restrict__ prep,
+                   int32_t *__restrict__ res_out, uint8_t *__restrict__ bits_out, long long slot_bytes,
+                   int narrow_ok, const int32_t *__restrict__ dev_sub)
+{
+    if (dev_sub && (int)blockIdx.x >= dev_count(dev_sub, 0)) return;      // (a ragged batch's grid is its bin's capacity)
+    encode_pow2_body<C, T, MODE>(P, n, smp_all, coefs_all, shift_all, opt_all, fin_all, info, prep, res_out, bits_out,
+                                 slot_bytes, narrow_ok, (int)blockIdx.x);
+}
+
+// Several thinly filled bins of a ragged batch in ONE launch (kernels.h: MultiBin, units = subframes; k_order_search_bins
+// has the why): 256-thread geometries with runs of 2, 4, 8, 10, 12, 14, 16 samples -- every piece of a 4096 block but three
+// eighths, the first four of an 8192 block -- whose row is known when the kernel starts (MODE 0 / 3).
+template <int MODE>
+__global__ __launch_bounds__(256, 5)
+void k_encode_bins(fhip_params P, MultiBin mb, const int32_t *__restrict__ smp,
+                   const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
+                   const int32_t *__restrict__ opt_all, const int32_t *__restrict__ fin_all,
+                   fhip_subframe_info *__restrict__ info, const fhip_subframe_info *__restrict__ prep,
+                   uint8_t *__restrict__ bits)
+{
+    constexpr int T = 256;
+    const int blk = blockIdx.x;
+    const int k = find_bin(mb, blk);
+    const int local = blk - mb.wg0[k];
+    if (local >= __builtin_amdgcn_readfirstlane(mb.cnt[mb.cnt_ix[k]])) return;
+    const int n = mb.n[k];
+    const int s = mb.unit0[k] + local;
+    const int32_t *smp_k = smp + mb.smp_off[k] - (long long)mb.unit0[k] * n;          // row s: smp_k + s n
+    const long long slot = mb.slot[k];
+    uint8_t *bits_k = bits + mb.bits_off[k] - (long long)mb.unit0[k] * slot;           // section s: bits_k + s slot
+    const int nar = mb.narrow[k];
+#define BODY_(CC) encode_pow2_body<CC, T, MODE>(P, n, smp_k, coefs_all, shift_all, opt_all, fin_all, info, prep, nullptr, bits_k, slot, nar, s)
+    const int c = n / T;
+    if (c == 2) BODY_(2); else if (c == 4) BODY_(4); else if (c == 8) BODY_(8); else if (c == 10) BODY_(10);
+    else if (c == 12) BODY_(12); else if (c == 14) BODY_(14); else BODY_(16);
+#undef BODY_
+}
+
 }  // namespace
 
 size_t encode_lds_bytes(int n)
@@ -2208,6 +2252,52 @@ bool narrow_rows_ok(const fhip_params &p, int nsub, int n, bool lpc_path, bool w
     if (!fast_geometry(p, n, &fc, &ft) || (fc % 8) != 0) return false;
     if (lpc_path && !wave_typed_k1 && !autocorr_is_wave_typed(nsub, n, p.max_prediction_order)) return false;
     return true;
+}
+
+// the K3 launch group of a bin of a ragged batch: 256 (k_encode_bins), or -1: launch_encode for the bin alone
+int encode_group(const fhip_params &p, int n, bool order_known)
+{
+    static const bool generic = getenv("FHIP_K3_GENERIC") != nullptr;           // measurements only
+    int fc = 0, ft = 0;
+    if (generic || !fast_geometry(p, n, &fc, &ft)) return -1;
+    const bool single_row = (p.prediction_type == 2) && (n > p.max_prediction_order) && (p.order_method <= 1 || order_known);
+    if (!single_row) return -1;
+    if (ft == 256 && (fc == 2 || fc == 4 || fc == 8 || fc == 10 || fc == 12 || fc == 14 || fc == 16)) return 256;
+    return -1;
+}
+
+hipError_t launch_encode_bins(hipStream_t st, const fhip_params &p, const MultiBin &mb, const int32_t *smp,
+                              const int32_t *coefs, const int32_t *shift, const int32_t *opt_order, const int32_t *fin,
+                              fhip_subframe_info *info, const fhip_subframe_info *prep, uint8_t *bits)
+{
+    if (mb.nbins < 1) return hipSuccess;
+    const int grid = mb.wg0[mb.nbins];
+    if (grid == 0) return hipSuccess;
+    if (!prep || prep == info) return hipErrorInvalidValue;
+    const int mode = (p.max_prediction_order > 8) ? 3 : 0;           // launch_encode's rule for a single row
+    size_t lds = 0;
+    for (int k = 0; k < mb.nbins; k++) {
+        int fc = 0, ft = 0;
+        if (encode_group(p, mb.n[k], true) != 256 || !fast_geometry(p, mb.n[k], &fc, &ft)) return hipErrorInvalidValue;
+        size_t off[12], img = 0;
+#define SZ_(CC) if (fc == CC) img = (size_t)SmpImg<CC, 256>::SIZE
+        SZ_(2); SZ_(4); SZ_(8); SZ_(10); SZ_(12); SZ_(14); SZ_(16);
+#undef SZ_
+        const size_t l = fast_lds_layout(mb.n[k], img, off, fast_wide_window(mode, p.bits_per_sample));
+        lds = l > lds ? l : lds;
+    }
+#define LAUNCH_EB(MM)                                                                        \
+    do {                                                                                     \
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_encode_bins<MM>), \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (er != hipSuccess) return er;                                                     \
+        hipLaunchKernelGGL((k_encode_bins<MM>), dim3(grid), dim3(256), lds, st, p, mb, smp, coefs, shift, opt_order, \
+                           fin, info, prep, bits);                                           \
+        return hipGetLastError();                                                            \
+    } while (0)
+    if (mode == 3) LAUNCH_EB(3);
+    LAUNCH_EB(0);
+#undef LAUNCH_EB
 }
 
 hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *smp,

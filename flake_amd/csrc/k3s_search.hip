@@ -655,15 +655,17 @@ template <int C, int T, int G, bool MM = false>
 #define FHIP_SRCH_WLONG 3
 #endif
 // (the matrix instances of runs >= 20 hold two workgroups per CU by their LDS -- image, limb planes, leaves: 59-72 KB)
-__global__ __launch_bounds__(T, (T <= 256) ? ((MM && C >= 20) ? 2 : (C >= 20 || MM) ? FHIP_SRCH_WLONG : 4) : (T <= 512) ? 2 : 1)
-void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
-                    const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
-                    int32_t *__restrict__ opt_all, int32_t *__restrict__ fin_all,
-                    const fhip_subframe_info *__restrict__ prep, int narrow_ok,
-                    const int32_t *__restrict__ dev_sub, uint32_t *__restrict__ table_out, LogPlan0 lg0)
+// The search of subframe s (an index into the subframe-indexed workspaces; its samples at smp_all + s n): the body of
+// k_order_search (one geometry: a batch, or one bin of a ragged batch) and of k_order_search_bins (several thinly
+// filled bins of a ragged batch in one launch).
+__device__ __forceinline__
+void order_search_body(const fhip_params &P, const int n, const int32_t *__restrict__ smp_all,
+                       const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
+                       int32_t *__restrict__ opt_all, int32_t *__restrict__ fin_all,
+                       const fhip_subframe_info *__restrict__ prep, const int narrow_ok,
+                       uint32_t *__restrict__ table_out, const LogPlan0 &lg0, const int s)
 {
     static_assert(C % 4 == 0 && T >= 128 && (T & (T - 1)) == 0, "k_order_search: runs of whole groups of four");
-    if (dev_sub && (int)blockIdx.x >= dev_count(dev_sub, 0)) return;
     using Img = SmpImg<C, T>;
     constexpr int LT = clog2(T);
     constexpr int NW = T / WAVE;
@@ -696,7 +698,6 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     // fp64 rounding toward -inf: fir_lpc's floor (see k_encode_pow2)
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 2" ::: "memory");
 
-    const int s = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef FHIP_WV_VECTOR
     const int wv = tid >> 6;
@@ -1255,6 +1256,51 @@ void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
     STAMP(31);
 }
 
+template <int C, int T, int G, bool MM = false>
+__global__ __launch_bounds__(T, (T <= 256) ? ((MM && C >= 20) ? 2 : (C >= 20 || MM) ? FHIP_SRCH_WLONG : 4) : (T <= 512) ? 2 : 1)
+void k_order_search(fhip_params P, int n, const int32_t *__restrict__ smp_all,
+                    const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
+                    int32_t *__restrict__ opt_all, int32_t *__restrict__ fin_all,
+                    const fhip_subframe_info *__restrict__ prep, int narrow_ok,
+                    const int32_t *__restrict__ dev_sub, uint32_t *__restrict__ table_out, LogPlan0 lg0)
+{
+    if (dev_sub && (int)blockIdx.x >= dev_count(dev_sub, 0)) return;
+    order_search_body<C, T, G, MM>(P, n, smp_all, coefs_all, shift_all, opt_all, fin_all, prep, narrow_ok, table_out, lg0,
+                                   (int)blockIdx.x);
+}
+
+// Several bins of a ragged batch in ONE launch (kernels.h: MultiBin, units = subframes): bins whose geometries share the
+// workgroup size T and the register class -- CSET 0: runs of 4 .. 16 samples, 1: runs of 20 .. 28 -- for the THINLY filled
+// bins of a small batch (the long pieces: a few hundred subframes each), whose launches are latency one after another on
+// the handle's three lanes (`profiles/r04_vbs_timeline.txt`).  Every bin of the launch runs with the largest one's LDS and
+// registers: for well-filled bins a launch each is faster, and the matrix instances are not built this way.
+template <int T, int G, int CSET>
+__global__ __launch_bounds__(T, CSET ? FHIP_SRCH_WLONG : 4)
+void k_order_search_bins(fhip_params P, MultiBin mb, const int32_t *__restrict__ smp,
+                         const int32_t *__restrict__ coefs_all, const int32_t *__restrict__ shift_all,
+                         int32_t *__restrict__ opt_all, int32_t *__restrict__ fin_all,
+                         const fhip_subframe_info *__restrict__ prep, LogPlan0 lg0)
+{
+    const int blk = blockIdx.x;
+    const int k = find_bin(mb, blk);
+    const int local = blk - mb.wg0[k];
+    if (local >= __builtin_amdgcn_readfirstlane(mb.cnt[mb.cnt_ix[k]])) return;
+    const int n = mb.n[k];
+    const int s = mb.unit0[k] + local;
+    const int32_t *smp_k = smp + mb.smp_off[k] - (long long)mb.unit0[k] * n;          // row s: smp_k + s n
+    const int nar = mb.narrow[k];
+#define BODY_(CC) order_search_body<CC, T, G, false>(P, n, smp_k, coefs_all, shift_all, opt_all, fin_all, prep, nar, nullptr, lg0, s)
+    const int c = n / T;
+    if constexpr (T == 128) {
+        if constexpr (CSET == 0) { if (c == 4) BODY_(4); else BODY_(12); }
+        else { if (c == 20) BODY_(20); else BODY_(28); }
+    } else {
+        if constexpr (CSET == 0) { if (c == 4) BODY_(4); else if (c == 8) BODY_(8); else if (c == 12) BODY_(12); else BODY_(16); }
+        else { if (c == 20) BODY_(20); else if (c == 24) BODY_(24); else BODY_(28); }
+    }
+#undef BODY_
+}
+
 }  // namespace
 
 // The order-search kernel serves the LPC order searches (order methods 2..6) of block sizes that
@@ -1384,6 +1430,72 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
     }
 #undef LAUNCH_SRCH
     return hipGetLastError();
+}
+
+static bool order_search_is_matrix(const fhip_params &p, int ft)
+{
+    // (launch_order_search's rule)
+    static const bool no_mm = getenv("FHIP_NO_MM") != nullptr;              // measurements only
+    return !no_mm && ft >= 256 && p.order_method == 5 && p.bits_per_sample <= 24 &&
+           (p.bits_per_sample > 16 || p.max_prediction_order > 16);
+}
+
+static size_t smp_img_size(int fc, int ft)
+{
+#define SZ_(CC, TT) if (fc == CC && ft == TT) return (size_t)SmpImg<CC, TT>::SIZE
+    SZ_(4, 128); SZ_(12, 128); SZ_(20, 128); SZ_(28, 128);
+    SZ_(4, 256); SZ_(8, 256); SZ_(12, 256); SZ_(16, 256); SZ_(20, 256); SZ_(24, 256); SZ_(28, 256);
+#undef SZ_
+    return 0;
+}
+
+// the launch group of a bin of a ragged batch: bins of one group can share a k_order_search_bins launch; -1: the bin has
+// its own launch (launch_order_search: the matrix instances, the 512-thread ones)
+int order_search_group(const fhip_params &p, int n)
+{
+    int fc = 0, ft = 0;
+    if (!order_search_supported(p, n) || !search_geometry(n, &fc, &ft) || ft > 256 || order_search_is_matrix(p, ft)) return -1;
+    return ft | ((fc >= 20) ? 0x1000 : 0);
+}
+
+hipError_t launch_order_search_bins(hipStream_t st, const fhip_params &p, const MultiBin &mb, const int32_t *smp,
+                                    const int32_t *coefs, const int32_t *shift, int32_t *opt_order, int32_t *fin,
+                                    const fhip_subframe_info *prep)
+{
+    if (mb.nbins < 1) return hipSuccess;
+    const int grid = mb.wg0[mb.nbins];
+    if (grid == 0) return hipSuccess;
+    const int key = order_search_group(p, mb.n[0]);
+    if (key < 0) return hipErrorInvalidValue;
+    constexpr int G = 4;
+    size_t lds = 0;
+    for (int k = 0; k < mb.nbins; k++) {
+        if (order_search_group(p, mb.n[k]) != key) return hipErrorInvalidValue;
+        int fc = 0, ft = 0;
+        search_geometry(mb.n[k], &fc, &ft);
+        size_t off[16];
+        const size_t l = srch_lds_layout<G>(smp_img_size(fc, ft), off, ft < 256 ? 256 : ft, 0, srch_crow(fc));
+        lds = l > lds ? l : lds;
+    }
+    const LogPlan0 lg0 = (p.order_method == 6) ? log_plan_round0(p.min_prediction_order, p.max_prediction_order, G) : LogPlan0{0u, 0, 0};
+#define LAUNCH_BINS(TT, CS)                                                                  \
+    do {                                                                                     \
+        hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_order_search_bins<TT, G, CS>), \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (er != hipSuccess) return er;                                                     \
+        hipLaunchKernelGGL((k_order_search_bins<TT, G, CS>), dim3(grid), dim3(TT), lds, st, p, mb, smp, coefs, \
+                           shift, opt_order, fin, prep, lg0);                                \
+        return hipGetLastError();                                                            \
+    } while (0)
+    switch (key) {
+    case 128: LAUNCH_BINS(128, 0);
+    case 128 | 0x1000: LAUNCH_BINS(128, 1);
+    case 256: LAUNCH_BINS(256, 0);
+    case 256 | 0x1000: LAUNCH_BINS(256, 1);
+    default: break;
+    }
+#undef LAUNCH_BINS
+    return hipErrorInvalidValue;
 }
 
 }  // namespace fhip

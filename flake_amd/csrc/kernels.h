@@ -100,6 +100,20 @@ hipError_t launch_order_search(hipStream_t st, const fhip_params &p, const int32
                                bool narrow_ok, const int32_t *dev_sub = nullptr,
                                uint32_t *table_out = nullptr);
 
+struct MultiBin;
+// The thinly filled bins of a small ragged batch: several bins in one search launch and one K3 launch.
+// order_search_group: >= 0, equal for bins that can share a launch (-1: launch_order_search for that bin alone);
+// encode_group: 256 or -1 likewise.  mb: units = subframes, wg0 from the capacities, cnt = live subframes per bin, unit0 =
+// the bin's first subframe, smp_off, narrow (+ slot, bits_off for K3); the workspaces whole.
+int order_search_group(const fhip_params &p, int n);
+hipError_t launch_order_search_bins(hipStream_t st, const fhip_params &p, const MultiBin &mb, const int32_t *smp,
+                                    const int32_t *coefs, const int32_t *shift, int32_t *opt_order, int32_t *fin,
+                                    const fhip_subframe_info *prep);
+int encode_group(const fhip_params &p, int n, bool order_known);
+hipError_t launch_encode_bins(hipStream_t st, const fhip_params &p, const MultiBin &mb, const int32_t *smp,
+                              const int32_t *coefs, const int32_t *shift, const int32_t *opt_order, const int32_t *fin,
+                              fhip_subframe_info *info, const fhip_subframe_info *prep, uint8_t *bits);
+
 // K4: whole frames on the device (encode.c:718-764, :800-917, :949-964):
 // frames [nframes][frame_stride] bytes, frame_bytes [nframes].
 hipError_t launch_assemble(hipStream_t st, const fhip_params &p, const int32_t *pcm, int nframes,

@@ -78,6 +78,32 @@ def test_vbs_dev_levels(oracle, decoder, level):
     assert len(set(int(v) * 8 // n for v in bs)) >= 5                       # most bins were used
 
 
+def test_vbs_dev_levels_a_launch_per_bin_subprocess():
+    """Batches of up to 2048 blocks send their thinly filled bins (four eighths and longer) through ONE order-search
+    launch and ONE K3 launch (k_order_search_bins / k_encode_bins); larger batches keep a launch per bin.
+    FHIP_VBS_MERGE_MAX=0 takes the tests' small batches the second way: the stream must be the oracle's either way
+    (test_vbs_dev_levels above runs the first)."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import flake_amd, test_gpu_vbs_dev as t
+        from oraclelib import Oracle, Decoder
+        o, d = Oracle(), Decoder()
+        for level in (9, 10, 11, 12):
+            p = flake_amd.level_params(level)
+            n = p.block_size
+            pcm = t.split_blocks(8, n, 2, 16, every=1)
+            pcm[7] = flake_amd.synth_pcm(1, n, 2, 16, first_frame=77)[0]
+            t.check_against_oracle(o, d, p, pcm, n, "level %%d, a launch per bin" %% level)
+        print("per bin ok")
+    """ % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, FHIP_VBS_MERGE_MAX="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "per bin ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("ch,bps,n", [(1, 16, 4096), (3, 24, 2048), (2, 24, 4096), (8, 16, 1024),
                                       (2, 16, 1000), (2, 8, 128)])
 def test_vbs_dev_shapes(oracle, decoder, ch, bps, n):

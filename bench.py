@@ -673,8 +673,9 @@ def vbs_case(dev_index, level, nblocks, steps, cpu=True, case=None, cases=None):
         "dominant_kernel": dom,
         "algorithmic_bytes": alg,
         "hbm_frac_step": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-        "note": "eight bins of equal piece length; K0 / K1 / K2 / K4 one launch over all bins, order search / "
-                "K3 per bin on three internal streams; no host synchronisation inside",
+        "note": "eight bins of equal piece length; K0 / K1 / K2 one launch over all bins; order search / K3 per bin (the "
+                "thinly filled 256-thread bins of a batch of <= 2048 blocks in one launch each) and K4 per lane on three "
+                "lanes: the handle's stream and two internal ones; no host synchronisation inside",
     }
     if cases and case and isinstance(cases.get(case), dict):
         # the order searches and K3 of all bins against their instruction issue (sums over the bins' instances)

@@ -2222,6 +2222,9 @@ bool fast_geometry(const fhip_params &p, int n, int *C, int *T)
         // workgroup of 1024 threads per subframe left the CU to one or two subframes at a time
         // (round 3: k_encode_pow2<3,1024> 84 us, <6,1024> 131 us per VBS batch of 1024 blocks)
         if (lg == 10 || lg == 11) { c = 12; t = 1 << (lg - 2); }
+        // 1536 (three eighths of a 4096 block): runs of 6 in 256 threads -- a thread per finest partition of the VBS presets;
+        // (3, 512) took 11.0 ns per subframe where 1024 / 2048 samples take 4.8 / 5.8 (tools/piece_cost.py)
+        if (lg == 9) { c = 6; t = 256; }
     } else if ((odd == 5 || odd == 7) && (lg == 9 || lg == 10)) {
         // 2560, 3584, 5120, 7168: five or seven eighths of a 4096 / 8192 block, the pieces
         // the VBS splitter (vbs.c:36-83) makes most often besides the plain power-of-two ones
@@ -2367,6 +2370,7 @@ hipError_t launch_encode(hipStream_t st, const fhip_params &p, const int32_t *sm
         case 30512: LAUNCH_FAST(3, 512); break;
         case 31024: LAUNCH_FAST(3, 1024); break;
         case 61024: LAUNCH_FAST(6, 1024); break;
+        case 60256: LAUNCH_FAST(6, 256); break;
         case 120256: LAUNCH_FAST(12, 256); break;
         case 120512: LAUNCH_FAST(12, 512); break;
         default: return hipErrorInvalidValue;

@@ -761,9 +761,13 @@ void k_vbs_plan(const int32_t *__restrict__ nfr, const int32_t *__restrict__ siz
     // carried from chunk to chunk) -- a thread that owned nblocks / 1024 consecutive blocks walked them by dependent
     // loads twice over: 123 us for 8192 blocks.
     __shared__ int32_t s_wtot[9][PLAN_NT / 64 + 1];
+    __shared__ int s_slot0[8];
+    __shared__ long long s_froff[8], s_stride[8];       // (the bins' constants by a piece's bin: an LDS read, not a select chain)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int eighth = block_size / 8;
+    const float inv_eighth = 1.0f / (float)eighth;      // a piece is 1 .. 8 whole eighths: len / eighth by one rounding
+    if (tid < 8) { s_slot0[tid] = bins.slot0[tid]; s_froff[tid] = bins.fr_off[tid]; s_stride[tid] = bins.stride[tid]; }
     int base[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) base[k] = 0;
@@ -787,7 +791,7 @@ void k_vbs_plan(const int32_t *__restrict__ nfr, const int32_t *__restrict__ siz
         for (int k = 0; k < 9; k++) c[k] = 0;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            bin[q] = (q < f) ? len[q] / eighth - 1 : -1;
+            bin[q] = (q < f) ? (int)((float)len[q] * inv_eighth + 0.5f) - 1 : -1;
 #pragma unroll
             for (int z = 0; z < 8; z++) c[z] += (z == bin[q]);
         }
@@ -827,10 +831,10 @@ void k_vbs_plan(const int32_t *__restrict__ nfr, const int32_t *__restrict__ siz
                     int j = 0;
 #pragma unroll
                     for (int z = 0; z < 8; z++) if (z == k) { j = run[z]; run[z]++; }
-                    const int slot = bins.slot0[k] + j;
+                    const int slot = s_slot0[k] + j;
                     order[run[8]++] = slot;
                     frame_src[slot] = pos * nch;
-                    src_off[slot] = bins.fr_off[k] + (long long)j * bins.stride[k];
+                    src_off[slot] = s_froff[k] + (long long)j * s_stride[k];
                     numbers[slot] = first_number + (uint32_t)pos;
                     pos += len[q];
                 }

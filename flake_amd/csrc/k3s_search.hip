@@ -477,6 +477,107 @@ __device__ __forceinline__ uint32_t wave_candidate_bits_s6(const uint32_t *__res
     return bits;
 }
 
+// The same for FOUR candidates by one wave, a 16-lane row each (candidate m0 + row): a lane takes four consecutive level-6
+// sums and evaluates its two nodes of level 5 and its node of level 4; levels 3 .. 0 are 15 nodes built by a pyramid inside
+// the row and handed to the row's lanes through a 16-entry heap.  (A wave per candidate spent ~240 instructions on 63
+// nodes, one per lane, most of them reductions and the level choice: eight candidates a wave in sequence behind
+// mm_search32's single pass -- a quarter of that kernel's instructions.)  Level totals are row sums; the level choice runs
+// per lane on the row's values.
+__device__ __forceinline__ void wave_candidates_s6x4(const uint32_t *__restrict__ s6all, const uint4 *__restrict__ part,
+                                                     unsigned long long *__restrict__ heap, const int32_t *__restrict__ tab,
+                                                     uint32_t *__restrict__ trial, int n, int m0, int max_order, int obits,
+                                                     int precision, int lane)
+{
+    const int row16 = lane & 48, ll = lane & 15;
+    const int m = m0 + (lane >> 4);
+    const bool live = m < max_order;
+    const int mc = live ? m : max_order - 1;
+    const int pm = tab[32 + mc];
+    const int pmin = pm & 0xFF, pmax = pm >> 8, ord = mc + 1;
+    uint32_t lb[9];
+#pragma unroll
+    for (int p = 0; p < 9; p++) lb[p] = 0;
+    uint32_t rice2;
+#define ROWSCAN(X_) do { X_ += dpp_u32<0x111>(X_); X_ += dpp_u32<0x112>(X_); X_ += dpp_u32<0x114>(X_); X_ += dpp_u32<0x118>(X_); } while (0)
+    {
+        // levels 8, 7, 6: eight partial totals (x: level 8, y: 7, z: 6, w: RICE2 flags by level bit)
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ll < 8) v = part[mc * 8 + ll];
+        uint32_t a = v.x, b = v.y, c = v.z, f = v.w;
+        ROWSCAN(a); ROWSCAN(b); ROWSCAN(c);
+        f |= dpp_u32<0x111>(f); f |= dpp_u32<0x112>(f); f |= dpp_u32<0x114>(f); f |= dpp_u32<0x118>(f);
+        lb[8] = (uint32_t)__shfl((int)a, row16 | 15, WAVE);
+        lb[7] = (uint32_t)__shfl((int)b, row16 | 15, WAVE);
+        lb[6] = (uint32_t)__shfl((int)c, row16 | 15, WAVE);
+        rice2 = (uint32_t)__shfl((int)f, row16 | 15, WAVE) & 0x1C0u;
+    }
+    {
+        const uint4 q = *reinterpret_cast<const uint4 *>(s6all + mc * 64 + 4 * ll);
+        const unsigned long long s5a = (unsigned long long)q.x + q.y, s5b = (unsigned long long)q.z + q.w;
+        const unsigned long long s4 = s5a + s5b;
+        // levels 3 .. 0 of the row: after step s, lanes = 0 mod 2^s hold node (ll >> s) of level 4 - s
+        unsigned long long v = s4;
+        unsigned long long *hp = heap + (row16 >> 4) * 16;
+#define HEAP_STORE(S_) do { if ((ll & ((1 << (S_)) - 1)) == 0) hp[(1 << (4 - (S_))) - 1 + (ll >> (S_))] = v; } while (0)
+        v += row_shl_u64<1>(v); HEAP_STORE(1);
+        v += row_shl_u64<2>(v); HEAP_STORE(2);
+        v += row_shl_u64<4>(v); HEAP_STORE(3);
+        v += row_shl_u64<8>(v); HEAP_STORE(4);
+#undef HEAP_STORE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long hs = hp[min(ll, 14)];
+        const unsigned long long total = hp[0];
+        auto node = [&](unsigned long long sum, int p, int jn, uint32_t *b) -> bool {
+            const int cnt = (n >> p) - (jn == 0 ? ord : 0);
+            if (total < 0xFFE00000ull) return rice_k_u32_nb((uint32_t)sum, (uint32_t)cnt, b) > 14;
+            return ((sum >> 32) ? rice_k_fast(sum, cnt, b) : rice_k_fast_u32((uint32_t)sum, cnt, b)) > 14;
+        };
+        uint32_t b5 = 0, b4 = 0, bh = 0;
+        bool big5 = false, big4 = false, bigh = false;
+        if (pmin <= 5 && pmax >= 5) {
+            uint32_t x, y;
+            big5 = node(s5a, 5, 2 * ll, &x);
+            big5 |= node(s5b, 5, 2 * ll + 1, &y);
+            b5 = x + y;
+        }
+        if (pmin <= 4 && pmax >= 4) big4 = node(s4, 4, ll, &b4);
+        const int p = ilog2_dev((uint32_t)(ll + 1));              // lanes 0 .. 14 of the row: node ll of the heap, level p
+        if (ll < 15 && p >= pmin && p <= pmax) bigh = node(hs, p, ll + 1 - (1 << p), &bh);
+        ROWSCAN(b5); ROWSCAN(b4); ROWSCAN(bh);
+        lb[5] = (uint32_t)__shfl((int)b5, row16 | 15, WAVE);
+        lb[4] = (uint32_t)__shfl((int)b4, row16 | 15, WAVE);
+#pragma unroll
+        for (int q2 = 0; q2 < 4; q2++) {
+            const uint32_t hi = (uint32_t)__shfl((int)bh, row16 | ((2 << q2) - 2), WAVE);
+            const uint32_t lo = q2 ? (uint32_t)__shfl((int)bh, row16 | ((1 << q2) - 2), WAVE) : 0u;
+            lb[q2] = hi - lo;
+        }
+        const uint32_t m5 = (uint32_t)(__ballot(big5) >> row16) & 0xFFFFu, m4 = (uint32_t)(__ballot(big4) >> row16) & 0xFFFFu;
+        const uint32_t mh = (uint32_t)(__ballot(bigh) >> row16) & 0xFFFFu;
+        if (m5) rice2 |= 1u << 5;
+        if (m4) rice2 |= 1u << 4;
+#pragma unroll
+        for (int q2 = 0; q2 < 4; q2++) {
+            const uint32_t lvl = ((1u << ((2 << q2) - 1)) - 1u) & ~((1u << ((1 << q2) - 1)) - 1u);
+            if (mh & lvl) rice2 |= 1u << q2;
+        }
+        __builtin_amdgcn_wave_barrier();                        // the heaps are reused by the wave's next four candidates
+    }
+#undef ROWSCAN
+    // rice.c:127-138, :157-171, :180-187
+    uint32_t best = 0, method = 0;
+#pragma unroll
+    for (int p = 0; p < 9; p++) {
+        const uint32_t b = lb[p] + 4u * (1u << p);
+        if (p >= pmin && p <= pmax && (p == pmin || b <= best)) { best = b; method = (rice2 >> p) & 1u; }
+    }
+    uint32_t bits = (uint32_t)(ord * obits + 2) + (uint32_t)(4 + 5 + ord * precision);
+    bits += best;
+    bits += method + 4u;
+    if (live && ll == 0) trial[m] = bits;
+}
+
 // ---------------------------------------------------------------------------
 // Round 4: the same FIRs for ALL 32 candidates in one pass on v_mfma_i32_32x32x32_i8 (256-thread instances)
 // ---------------------------------------------------------------------------
@@ -634,11 +735,19 @@ __device__ __forceinline__ bool mm_search32(const unsigned char *__restrict__ pl
     __syncthreads();
     if (*flagw != 0) return false;                            // workgroup-uniform: the general way does this subframe
     // ---- levels 5 .. 0 and the level choice per candidate, a wave each ----
-    for (int m = wv; m < max_order; m += NW) {
-        const int pm = tab[32 + m];
-        const uint32_t b = wave_candidate_bits_s6(s6all + m * 64, part + m * 8, heaps + wv * 128, n, m + 1, pm & 0xFF,
-                                                  pm >> 8, obits, precision, lane);
-        if (lane == 0) trial[m] = b;
+#ifndef FHIP_S6X4
+#define FHIP_S6X4 1
+#endif
+    if (FHIP_S6X4) {
+        for (int m0 = 4 * wv; m0 < max_order; m0 += 4 * NW)
+            wave_candidates_s6x4(s6all, part, heaps + wv * 128, tab, trial, n, m0, max_order, obits, precision, lane);
+    } else {
+        for (int m = wv; m < max_order; m += NW) {
+            const int pm = tab[32 + m];
+            const uint32_t b = wave_candidate_bits_s6(s6all + m * 64, part + m * 8, heaps + wv * 128, n, m + 1, pm & 0xFF,
+                                                      pm >> 8, obits, precision, lane);
+            if (lane == 0) trial[m] = b;
+        }
     }
     __syncthreads();
     return true;

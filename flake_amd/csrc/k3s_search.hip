@@ -528,9 +528,11 @@ __device__ __forceinline__ void wave_candidates_s6x4(const uint32_t *__restrict_
         __builtin_amdgcn_wave_barrier();
         const unsigned long long hs = hp[min(ll, 14)];
         const unsigned long long total = hp[0];
+        // (the straight-line 32-bit node form where every row of the wave allows it: a wave-uniform choice)
+        const bool small = __all(total < 0xFFE00000ull) != 0;
         auto node = [&](unsigned long long sum, int p, int jn, uint32_t *b) -> bool {
             const int cnt = (n >> p) - (jn == 0 ? ord : 0);
-            if (total < 0xFFE00000ull) return rice_k_u32_nb((uint32_t)sum, (uint32_t)cnt, b) > 14;
+            if (small) return rice_k_u32_nb((uint32_t)sum, (uint32_t)cnt, b) > 14;
             return ((sum >> 32) ? rice_k_fast(sum, cnt, b) : rice_k_fast_u32((uint32_t)sum, cnt, b)) > 14;
         };
         uint32_t b5 = 0, b4 = 0, bh = 0;

@@ -225,6 +225,133 @@ __device__ __forceinline__ uint32_t wave_candidate_bits(const uint32_t *__restri
 }
 
 
+// The same for TWO candidates by one wave, a 32-lane half each (round 4): a lane takes NL / 32 consecutive leaves of its
+// half's candidate and owns the nodes above them down to level 5 (fifteen that can be asked for: eight at level 8, four at 7,
+// two at 6, one at 5); levels 4 .. 0 are 31 nodes built through a 32-entry heap of the half.  A wave per candidate spends
+// ~350 of its ~510 instructions on the reductions, the heap trip and the level choice, whatever the number of nodes a lane
+// evaluates: a 128-thread workgroup (two waves, four candidates a round) ran two such passes per wave in sequence.
+// leaf / heap / ord / pmin / pmax are the HALF's (per lane); the result is the half's, in every lane of it.  The node forms
+// are chosen wave-uniformly (both halves small, or the general form for both).
+template <int NL>
+__device__ __forceinline__ uint32_t wave_candidate_bits_x2(const uint32_t *__restrict__ leaf,
+                                                           unsigned long long *__restrict__ heap, int n, int ord,
+                                                           int pmin, int pmax, int obits, int precision, int lane)
+{
+    constexpr int LPL = NL / 32;                // leaves per lane: 8 (256 leaves), 16
+    constexpr int L8 = NL / 256;                // leaves per level-8 node
+    static_assert(NL == 256 || NL == 512, "wave_candidate_bits_x2: 256 or 512 leaves");
+    const int hl = lane & 31, h32 = lane & 32;
+    uint32_t lf[LPL];
+#pragma unroll
+    for (int q = 0; q < LPL; q += 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(leaf + hl * LPL + q);
+        lf[q] = v.x; lf[q + 1] = v.y; lf[q + 2] = v.z; lf[q + 3] = v.w;
+    }
+    unsigned long long s8[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        s8[i] = 0;
+#pragma unroll
+        for (int q = 0; q < L8; q++) s8[i] += lf[i * L8 + q];
+    }
+    const unsigned long long s7[4] = {s8[0] + s8[1], s8[2] + s8[3], s8[4] + s8[5], s8[6] + s8[7]};
+    const unsigned long long s6[2] = {s7[0] + s7[1], s7[2] + s7[3]};
+    const unsigned long long s5 = s6[0] + s6[1];
+    const bool corners = !FHIP_NODE_FAST || __any(s5 >= 0xFFE00000ull) || __any(((n >> pmax) - ord) <= 0);
+    uint32_t lb[9];
+#pragma unroll
+    for (int p = 0; p < 9; p++) lb[p] = 0;
+    uint32_t rice2 = 0;                         // bit p: some parameter of level p is above 14
+    // inclusive scan inside each 32-lane half: four steps inside the rows, row 0 -> 1 and 2 -> 3
+#define HSCAN(X_) do { X_ += dpp_u32<0x111>(X_); X_ += dpp_u32<0x112>(X_); X_ += dpp_u32<0x114>(X_);       \
+                       X_ += dpp_u32<0x118>(X_); X_ += dpp_u32<0x142, 0xA>(X_); } while (0)
+    auto levels = [&](auto fast_c) {
+        constexpr bool FAST = decltype(fast_c)::value;
+        auto node = [&](unsigned long long sum, int p, int jn, uint32_t *b) -> bool {
+            const int cnt = (n >> p) - (jn == 0 ? ord : 0);
+            if constexpr (FAST) return rice_k_u32_nb((uint32_t)sum, (uint32_t)cnt, b) > 14;
+            else return ((sum >> 32) ? rice_k_fast(sum, cnt, b) : rice_k_fast_u32((uint32_t)sum, cnt, b)) > 14;
+        };
+        // ---- lane-local levels 8, 7, 6, 5 ----
+        {
+            uint32_t b8 = 0, b7 = 0, b6 = 0, b5 = 0;
+            bool k8 = false, k7 = false, k6 = false, k5 = false;
+            if (pmax >= 8 && pmin <= 8) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) { uint32_t b; k8 |= node(s8[i], 8, 8 * hl + i, &b); b8 += b; }
+            }
+            if (pmax >= 7 && pmin <= 7) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) { uint32_t b; k7 |= node(s7[i], 7, 4 * hl + i, &b); b7 += b; }
+            }
+            if (pmax >= 6 && pmin <= 6) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) { uint32_t b; k6 |= node(s6[i], 6, 2 * hl + i, &b); b6 += b; }
+            }
+            if (pmax >= 5 && pmin <= 5) k5 = node(s5, 5, hl, &b5);
+            HSCAN(b8); HSCAN(b7); HSCAN(b6); HSCAN(b5);
+            lb[8] = (uint32_t)__shfl((int)b8, h32 | 31, WAVE);
+            lb[7] = (uint32_t)__shfl((int)b7, h32 | 31, WAVE);
+            lb[6] = (uint32_t)__shfl((int)b6, h32 | 31, WAVE);
+            lb[5] = (uint32_t)__shfl((int)b5, h32 | 31, WAVE);
+            if ((uint32_t)(__ballot(k8) >> h32)) rice2 |= 1u << 8;
+            if ((uint32_t)(__ballot(k7) >> h32)) rice2 |= 1u << 7;
+            if ((uint32_t)(__ballot(k6) >> h32)) rice2 |= 1u << 6;
+            if ((uint32_t)(__ballot(k5) >> h32)) rice2 |= 1u << 5;
+        }
+        // ---- levels 4 .. 0: a 31-entry heap of the half (entry 2^p - 1 + j = node j of level p) ----
+        {
+            unsigned long long v = s5;
+#define HEAP_STORE(S_) do { if ((hl & ((1 << (S_)) - 1)) == 0) heap[(1 << (5 - (S_))) - 1 + (hl >> (S_))] = v; } while (0)
+            v += row_shl_u64<1>(v); HEAP_STORE(1);
+            v += row_shl_u64<2>(v); HEAP_STORE(2);
+            v += row_shl_u64<4>(v); HEAP_STORE(3);
+            v += row_shl_u64<8>(v); HEAP_STORE(4);
+            v += __shfl_down(v, 16, WAVE); HEAP_STORE(5);
+#undef HEAP_STORE
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int p = ilog2_dev((uint32_t)(hl + 1));             // lanes 0 .. 30 of the half: node hl, level p
+            uint32_t b = 0;
+            bool big = false;
+            const unsigned long long hs = heap[min(hl, 30)];
+            // (a half's total bounds every node of its heap: the 32-bit form only where both halves' totals allow it)
+            const bool small = FAST && __all(heap[0] < 0xFFE00000ull) != 0;
+            if (hl < 31 && p >= pmin && p <= pmax) {
+                const int jn = hl + 1 - (1 << p);
+                const int cnt = (n >> p) - (jn == 0 ? ord : 0);
+                if (small) big = rice_k_u32_nb((uint32_t)hs, (uint32_t)cnt, &b) > 14;
+                else big = ((hs >> 32) ? rice_k_fast(hs, cnt, &b) : rice_k_fast_u32((uint32_t)hs, cnt, &b)) > 14;
+            }
+            HSCAN(b);
+            const uint32_t bigm = (uint32_t)(__ballot(big) >> h32);
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const uint32_t hi = (uint32_t)__shfl((int)b, h32 | ((2 << q) - 2), WAVE);
+                const uint32_t lo = q ? (uint32_t)__shfl((int)b, h32 | ((1 << q) - 2), WAVE) : 0u;
+                lb[q] = hi - lo;
+                const uint32_t lvl = ((1u << ((2 << q) - 1)) - 1u) & ~((1u << ((1 << q) - 1)) - 1u);
+                if (bigm & lvl) rice2 |= 1u << q;
+            }
+            __builtin_amdgcn_wave_barrier();                        // the heaps are reused by the next candidates
+        }
+    };
+    if (!corners) levels(std::true_type{});
+    else levels(std::false_type{});
+#undef HSCAN
+    // rice.c:127-138, :157-171, :180-187
+    uint32_t best = 0, method = 0;
+#pragma unroll
+    for (int p = 0; p < 9; p++) {
+        const uint32_t b = lb[p] + 4u * (1u << p);
+        if (p >= pmin && p <= pmax && (p == pmin || b <= best)) { best = b; method = (rice2 >> p) & 1u; }
+    }
+    uint32_t bits = (uint32_t)(ord * obits + 2) + (uint32_t)(4 + 5 + ord * precision);
+    bits += best;
+    bits += method + 4u;
+    return bits;
+}
+
 // ---------------------------------------------------------------------------
 // The FIRs of an order SEARCH on the int8 matrix pipe (round 3; tools/mfma_i8_probe.hip priced it)
 // ---------------------------------------------------------------------------
@@ -393,12 +520,29 @@ __device__ __forceinline__ void mm_search(const unsigned char *__restrict__ plan
         }
         __syncthreads();
         // ---- rice.c:105-187 per candidate, a wave each ----
-        for (int m = wv; m < 16 && ct * 16 + m < max_order; m += NW) {
-            const int o1 = ct * 16 + m + 1;
-            const int pmm = tab[32 + ct * 16 + m];
-            const uint32_t b = wave_candidate_bits<T>(leaf + m * T, heaps + wv * 128, n, o1, pmm & 0xFF, pmm >> 8,
-                                                      obits, precision, lane);
-            if (lane == 0) trial[o1 - 1] = b;
+#ifndef FHIP_CAND_X2
+#define FHIP_CAND_X2 1
+#endif
+        if constexpr (FHIP_CAND_X2 && (T == 256 || T == 512)) {
+            // two candidates a wave (wave_candidate_bits_x2): a half whose candidate does not exist repeats the last one
+            const int lastm = min(16, max_order - ct * 16) - 1;
+            for (int m0 = 2 * wv; m0 <= lastm; m0 += 2 * NW) {
+                const int m = m0 + (lane >> 5);
+                const int mc = min(m, lastm);
+                const int o1 = ct * 16 + mc + 1;
+                const int pmm = tab[32 + ct * 16 + mc];
+                const uint32_t b = wave_candidate_bits_x2<T>(leaf + mc * T, heaps + wv * 128 + (lane >> 5) * 32, n, o1, pmm & 0xFF,
+                                                             pmm >> 8, obits, precision, lane);
+                if ((lane & 31) == 0 && m <= lastm) trial[o1 - 1] = b;
+            }
+        } else {
+            for (int m = wv; m < 16 && ct * 16 + m < max_order; m += NW) {
+                const int o1 = ct * 16 + m + 1;
+                const int pmm = tab[32 + ct * 16 + m];
+                const uint32_t b = wave_candidate_bits<T>(leaf + m * T, heaps + wv * 128, n, o1, pmm & 0xFF, pmm >> 8,
+                                                          obits, precision, lane);
+                if (lane == 0) trial[o1 - 1] = b;
+            }
         }
         __syncthreads();
     }
@@ -1204,12 +1348,25 @@ void order_search_body(const fhip_params &P, const int n, const int32_t *__restr
         if (leaf_mode) {
             if (l.misc[24 + par] != 0) { leaf_mode = false; continue; }      // workgroup-uniform
             // one wave per candidate (two candidates per wave where the workgroup has only two waves)
-            for (int m = wv; m < ng; m += NW) {
-                const int ord = l.rowi[m * 4 + 0] + 1;
-                const int pmm = l.rowi[m * 4 + 3];
-                const uint32_t b = wave_candidate_bits<NL>(rleaf + m * NL, l.sums + m * 128, n, ord, pmm & 0xFF,
-                                                           pmm >> 8, e.obits, e.precision, lane);
-                if (lane == 0) l.trial[ord - 1] = b;
+            if constexpr (FHIP_CAND_X2 && (NL == 256 || NL == 512)) {
+                // two candidates a wave (wave_candidate_bits_x2): a half whose candidate does not exist repeats the last one
+                for (int m0 = 2 * wv; m0 < ng; m0 += 2 * NW) {
+                    const int m = m0 + (lane >> 5);
+                    const int mc = min(m, ng - 1);
+                    const int ord = l.rowi[mc * 4 + 0] + 1;
+                    const int pmm = l.rowi[mc * 4 + 3];
+                    const uint32_t b = wave_candidate_bits_x2<NL>(rleaf + mc * NL, l.sums + mc * 128, n, ord, pmm & 0xFF,
+                                                                  pmm >> 8, e.obits, e.precision, lane);
+                    if ((lane & 31) == 0 && m < ng) l.trial[ord - 1] = b;
+                }
+            } else {
+                for (int m = wv; m < ng; m += NW) {
+                    const int ord = l.rowi[m * 4 + 0] + 1;
+                    const int pmm = l.rowi[m * 4 + 3];
+                    const uint32_t b = wave_candidate_bits<NL>(rleaf + m * NL, l.sums + m * 128, n, ord, pmm & 0xFF,
+                                                               pmm >> 8, e.obits, e.precision, lane);
+                    if (lane == 0) l.trial[ord - 1] = b;
+                }
             }
             STAMP(6 + 6 * (round & 3));
             break;

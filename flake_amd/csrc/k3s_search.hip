@@ -1348,8 +1348,10 @@ void order_search_body(const fhip_params &P, const int n, const int32_t *__restr
         if (leaf_mode) {
             if (l.misc[24 + par] != 0) { leaf_mode = false; continue; }      // workgroup-uniform
             // one wave per candidate (two candidates per wave where the workgroup has only two waves)
-            if constexpr (FHIP_CAND_X2 && (NL == 256 || NL == 512)) {
-                // two candidates a wave (wave_candidate_bits_x2): a half whose candidate does not exist repeats the last one
+            if constexpr (FHIP_CAND_X2 && NW == 2) {
+                // 128 threads: two candidates a wave (wave_candidate_bits_x2; a half whose candidate does not exist repeats the
+                // last one) -- with four waves the candidates of a round have a wave each already, and a LOG round of three
+                // took 11 % longer by halves (level 8)
                 for (int m0 = 2 * wv; m0 < ng; m0 += 2 * NW) {
                     const int m = m0 + (lane >> 5);
                     const int mc = min(m, ng - 1);
